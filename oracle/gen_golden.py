@@ -1,0 +1,68 @@
+"""Writes the committed fixtures (run in the build container, where /root/reference exists):
+
+  weights/tandem_va.tdmw            trained weights recovered from tandem/exported/tandem_512x320/model.pt
+  tests/golden/mvsnet_<name>.npz    inputs at the DrMvsnet boundary + the REFERENCE model's outputs
+
+and checks, while doing so, that oracle/mvsnet_oracle.py reproduces the reference bit-for-bit on them.
+Usage: python oracle/gen_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import mvsnet_oracle as O  # noqa: E402
+from oracle import ref_model, scene  # noqa: E402
+from tandem_amd import weights as Wt  # noqa: E402
+
+CASES = [  # name, H, W, V, planes, discard, weights
+    ("v3_64x96", 64, 96, 3, (48, 32, 8), 2.5, "trained"),
+    ("v7_64x96", 64, 96, 7, (48, 32, 8), 10.0, "trained"),
+    ("v3_64x64_d4", 64, 64, 3, (48, 4, 4), 10.0, "trained"),
+    ("v4_96x128_rand", 96, 128, 4, (48, 32, 8), 5.0, "random"),
+]
+
+
+def main():
+    torch.set_num_threads(8)
+    os.makedirs(os.path.join(ROOT, "weights"), exist_ok=True)
+    os.makedirs(os.path.join(ROOT, "tests/golden"), exist_ok=True)
+    sd = ref_model.exported_state_dict()
+    blob = os.path.join(ROOT, "weights/tandem_va.tdmw")
+    Wt.write_blob(blob, sd, depth_num=(48, 32, 8))
+    print("wrote", blob, os.path.getsize(blob))
+    for name, H, Wd, V, planes, disc, wsrc in CASES:
+        if wsrc == "trained":
+            state = {k: v.numpy() for k, v in sd.items() if v.dtype.is_floating_point}
+        else:
+            state = Wt.random_state(planes, seed=7)
+        net, cva = ref_model.build(planes, state)
+        win = scene.make_window(H, Wd, V, seed=len(name))
+        w = O.Weights(dict(depth_num=planes, interval_ratio=(1.0, 0.5, 0.25), view_aggregation=True,
+                           base_channels=8), state)
+        image, Ks, c2w = O.preprocess(win["bgrs"], win["K"], win["c2ws"], win["ref_index"])
+        ref = ref_model.run(net, cva, image, Ks, c2w, win["depth_min"], win["depth_max"], disc)
+        mine = O.forward(w, win["bgrs"], win["K"], win["c2ws"], win["ref_index"], win["depth_min"],
+                         win["depth_max"], disc)
+        save = dict(bgrs=np.stack(win["bgrs"]), K=win["K"], c2ws=win["c2ws"], ref_index=win["ref_index"],
+                    depth_min=np.float32(win["depth_min"]), depth_max=np.float32(win["depth_max"]),
+                    discard=np.float32(disc), planes=np.array(planes), weights=wsrc, gt_depth=win["gt_depth"])
+        for s in (1, 2, 3):
+            for k in ("depth", "confidence", "depth_dense", "confidence_dense"):
+                r = getattr(ref[s - 1], k)[0].numpy()
+                m = mine["stages"][s][k].numpy()
+                err = float(np.abs(r - m).max())
+                same = np.array_equal(r, m)
+                print(f"{name} stage{s} {k:17s} max|ref-oracle|={err:.3e} bit-identical={same}")
+                save[f"ref_s{s}_{k}"] = r
+        gt = win["gt_depth"]
+        d3 = getattr(ref[2], "depth_dense")[0].numpy()
+        print(f"{name}: mean|depth_dense-gt| = {np.abs(d3 - gt).mean():.4f} m")
+        np.savez_compressed(os.path.join(ROOT, f"tests/golden/mvsnet_{name}.npz"), **save)
+
+
+if __name__ == "__main__":
+    main()
