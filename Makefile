@@ -1,0 +1,24 @@
+# Builds libdr_mi355x.so (HIP kernels + engines + C ABI, gfx950 only) and the CPU oracle library.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+CSRC  := tandem_amd/csrc
+LIB   := tandem_amd/libdr_mi355x.so
+# -ffp-contract=off: the TSDF path is compared bit-for-bit with the C oracle (no FMA contraction on either side)
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-pass-failed
+OBJS := $(CSRC)/dr_mvsnet.o $(CSRC)/dr_fusion.o
+
+all: $(LIB) oracle/libtsdf_oracle.so
+
+$(CSRC)/dr_mvsnet.o: $(CSRC)/dr_mvsnet.hip $(CSRC)/conv_mfma.h $(CSRC)/mvs_kernels.h $(CSRC)/dr_common.h include/dr_mi355x.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(CSRC)/dr_fusion.o: $(CSRC)/dr_fusion.hip $(CSRC)/dr_common.h include/dr_mi355x.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@ -lpthread
+
+oracle/libtsdf_oracle.so: oracle/tsdf_oracle.c
+	gcc -O2 -std=c99 -fPIC -shared -ffp-contract=off -fno-fast-math $< -o $@ -lm
+
+clean:
+	rm -f $(OBJS) $(LIB) oracle/libtsdf_oracle.so
+.PHONY: all clean

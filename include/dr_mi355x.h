@@ -1,0 +1,156 @@
+/* dr_mi355x.h -- C ABI of libdr_mi355x.so: the MI355X-native drop-in for TANDEM's libdr
+ * operator API (DrMvsnet + DrFusion).  Plain pointers and sizes only; no torch / HIP types.
+ *
+ * Every entry point below replaces one member of the reference's C++ interface
+ *   tandem/libdr/dr_mvsnet/src/dr_mvsnet/dr_mvsnet.h   (class DrMvsnet, DrMvsnetOutput)
+ *   tandem/libdr/dr_fusion/src/dr_fusion/dr_fusion.h   (class DrFusion, DrFusionOptions, DrMesh)
+ * The header-compatible C++ shim classes that forward to this ABI live in
+ * tandem_amd/libdr/{dr_mvsnet.h,dr_fusion.h}; INTEGRATION.md shows how TANDEM links them.
+ *
+ * Error convention: the reference prints and exit()s on protocol violations and has no return
+ * codes (dr_mvsnet.cpp:100-102,156-157; tsdf_volume.cu:520-524).  The C ABI returns an int
+ * status instead (0 = ok) and keeps the message in dr_last_error(); the C++ shim reproduces the
+ * reference's exit(EXIT_FAILURE) behaviour on non-zero status.
+ */
+#ifndef DR_MI355X_H
+#define DR_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  DR_OK = 0,
+  DR_ERR_ARG = 1,       /* bad argument (null pointer, aliasing views, unsupported size) */
+  DR_ERR_PROTOCOL = 2,  /* call-order violation (reference: exit(EXIT_FAILURE)) */
+  DR_ERR_DEVICE = 3,    /* HIP error / no GPU */
+  DR_ERR_IO = 4,        /* weight blob missing or malformed */
+  DR_ERR_CAPACITY = 5,  /* hash table / block pool exhausted (reference: KERNEL_ABORT trap, heap.cu:16) */
+  DR_ERR_UNSUPPORTED = 6
+};
+
+/* Thread-local message of the last failing call in this thread ("" if none). */
+const char *dr_last_error(void);
+/* Library version string, e.g. "dr_mi355x 0.1 gfx950". */
+const char *dr_version(void);
+
+/* ------------------------------------------------------------------ DrMvsnet */
+typedef struct drm_s drm_t;
+
+/* DrMvsnet::DrMvsnet(char const* filename)                      dr_mvsnet.h:38, dr_mvsnet.cpp:20-26
+ * `weights_path` names a TDMW blob (tandem_amd/weights.py) instead of a TorchScript archive. */
+int drm_create(const char *weights_path, int device, drm_t **out);
+/* DrMvsnet::~DrMvsnet(): waits for pending work, joins the worker  dr_mvsnet.cpp:28-38 */
+void drm_destroy(drm_t *h);
+/* DrMvsnet::CallAsync(...)                                      dr_mvsnet.h:43-53, dr_mvsnet.cpp:125-283
+ * bgrs[v] -> H*W*3 u8 interleaved BGR; K9 row-major full-res intrinsics; c2ws[v] -> 16 floats
+ * row-major camera-to-world.  Inputs are copied before return.  Blocks while the previous call
+ * is still being processed ("Blocking for last input. Non-blocking for this input").
+ * Returns DR_ERR_ARG if two bgr / c2w pointers alias (reference: exit, :153-160). */
+int drm_call_async(drm_t *h, int height, int width, int view_num, int ref_index,
+                   const uint8_t *const *bgrs, const float *K9, const float *const *c2ws,
+                   float depth_min, float depth_max, float discard_percentage);
+/* DrMvsnet::Ready()  non-blocking, 1 = no unprocessed input      dr_mvsnet.h:62, dr_mvsnet.cpp:54 */
+int drm_ready(drm_t *h);
+/* DrMvsnet::Wait()   blocking                                    dr_mvsnet.h:59, dr_mvsnet.cpp:109-119 */
+int drm_wait(drm_t *h);
+/* DrMvsnet::GetResult()  blocking; fills four caller-owned H*W float arrays (the members of
+ * DrMvsnetOutput, dr_mvsnet.h:12-34).  A second call without a new drm_call_async returns
+ * DR_ERR_PROTOCOL (reference: exit, dr_mvsnet.cpp:100-103). */
+int drm_get_result(drm_t *h, float *depth, float *confidence, float *depth_dense, float *confidence_dense);
+
+/* --- device-resident / measurement / introspection hooks (no reference counterpart) --- */
+/* Upload a window (same arguments as drm_call_async) and keep it resident in HBM. Synchronous. */
+int drm_upload(drm_t *h, int height, int width, int view_num, int ref_index, const uint8_t *const *bgrs,
+               const float *K9, const float *const *c2ws, float depth_min, float depth_max,
+               float discard_percentage);
+/* Enqueue `iters` complete forwards (pre-process .. edge filter) of the resident window on the
+ * engine stream; returns after a stream synchronise.  ms_total (may be NULL) = hipEvent time. */
+int drm_forward(drm_t *h, int iters, float *ms_total);
+/* Copy the last forward's stage-3 outputs to host (same four arrays as drm_get_result). */
+int drm_download(drm_t *h, float *depth, float *confidence, float *depth_dense, float *confidence_dense);
+/* Unfiltered depth / confidence of stage 1..3 (h_s*w_s floats each). */
+int drm_get_stage_output(drm_t *h, int stage, float *depth, float *confidence);
+/* Named internal tensor of the last forward, copied to host in its device layout (channels-last).
+ * n_max = capacity of out in floats; *n = element count; dims[4] = {D|V, H, W, C}. */
+int drm_get_tensor(drm_t *h, const char *name, float *out, size_t n_max, size_t *n, int dims[4]);
+/* Per-kernel timing of one forward (hipEvents around every launch). names: '\n'-separated. */
+int drm_profile(drm_t *h, char *names, size_t names_cap, float *ms, int cap, int *count);
+/* Algorithmic work of one forward of the resident window (SURVEY.md 8d "layer-boundary" model). */
+int drm_work(drm_t *h, double *flops, double *bytes);
+
+/* Kernel unit-test hook: run one convolution layer through the engine's packer + MFMA kernel.
+ * in  : (D,H,W,Cin) channels-last, host.  weight: torch layout (Cout,Cin,kd,kh,kw) for conv,
+ * (Cin,Cout,kd,kh,kw) for transposed.  scale/bias: per-Cout affine applied before ReLU (may be NULL).
+ * add : optional residual, output-shaped (or (D,H/2,W/2,Cout) when add_up2).  out: (Do,Ho,Wo,Cout). */
+int drm_debug_conv(int device, const float *in, int D, int H, int W, int Cin, const float *weight, int Cout,
+                   int kd, int kh, int kw, int sd, int sh, int sw, int transposed, const float *scale,
+                   const float *bias, int relu, const float *add, int add_up2, float *out, int out_dims[3]);
+
+/* ------------------------------------------------------------------ DrFusion */
+/* struct DrFusionOptions                                         dr_fusion.h:18-36 (same field order) */
+typedef struct {
+  float voxel_size;
+  int num_buckets;
+  int bucket_size;
+  int num_blocks;
+  int block_size;
+  int max_sdf_weight;
+  float truncation_distance;
+  float max_sensor_depth;
+  float min_sensor_depth;
+  int num_render_streams;
+  float fx, fy, cx, cy;
+  int height, width;
+} drf_options_t;
+
+typedef struct drf_s drf_t;
+
+/* DrFusion::DrFusion(DrFusionOptions const&)                     dr_fusion.h:46, dr_fusion.cpp:8-38 */
+int drf_create(const drf_options_t *opt, int device, drf_t **out);
+/* DrFusion::~DrFusion()                                          dr_fusion.cpp:41-46 */
+void drf_destroy(drf_t *h);
+/* DrFusion::IntegrateScanAsync(bgr, depth, pose)                 dr_fusion.h:50, tsdf_volume.cu:515-598
+ * H*W*3 u8 BGR, H*W f32 metres (0 = invalid), 16-float row-major cam-to-world; inputs are copied
+ * to pinned memory before return.  Wrong call order -> DR_ERR_PROTOCOL (reference: exit). */
+int drf_integrate_scan_async(drf_t *h, const uint8_t *bgr, const float *depth, const float *pose16);
+/* DrFusion::RenderAsync(std::vector<float const*>)               dr_fusion.h:52, tsdf_volume.cu:634-700
+ * n must equal num_render_streams (may be 0). */
+int drf_render_async(drf_t *h, const float *const *poses16, int n);
+/* DrFusion::GetRenderResult(bgr, depth)                          dr_fusion.h:54, tsdf_volume.cu:702-737
+ * Fills n library-owned pinned pointers, valid until the next drf_get_render_result. */
+int drf_get_render_result(drf_t *h, uint8_t **bgr, float **depth, int n);
+/* DrFusion::ExtractMeshAsync / GetMeshSync / SaveMeshToFile / GetMesh   dr_fusion.h:56-62
+ * Marching cubes is a SURVEY 8(f) "next" row: round 1 returns DR_ERR_UNSUPPORTED. */
+int drf_extract_mesh_async(drf_t *h, const float lower[3], const float upper[3]);
+int drf_get_mesh_sync(drf_t *h, size_t num_max, size_t *num, float *vert, float *cols);
+int drf_save_mesh(drf_t *h, const char *filename, const float lower[3], const float upper[3]);
+/* DrFusion::Synchronize()                                        dr_fusion.h:64 */
+int drf_synchronize(drf_t *h);
+
+/* --- introspection / measurement hooks (no reference counterpart) --- */
+/* Counters: [0] allocated blocks, [1] voxels updated by the last scan (band + carve),
+ * [2] voxels updated in total, [3] round-trip voxel mismatches (must stay 0). */
+int drf_stats(drf_t *h, uint64_t out[4]);
+/* Canonical dump for bit-exact comparison: coords[3*i..] block coordinates, voxels[4096*i..] the
+ * 512 8-byte voxels {f32 sdf, u8 b,g,r, u8 weight} of block i in index order x*64+y*8+z. */
+int drf_export_blocks(drf_t *h, int max_blocks, int32_t *coords, uint8_t *voxels, int *n);
+/* Integrate scans already resident in HBM (bench path): d_* are device pointers. */
+int drf_integrate_device(drf_t *h, const void *d_bgr, const void *d_depth, const float *pose16);
+/* Device-side scratch allocation helpers so a host without a HIP runtime binding can stage inputs. */
+int dr_device_alloc(int device, size_t bytes, void **dptr);
+int dr_device_free(void *dptr);
+int dr_memcpy_h2d(void *dptr, const void *src, size_t bytes);
+int dr_memcpy_d2h(void *dst, const void *dptr, size_t bytes);
+/* Time `iters` back-to-back integrations of `nscans` resident scans with hipEvents on the
+ * integration stream.  ms / kernel_ms (integrate kernel only) may be NULL. */
+int drf_bench_integrate(drf_t *h, const void *d_bgr, const void *d_depth, const float *poses16, int nscans,
+                        float *ms, float *kernel_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DR_MI355X_H */

@@ -1,0 +1,375 @@
+// conv_mfma.h -- the one convolution kernel of the depth pipeline: a tap-table implicit GEMM on
+// the fp32 matrix cores of gfx950 (v_mfma_f32_16x16x4_f32, exact fp32 == an fmaf chain).
+//
+// It replaces every dense contraction the reference hands to cuDNN through ATen
+// (FeatureNet.forward cva_mvsnet/models/module.py:496-531, CostRegNet.forward module.py:577-600):
+// Conv2d 3x3 / 5x5-stride-2 / 1x1, Conv3d 3^3 (stride 1, 2, (1,2,2)) and ConvTranspose3d 3^3
+// stride 2 (as 8 output-parity classes), with the eval-mode BatchNorm folded into a per-channel
+// scale/bias, ReLU, the UNet residual adds and FeatureNet's nearest-upsample-add fused in the epilogue.
+//
+// Data layout: channels-last everywhere, tensor = (D|V, H, W, C) fp32.
+//
+// GEMM mapping (one wave = 64 lanes):
+//   A (16 x 4)  = weights : row i = output row (channel), 4 K-values        -> lane (i = l&15, g = l>>4)
+//   B (4 x 16)  = inputs  : col j = output position (16 consecutive along W) -> lane (j = l&15, g = l>>4)
+//   D (16 x 16) : lane holds rows 4g..4g+3 of column j  => one float4 channels-last store per lane.
+// K is the flattened (tap, cin) axis, walked in chunks of 16: each lane fetches ONE float4 (4
+// consecutive cin of "its" tap) from the LDS-staged input tile and ONE float4 of pre-packed weights,
+// and feeds four back-to-back MFMAs (k-order inside the dot product is free, so lane-group g owns
+// K = 16q+4g .. +3).  Taps are a runtime table of LDS offsets, which is what lets the same kernel do
+// strided convs, transposed-conv parity classes and the two "shifted-weights" modes:
+//   XPAIR: a Cout=8 layer is run as a stride-(1,1,2) conv with a 4-wide kernel and 16 output rows
+//          (8 channels x 2 adjacent x) on the output viewed as (D,H,W/2,16): 75 % MFMA row use, not 50 %.
+//   X8   : the Cout=1 `prob` layer is run as 8 x-shifts per column on the output viewed as (D,H,W/8,8).
+#pragma once
+#include <algorithm>
+#include <functional>
+
+#include "dr_common.h"
+
+namespace dr {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+  const float *in;
+  float *out;
+  const float4 *wpk;
+  const float *scale, *bias, *add;
+  const int *tapoff;
+  int inD, inH, inW, inC;
+  int outD, outH, outW, outC;
+  int nPD, nPH, nPW;
+  int sz, sy, sx, pz, py, px;
+  int omz, omy, omx, ooz, ooy, oox;
+  int TZ, TY, TXT, TZI, TYI, TXI;
+  int NU, npass, rows_valid, relu, add_mode, addH, addW;
+  int tilesD, tilesH, tilesW;
+};
+
+constexpr int kConvThreads = 256;
+constexpr int kPT = 4;  // position tiles (16 positions each) per wave
+constexpr size_t kConvMaxLds = 160 * 1024;  // gfx950: 160 KiB LDS per CU, one workgroup may take all of it
+
+template <int CI, int CT>
+__global__ __launch_bounds__(kConvThreads) void k_conv(const ConvArgs a) {
+  extern __shared__ float4 lds4[];
+  float *lds = reinterpret_cast<float *>(lds4);
+  constexpr int CIS = CI + 4;  // LDS floats per staged position (+4: spreads b128 reads over bank slots)
+  constexpr int TPC = 16 / CI; // taps per 16-wide K chunk
+  constexpr int C4 = CI / 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+
+  int b = blockIdx.x;
+  const int tw = b % a.tilesW;
+  b /= a.tilesW;
+  const int th = b % a.tilesH, td = b / a.tilesH;
+  const int pz0 = td * a.TZ, py0 = th * a.TY, px0 = tw * a.TXT * 16;
+  const int iz0 = pz0 * a.sz - a.pz, iy0 = py0 * a.sy - a.py, ix0 = px0 * a.sx - a.px;
+
+  int base[kPT];
+#pragma unroll
+  for (int pt = 0; pt < kPT; ++pt) {
+    const int tau = wave * kPT + pt;
+    const int xt = tau % a.TXT, yt = (tau / a.TXT) % a.TY, zt = tau / (a.TXT * a.TY);
+    base[pt] = ((zt * a.sz) * a.TYI + yt * a.sy) * a.TXI + (xt * 16 + j) * a.sx;
+  }
+  const int sub = (4 * g) / CI, coff = (4 * g) % CI;
+
+  floatx4 acc[CT][kPT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int pt = 0; pt < kPT; ++pt) acc[ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  const int NP = a.TZI * a.TYI * a.TXI;
+  for (int p = 0; p < a.npass; ++p) {
+    // ---- stage CI channels of the input halo tile into LDS (zero outside the tensor) ----
+    for (int e = tid; e < NP * C4; e += kConvThreads) {
+      const int pos = e / C4, c4 = e - pos * C4;
+      const int x = pos % a.TXI, t = pos / a.TXI;
+      const int y = t % a.TYI, z = t / a.TYI;
+      const int gz = iz0 + z, gy = iy0 + y, gx = ix0 + x;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gz >= 0 && gz < a.inD && gy >= 0 && gy < a.inH && gx >= 0 && gx < a.inW)
+        v = *reinterpret_cast<const float4 *>(a.in + (((size_t)gz * a.inH + gy) * a.inW + gx) * a.inC + p * CI + c4 * 4);
+      *reinterpret_cast<float4 *>(lds + pos * CIS + c4 * 4) = v;
+    }
+    __syncthreads();
+    // ---- K loop over (tap-group) chunks of this channel pass ----
+    const float4 *wp = a.wpk + (size_t)p * a.NU * CT * 64 + lane;
+    for (int u = 0; u < a.NU; ++u) {
+      float4 av[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) av[ct] = wp[(u * CT + ct) * 64];
+      const int toff = a.tapoff[u * TPC + sub];
+      float4 bv[kPT];
+#pragma unroll
+      for (int pt = 0; pt < kPT; ++pt)
+        bv[pt] = *reinterpret_cast<const float4 *>(lds + (base[pt] + toff) * CIS + coff);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < kPT; ++pt) {
+          acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct].x, bv[pt].x, acc[ct][pt], 0, 0, 0);
+          acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct].y, bv[pt].y, acc[ct][pt], 0, 0, 0);
+          acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct].z, bv[pt].z, acc[ct][pt], 0, 0, 0);
+          acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct].w, bv[pt].w, acc[ct][pt], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: folded BN, ReLU, residual / upsample add, one float4 (4 channels) per lane ----
+#pragma unroll
+  for (int pt = 0; pt < kPT; ++pt) {
+    const int tau = wave * kPT + pt;
+    const int xt = tau % a.TXT, yt = (tau / a.TXT) % a.TY, zt = tau / (a.TXT * a.TY);
+    const int qz = pz0 + zt, qy = py0 + yt, qx = px0 + xt * 16 + j;
+    if (qz >= a.nPD || qy >= a.nPH || qx >= a.nPW) continue;
+    const int oz = qz * a.omz + a.ooz, oy = qy * a.omy + a.ooy, ox = qx * a.omx + a.oox;
+    const size_t obase = (((size_t)oz * a.outH + oy) * a.outW + ox) * a.outC;
+    size_t abase = obase;
+    if (a.add_mode == 2) abase = (((size_t)oz * a.addH + (oy >> 1)) * a.addW + (ox >> 1)) * a.outC;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int c0 = ct * 16 + 4 * g;
+      if (c0 >= a.rows_valid) continue;
+      const float4 sc = *reinterpret_cast<const float4 *>(a.scale + c0);
+      const float4 bi = *reinterpret_cast<const float4 *>(a.bias + c0);
+      float4 v;
+      v.x = acc[ct][pt][0] * sc.x + bi.x;
+      v.y = acc[ct][pt][1] * sc.y + bi.y;
+      v.z = acc[ct][pt][2] * sc.z + bi.z;
+      v.w = acc[ct][pt][3] * sc.w + bi.w;
+      if (a.relu) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      if (a.add_mode) {
+        const float4 r = *reinterpret_cast<const float4 *>(a.add + abase + c0);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      *reinterpret_cast<float4 *>(a.out + obase + c0) = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host side: logical layer description -> packed weights, tap table, tile plan, launches.
+
+enum ConvMode { CONV_NORMAL = 0, CONV_XPAIR = 1, CONV_X8 = 2 };
+
+struct ConvLayer {  // logical description (torch semantics)
+  int Cin = 0, Cout = 0;
+  int kd = 1, kh = 1, kw = 1;
+  int sd = 1, sh = 1, sw = 1;
+  bool transposed = false;          // ConvTranspose3d(k=3, pad=1, output_padding = stride-1)
+  const float *weight = nullptr;    // (Cout,Cin,kd,kh,kw) or transposed (Cin,Cout,kd,kh,kw)
+  std::vector<float> scale, bias;   // per Cout (folded BN / conv bias); empty -> 1 / 0
+  bool relu = false;
+};
+
+struct ConvLaunch {
+  ConvArgs args;
+  int ci, ct;
+  int grid;
+  size_t lds_bytes;
+  double flops;  // useful (algorithmic) flops of this launch
+};
+
+struct DimTaps {               // per-axis decomposition of one launch
+  std::vector<int> t, off;     // kernel index, input offset (>= 0)
+  int s = 1, p = 0, om = 1, oo = 0, npos = 0;
+};
+
+// Per-axis tap lists.  Normal conv: in = pos*s - pad + t.  Transposed stride 2 (parity class c):
+// out[2m] = x[m] w[1];  out[2m+1] = x[m] w[2] + x[m+1] w[0].  Transposed stride 1: out[o] = sum_t x[o+1-t] w[t].
+inline std::vector<DimTaps> axis_classes(int k, int s, bool transposed, int in_size) {
+  std::vector<DimTaps> r;
+  if (!transposed) {
+    DimTaps d;
+    for (int t = 0; t < k; ++t) { d.t.push_back(t); d.off.push_back(t); }
+    d.s = s; d.p = k / 2; d.npos = (in_size + 2 * (k / 2) - k) / s + 1;
+    r.push_back(d);
+  } else if (k == 1) {
+    DimTaps d; d.t = {0}; d.off = {0}; d.npos = in_size; r.push_back(d);
+  } else if (s == 1) {
+    DimTaps d;
+    for (int t = 0; t < k; ++t) { d.t.push_back(t); d.off.push_back(2 - t); }
+    d.p = 1; d.npos = in_size;
+    r.push_back(d);
+  } else {
+    DimTaps e; e.t = {1}; e.off = {0}; e.om = 2; e.oo = 0; e.npos = in_size; r.push_back(e);
+    DimTaps o; o.t = {2, 0}; o.off = {0, 1}; o.om = 2; o.oo = 1; o.npos = in_size; r.push_back(o);
+  }
+  return r;
+}
+
+struct ConvPlanOut {
+  std::vector<ConvLaunch> launches;
+  int outD, outH, outW;
+};
+
+struct DeviceArena {  // owns small device buffers created while planning (weights, tables)
+  std::vector<void *> ptrs;
+  template <class T>
+  T *upload(const std::vector<T> &h) {
+    T *d = dalloc<T>(h.size());
+    DR_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    ptrs.push_back(d);
+    return d;
+  }
+  ~DeviceArena() { for (void *p : ptrs) (void)hipFree(p); }
+};
+
+inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in, int inD, int inH, int inW, int inC,
+                             float *out, const float *add, int add_mode, DeviceArena &arena) {
+  if (L.Cin % 4 != 0 || inC < L.Cin) fail(DR_ERR_ARG, "plan_conv: Cin=%d must be a multiple of 4 (tensor C=%d)", L.Cin, inC);
+  const int CI = L.Cin >= 16 ? 16 : L.Cin;  // 4, 8 or 16
+  if (L.Cin % CI != 0 || (CI != 4 && CI != 8 && CI != 16)) fail(DR_ERR_ARG, "plan_conv: unsupported Cin=%d", L.Cin);
+  const int npass = L.Cin / CI, TPC = 16 / CI, CIS = CI + 4;
+  auto cz = axis_classes(L.kd, L.sd, L.transposed, inD);
+  auto cy = axis_classes(L.kh, L.sh, L.transposed, inH);
+  auto cx = axis_classes(L.kw, L.sw, L.transposed, inW);
+  ConvPlanOut R;
+  R.outD = L.transposed ? inD * L.sd : cz[0].npos;
+  R.outH = L.transposed ? inH * L.sh : cy[0].npos;
+  R.outW = L.transposed ? inW * L.sw : cx[0].npos;
+  int rows, rows_valid, outWv = R.outW, outCv;
+  if (mode == CONV_XPAIR) {
+    if (L.transposed || L.sw != 1 || L.Cout != 8 || (R.outW & 1)) fail(DR_ERR_ARG, "XPAIR needs Cout=8, stride 1, even W");
+    rows = 16; rows_valid = 16; outWv = R.outW / 2; outCv = 16;
+  } else if (mode == CONV_X8) {
+    if (L.transposed || L.sw != 1 || L.Cout != 1 || (R.outW & 7)) fail(DR_ERR_ARG, "X8 needs Cout=1, stride 1, W%%8==0");
+    rows = 16; rows_valid = 8; outWv = R.outW / 8; outCv = 8;
+  } else {
+    rows = cdiv(L.Cout, 16) * 16; rows_valid = L.Cout; outCv = L.Cout;
+    if (L.Cout % 4) fail(DR_ERR_ARG, "plan_conv: Cout=%d must be a multiple of 4", L.Cout);
+  }
+  const int CT = rows / 16;
+  if (!((CI == 4 && CT == 1) || (CI == 8 && CT <= 2) || (CI == 16 && (CT == 1 || CT == 2 || CT == 4))))
+    fail(DR_ERR_ARG, "plan_conv: no kernel instance for CI=%d CT=%d", CI, CT);
+  const int shifts = mode == CONV_XPAIR ? 2 : (mode == CONV_X8 ? 8 : 1);
+
+  // per-row epilogue affine
+  std::vector<float> sc(rows, 1.f), bi(rows, 0.f);
+  for (int r = 0; r < rows_valid; ++r) {
+    const int c = mode == CONV_NORMAL ? r : (mode == CONV_XPAIR ? (r & 7) : 0);
+    if (!L.scale.empty()) sc[r] = L.scale[c];
+    if (!L.bias.empty()) bi[r] = L.bias[c];
+  }
+  const float *d_scale = arena.upload(sc), *d_bias = arena.upload(bi);
+
+  auto weight_at = [&](int co, int ci, int tz, int ty, int tx) -> float {
+    if (!L.transposed) return L.weight[((((size_t)co * L.Cin + ci) * L.kd + tz) * L.kh + ty) * L.kw + tx];
+    return L.weight[((((size_t)ci * L.Cout + co) * L.kd + tz) * L.kh + ty) * L.kw + tx];
+  };
+
+  for (const DimTaps &Z : cz) for (const DimTaps &Y : cy) for (const DimTaps &X0 : cx) {
+    DimTaps X = X0;
+    if (shifts > 1) {  // widen the x taps: in = pos*shifts - pad + t', t' in [0, kw + shifts - 1)
+      X.t.clear(); X.off.clear();
+      for (int t = 0; t < L.kw + shifts - 1; ++t) { X.t.push_back(t); X.off.push_back(t); }
+      X.s = shifts; X.npos = outWv;
+    }
+    const int ntz = (int)Z.t.size(), nty = (int)Y.t.size(), ntx = (int)X.t.size();
+    const int ntaps = ntz * nty * ntx;
+    const int NU = cdiv(ntaps, TPC);
+    int exz = 0, exy = 0, exx = 0;
+    for (int o : Z.off) exz = std::max(exz, o + 1);
+    for (int o : Y.off) exy = std::max(exy, o + 1);
+    for (int o : X.off) exx = std::max(exx, o + 1);
+
+    // ---- tile plan: 16 position tiles (4 per wave) arranged TZ x TY x TXT, LDS <= 64 KB ----
+    static const int cand[][3] = {{1, 1, 16}, {1, 2, 8}, {1, 4, 4}, {1, 8, 2}, {1, 16, 1}, {2, 1, 8}, {2, 2, 4},
+                                  {2, 4, 2}, {2, 8, 1}, {4, 1, 4}, {4, 2, 2}, {4, 4, 1}, {8, 1, 2}, {8, 2, 1}, {16, 1, 1}};
+    double best = 1e300;
+    int TZ = 0, TY = 0, TXT = 0, TZI = 0, TYI = 0, TXI = 0;
+    for (size_t limit : {size_t(64) * 1024, kConvMaxLds}) {  // prefer >= 2 workgroups per CU
+      for (auto &c : cand) {
+        const int tzi = (c[0] - 1) * Z.s + exz, tyi = (c[1] - 1) * Y.s + exy, txi = (c[2] * 16 - 1) * X.s + exx;
+        const size_t bytes = (size_t)tzi * tyi * txi * CIS * 4;
+        if (bytes > limit) continue;
+        const double tiles = (double)cdiv(Z.npos, c[0]) * cdiv(Y.npos, c[1]) * cdiv(X.npos, c[2] * 16);
+        const double cost = tiles * ((double)NU * npass * CT * kPT * 4 * 32.0 + (double)tzi * tyi * txi * (CI / 4) * npass / 256.0 * 160.0);
+        if (cost < best) { best = cost; TZ = c[0]; TY = c[1]; TXT = c[2]; TZI = tzi; TYI = tyi; TXI = txi; }
+      }
+      if (TZ) break;
+    }
+    if (!TZ) fail(DR_ERR_ARG, "plan_conv: no tile shape fits LDS");
+
+    // ---- tap table (LDS position offsets) and packed weights ----
+    std::vector<int> tapoff((size_t)NU * TPC, 0);
+    std::vector<int> tz(ntaps), ty(ntaps), tx(ntaps);
+    {
+      int n = 0;
+      for (int iz = 0; iz < ntz; ++iz) for (int iy = 0; iy < nty; ++iy) for (int ix = 0; ix < ntx; ++ix, ++n) {
+        tapoff[n] = (Z.off[iz] * TYI + Y.off[iy]) * TXI + X.off[ix];
+        tz[n] = Z.t[iz]; ty[n] = Y.t[iy]; tx[n] = X.t[ix];
+      }
+    }
+    std::vector<float> pk((size_t)npass * NU * CT * 64 * 4, 0.f);
+    for (int p = 0; p < npass; ++p) for (int u = 0; u < NU; ++u) for (int ct = 0; ct < CT; ++ct)
+      for (int l = 0; l < 64; ++l) for (int s = 0; s < 4; ++s) {
+        const int g = l >> 4, i = l & 15, k16 = 4 * g + s;
+        const int tap = u * TPC + k16 / CI, cin = p * CI + k16 % CI, row = ct * 16 + i;
+        float v = 0.f;
+        if (tap < ntaps && row < rows_valid) {
+          if (mode == CONV_NORMAL) v = weight_at(row, cin, tz[tap], ty[tap], tx[tap]);
+          else {
+            const int shift = mode == CONV_XPAIR ? (row >> 3) : row, co = mode == CONV_XPAIR ? (row & 7) : 0;
+            const int kx = tx[tap] - shift;
+            if (kx >= 0 && kx < L.kw) v = weight_at(co, cin, tz[tap], ty[tap], kx);
+          }
+        }
+        pk[((((size_t)p * NU + u) * CT + ct) * 64 + l) * 4 + s] = v;
+      }
+
+    ConvLaunch cl{};
+    ConvArgs &a = cl.args;
+    a.in = in; a.out = out; a.wpk = reinterpret_cast<const float4 *>(arena.upload(pk));
+    a.scale = d_scale; a.bias = d_bias; a.add = add; a.tapoff = arena.upload(tapoff);
+    a.inD = inD; a.inH = inH; a.inW = inW; a.inC = inC;
+    a.outD = R.outD; a.outH = R.outH; a.outW = outWv; a.outC = outCv;
+    a.nPD = Z.npos; a.nPH = Y.npos; a.nPW = X.npos;
+    a.sz = Z.s; a.sy = Y.s; a.sx = X.s; a.pz = Z.p; a.py = Y.p; a.px = X.p;
+    a.omz = Z.om; a.omy = Y.om; a.omx = X.om; a.ooz = Z.oo; a.ooy = Y.oo; a.oox = X.oo;
+    a.TZ = TZ; a.TY = TY; a.TXT = TXT; a.TZI = TZI; a.TYI = TYI; a.TXI = TXI;
+    a.NU = NU; a.npass = npass; a.rows_valid = rows_valid; a.relu = L.relu ? 1 : 0;
+    a.add_mode = add ? add_mode : 0;
+    a.addH = R.outH / 2; a.addW = (mode == CONV_NORMAL ? R.outW : outWv) / 2;
+    a.tilesD = cdiv(Z.npos, TZ); a.tilesH = cdiv(Y.npos, TY); a.tilesW = cdiv(X.npos, TXT * 16);
+    cl.ci = CI; cl.ct = CT;
+    cl.grid = a.tilesD * a.tilesH * a.tilesW;
+    cl.lds_bytes = (size_t)TZI * TYI * TXI * CIS * 4;
+    cl.flops = 2.0 * Z.npos * Y.npos * X.npos * (mode == CONV_NORMAL ? 1 : shifts) * (double)ntz * nty *
+               (mode == CONV_NORMAL ? ntx : L.kw) * L.Cin * L.Cout;
+    R.launches.push_back(cl);
+  }
+  return R;
+}
+
+inline void launch_conv(const ConvLaunch &c, hipStream_t st) {
+  dim3 grid(c.grid), block(kConvThreads);
+#define DR_CONV_CASE(CI_, CT_)                                                          \
+  if (c.ci == CI_ && c.ct == CT_) {                                                     \
+    static bool big = false;                                                            \
+    if (c.lds_bytes > 64 * 1024 && !big) {                                              \
+      DR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv<CI_, CT_>),     \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvMaxLds)); \
+      big = true;                                                                       \
+    }                                                                                   \
+    hipLaunchKernelGGL((k_conv<CI_, CT_>), grid, block, c.lds_bytes, st, c.args);       \
+    return;                                                                             \
+  }
+  DR_CONV_CASE(4, 1)
+  DR_CONV_CASE(8, 1)
+  DR_CONV_CASE(8, 2)
+  DR_CONV_CASE(16, 1)
+  DR_CONV_CASE(16, 2)
+  DR_CONV_CASE(16, 4)
+#undef DR_CONV_CASE
+  fail(DR_ERR_ARG, "launch_conv: no instance CI=%d CT=%d", c.ci, c.ct);
+}
+
+}  // namespace dr

@@ -1,0 +1,685 @@
+// dr_mvsnet.hip -- MI355X engine behind the DrMvsnet operator API (C ABI: include/dr_mi355x.h).
+//
+// Replaces tandem/libdr/dr_mvsnet/src/dr_mvsnet.cpp (libtorch TorchScript interpreter + cuDNN)
+// with a fixed launch plan of hand-written gfx950 kernels (conv_mfma.h, mvs_kernels.h):
+//   CallAsync   dr_mvsnet.cpp:125-283  -> MvsEngine::stage_inputs + worker thread
+//   forward     dr_mvsnet.cpp:285-331  -> MvsEngine::forward (cva_mvsnet.py:98-184 as ~120 launches)
+//   GetResult   dr_mvsnet.cpp:95-107   -> drm_get_result
+// The threading contract is the reference's: one worker thread, one mutex, two condition variables;
+// CallAsync blocks only while the previous input is still unprocessed.
+#include <cmath>
+#include <condition_variable>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
+
+#include "conv_mfma.h"
+#include "mvs_kernels.h"
+
+namespace dr {
+
+std::string &last_error_slot() {
+  thread_local std::string s;
+  return s;
+}
+
+// ------------------------------------------------------------------ TDMW blob (tandem_amd/weights.py)
+struct HostTensor {
+  std::vector<int> dims;
+  std::vector<float> data;
+};
+struct Blob {
+  int depth_num[3];
+  float ratio[3];
+  int view_aggregation, base;
+  std::map<std::string, HostTensor> t;
+  const HostTensor &at(const std::string &k) const {
+    auto it = t.find(k);
+    if (it == t.end()) fail(DR_ERR_IO, "weight blob: missing tensor %s", k.c_str());
+    return it->second;
+  }
+};
+
+static Blob load_blob(const char *path) {
+  FILE *f = fopen(path, "rb");
+  if (!f) fail(DR_ERR_IO, "cannot open weight blob %s", path);
+  Blob b;
+  char magic[8];
+  auto rd = [&](void *p, size_t n) {
+    if (fread(p, 1, n, f) != n) { fclose(f); fail(DR_ERR_IO, "weight blob %s truncated", path); }
+  };
+  rd(magic, 8);
+  if (memcmp(magic, "TDMW0001", 8)) { fclose(f); fail(DR_ERR_IO, "%s is not a TDMW blob", path); }
+  rd(b.depth_num, 12); rd(b.ratio, 12); rd(&b.view_aggregation, 4); rd(&b.base, 4);
+  uint32_t n;
+  rd(&n, 4);
+  for (uint32_t i = 0; i < n; ++i) {
+    uint32_t ln, nd;
+    rd(&ln, 4);
+    std::string name(ln, '\0');
+    rd(&name[0], ln);
+    rd(&nd, 4);
+    HostTensor t;
+    size_t cnt = 1;
+    for (uint32_t k = 0; k < nd; ++k) { uint32_t d; rd(&d, 4); t.dims.push_back((int)d); cnt *= d; }
+    t.data.resize(cnt);
+    rd(t.data.data(), cnt * 4);
+    b.t[name] = std::move(t);
+  }
+  fclose(f);
+  if (b.base != 8) fail(DR_ERR_UNSUPPORTED, "only feature_net_base_channels=8 is supported (got %d)", b.base);
+  return b;
+}
+
+// ------------------------------------------------------------------ small host math (double)
+static void inv4(const double *m, double *o) {  // Gauss-Jordan with partial pivoting
+  double a[4][8];
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { a[i][j] = m[4 * i + j]; a[i][4 + j] = i == j; }
+  for (int c = 0; c < 4; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < 4; ++r) if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+    if (piv != c) for (int j = 0; j < 8; ++j) std::swap(a[c][j], a[piv][j]);
+    const double d = a[c][c];
+    for (int j = 0; j < 8; ++j) a[c][j] /= d;
+    for (int r = 0; r < 4; ++r) if (r != c) { const double f = a[r][c]; for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j]; }
+  }
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) o[4 * i + j] = a[i][4 + j];
+}
+static void mul4(const double *a, const double *b, double *o) {
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { double s = 0; for (int k = 0; k < 4; ++k) s += a[4 * i + k] * b[4 * k + j]; o[4 * i + j] = s; }
+}
+// world->pixel 4x4 = [K * W2C(3x4); 0 0 0 1]   (module.py:798-804)
+static void world_to_pixel(const float *K9, const double *w2c, double *o) {
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += (double)K9[3 * i + k] * w2c[4 * k + j]; o[4 * i + j] = s; }
+  o[12] = w2c[12]; o[13] = w2c[13]; o[14] = w2c[14]; o[15] = w2c[15];
+}
+
+// ------------------------------------------------------------------ engine
+struct DevTensor {
+  float *d = nullptr;
+  int D = 0, H = 0, W = 0, C = 0;
+  size_t n() const { return (size_t)D * H * W * C; }
+};
+
+struct Op {
+  enum Kind { PREPROCESS, CONV, COSTVOL, REGRESS, EDGE, HIST, SCAN, APPLY } kind;
+  std::string name;
+  ConvLaunch conv;
+  int stage = 0, shift = 0, bits = 0;
+  double flops = 0, bytes = 0;
+};
+
+class MvsEngine {
+ public:
+  MvsEngine(const char *path, int device) : device_(device), blob_(load_blob(path)) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= device) fail(DR_ERR_DEVICE, "DrMvsnet: no HIP device %d (found %d) -- the MI355X path has no CPU fallback", device, n);
+    DR_HIP(hipSetDevice(device_));
+    DR_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    std::vector<float> lut(256);
+    for (int i = 0; i < 256; ++i) lut[i] = (float)((double)(float)i / 255.0);
+    lut_ = consts_.upload(lut);
+    worker_ = std::thread(&MvsEngine::loop, this);
+  }
+  ~MvsEngine() {
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      done_cv_.wait(lk, [&] { return !unprocessed_; });
+      running_ = false;
+      input_cv_.notify_all();
+    }
+    worker_.join();
+    (void)hipSetDevice(device_);
+    (void)hipStreamSynchronize(stream_);
+    release();
+    if (h_out_) (void)hipHostFree(h_out_);
+    if (h_in_) (void)hipHostFree(h_in_);
+    (void)hipStreamDestroy(stream_);
+  }
+
+  // --- reference-API surface -------------------------------------------------------------------
+  void call_async(int H, int W, int V, int ref, const uint8_t *const *bgrs, const float *K9, const float *const *c2ws,
+                  float dmin, float dmax, float disc) {
+    check_args(H, W, V, ref, bgrs, K9, c2ws);
+    std::unique_lock<std::mutex> lk(mu_);  // held by the worker for the whole forward (dr_mvsnet.cpp:84-92)
+    done_cv_.wait(lk, [&] { return !unprocessed_; });
+    stage_inputs(H, W, V, ref, bgrs, K9, c2ws, dmin, dmax, disc);
+    unprocessed_ = true;
+    input_cv_.notify_all();
+  }
+  bool ready() { return !unprocessed_; }
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [&] { return !unprocessed_; });
+    rethrow_worker_error();
+  }
+  void get_result(float *depth, float *conf, float *depth_dense, float *conf_dense) {
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [&] { return !unprocessed_; });
+    rethrow_worker_error();
+    if (!has_output_) fail(DR_ERR_PROTOCOL, "Output should be valid. Maybe you called GetResult more than once?");
+    const size_t n = (size_t)H_ * W_;
+    memcpy(depth, h_out_, n * 4); memcpy(conf, h_out_ + n, n * 4);
+    memcpy(depth_dense, h_out_ + 2 * n, n * 4); memcpy(conf_dense, h_out_ + 3 * n, n * 4);
+    has_output_ = false;
+  }
+
+  // --- device-resident hooks -------------------------------------------------------------------
+  void upload(int H, int W, int V, int ref, const uint8_t *const *bgrs, const float *K9, const float *const *c2ws,
+              float dmin, float dmax, float disc) {
+    check_args(H, W, V, ref, bgrs, K9, c2ws);
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [&] { return !unprocessed_; });
+    stage_inputs(H, W, V, ref, bgrs, K9, c2ws, dmin, dmax, disc);
+    DR_HIP(hipStreamSynchronize(stream_));
+  }
+  void forward_n(int iters, float *ms) {
+    std::unique_lock<std::mutex> lk(mu_);
+    require_config();
+    DR_HIP(hipSetDevice(device_));
+    hipEvent_t e0, e1;
+    DR_HIP(hipEventCreate(&e0)); DR_HIP(hipEventCreate(&e1));
+    DR_HIP(hipEventRecord(e0, stream_));
+    for (int i = 0; i < iters; ++i) forward(nullptr);
+    DR_HIP(hipEventRecord(e1, stream_));
+    DR_HIP(hipStreamSynchronize(stream_));
+    float t = 0;
+    DR_HIP(hipEventElapsedTime(&t, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (ms) *ms = t;
+  }
+  void download(float *depth, float *conf, float *depth_dense, float *conf_dense) {
+    std::unique_lock<std::mutex> lk(mu_);
+    require_config();
+    DR_HIP(hipSetDevice(device_));
+    const size_t n = (size_t)H_ * W_ * 4;
+    DR_HIP(hipMemcpyAsync(depth, T("depth").d, n, hipMemcpyDeviceToHost, stream_));
+    DR_HIP(hipMemcpyAsync(conf, T("confidence").d, n, hipMemcpyDeviceToHost, stream_));
+    DR_HIP(hipMemcpyAsync(depth_dense, T("depth3").d, n, hipMemcpyDeviceToHost, stream_));
+    DR_HIP(hipMemcpyAsync(conf_dense, T("conf3").d, n, hipMemcpyDeviceToHost, stream_));
+    DR_HIP(hipStreamSynchronize(stream_));
+  }
+  void get_tensor(const char *name, float *out, size_t n_max, size_t *n, int dims[4]) {
+    std::unique_lock<std::mutex> lk(mu_);
+    require_config();
+    DR_HIP(hipSetDevice(device_));
+    const DevTensor &t = T(name);
+    if (n) *n = t.n();
+    if (dims) { dims[0] = t.D; dims[1] = t.H; dims[2] = t.W; dims[3] = t.C; }
+    if (out) {
+      if (t.n() > n_max) fail(DR_ERR_ARG, "get_tensor(%s): need %zu floats, have %zu", name, t.n(), n_max);
+      DR_HIP(hipStreamSynchronize(stream_));
+      DR_HIP(hipMemcpy(out, t.d, t.n() * 4, hipMemcpyDeviceToHost));
+    }
+  }
+  void profile(std::string &names, std::vector<float> &ms) {
+    std::unique_lock<std::mutex> lk(mu_);
+    require_config();
+    DR_HIP(hipSetDevice(device_));
+    forward(nullptr);  // warm
+    std::vector<hipEvent_t> ev(ops_.size() + 1);
+    for (auto &e : ev) DR_HIP(hipEventCreate(&e));
+    forward(&ev);
+    DR_HIP(hipStreamSynchronize(stream_));
+    names.clear(); ms.clear();
+    for (size_t i = 0; i < ops_.size(); ++i) {
+      float t = 0;
+      DR_HIP(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+      ms.push_back(t);
+      names += ops_[i].name; names += '\n';
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+  }
+  void work(double *flops, double *bytes) {
+    std::unique_lock<std::mutex> lk(mu_);
+    require_config();
+    double f = 0, b = 0;
+    for (auto &o : ops_) { f += o.flops; b += o.bytes; }
+    if (flops) *flops = f;
+    if (bytes) *bytes = b;
+  }
+
+ private:
+  // ---------------------------------------------------------------- plumbing
+  void check_args(int H, int W, int V, int ref, const uint8_t *const *bgrs, const float *K9, const float *const *c2ws) {
+    if (!bgrs || !K9 || !c2ws) fail(DR_ERR_ARG, "CallAsync: null pointer argument");
+    if (V < 2 || V > kMaxSrc + 1) fail(DR_ERR_ARG, "CallAsync: view_num=%d unsupported (2..%d)", V, kMaxSrc + 1);
+    if (ref < 0 || ref >= V) fail(DR_ERR_ARG, "CallAsync: ref_index=%d out of range", ref);
+    if (H <= 0 || W <= 0 || H % 32 || W % 32) fail(DR_ERR_ARG, "CallAsync: height/width must be positive multiples of 32 (got %dx%d)", H, W);
+    for (int i = 0; i < V - 1; ++i) for (int j = i + 1; j < V; ++j)
+      if (bgrs[i] == bgrs[j] || c2ws[i] == c2ws[j])
+        fail(DR_ERR_ARG, "ERROR: In Call Async passing the same data for index %d and %d", i, j);  // dr_mvsnet.cpp:153-160
+  }
+  void require_config() { if (!H_) fail(DR_ERR_PROTOCOL, "no window uploaded yet"); }
+  void rethrow_worker_error() {
+    if (!worker_error_.empty()) { std::string e = worker_error_; worker_error_.clear(); fail(DR_ERR_DEVICE, "%s", e.c_str()); }
+  }
+  void loop() {  // dr_mvsnet.cpp:83-93
+    std::unique_lock<std::mutex> lk(mu_);
+    while (running_) {
+      if (unprocessed_) {
+        try {
+          DR_HIP(hipSetDevice(device_));
+          forward(nullptr);
+          const size_t n = (size_t)H_ * W_ * 4;
+          DR_HIP(hipMemcpyAsync(h_out_, T("depth").d, n, hipMemcpyDeviceToHost, stream_));
+          DR_HIP(hipMemcpyAsync(h_out_ + n / 4, T("confidence").d, n, hipMemcpyDeviceToHost, stream_));
+          DR_HIP(hipMemcpyAsync(h_out_ + 2 * (n / 4), T("depth3").d, n, hipMemcpyDeviceToHost, stream_));
+          DR_HIP(hipMemcpyAsync(h_out_ + 3 * (n / 4), T("conf3").d, n, hipMemcpyDeviceToHost, stream_));
+          DR_HIP(hipStreamSynchronize(stream_));
+          has_output_ = true;
+        } catch (const std::exception &e) { worker_error_ = e.what(); }
+        unprocessed_ = false;
+        done_cv_.notify_all();
+      }
+      input_cv_.wait(lk, [&] { return unprocessed_ || !running_; });
+    }
+  }
+
+  DevTensor &T(const std::string &name) {
+    auto it = tensors_.find(name);
+    if (it == tensors_.end()) fail(DR_ERR_ARG, "unknown tensor '%s'", name.c_str());
+    return it->second;
+  }
+  DevTensor &alloc(const std::string &name, int D, int H, int W, int C) {
+    DevTensor t; t.D = D; t.H = H; t.W = W; t.C = C;
+    t.d = dalloc<float>(t.n());
+    tensors_[name] = t;
+    return tensors_[name];
+  }
+  void release() {
+    for (auto &kv : tensors_) (void)hipFree(kv.second.d);
+    tensors_.clear();
+    ops_.clear();
+    plan_arena_.reset();
+    for (void *p : misc_) (void)hipFree(p);
+    misc_.clear();
+  }
+
+  // ---------------------------------------------------------------- layer construction
+  void fold_bn(const std::string &p, int C, std::vector<float> &sc, std::vector<float> &bi) {
+    const auto &g = blob_.at(p + ".weight").data, &b = blob_.at(p + ".bias").data;
+    const auto &m = blob_.at(p + ".running_mean").data, &v = blob_.at(p + ".running_var").data;
+    sc.resize(C); bi.resize(C);
+    for (int c = 0; c < C; ++c) {
+      const double s = (double)g[c] / std::sqrt((double)v[c] + 1e-5);
+      sc[c] = (float)s;
+      bi[c] = (float)((double)b[c] - (double)m[c] * s);
+    }
+  }
+  // Adds one convolution layer (possibly several launches) to the plan; returns the output tensor.
+  DevTensor &add_conv(const std::string &opname, const std::string &wname, const std::string &bnname, bool conv_bias, bool relu,
+                      const DevTensor &in, const std::string &outname, int k3d, int kh, int kw, int sd, int sh, int sw,
+                      bool transposed, ConvMode mode, const DevTensor *add, int add_mode) {
+    const HostTensor &w = blob_.at(wname + ".weight");
+    ConvLayer L;
+    L.transposed = transposed;
+    const int c_out = transposed ? w.dims[1] : w.dims[0], c_in_real = transposed ? w.dims[0] : w.dims[1];
+    L.Cout = c_out; L.Cin = in.C;
+    L.kd = k3d; L.kh = kh; L.kw = kw; L.sd = sd; L.sh = sh; L.sw = sw; L.relu = relu;
+    std::vector<float> padded;
+    if (c_in_real != in.C) {  // RGB -> RGB0: zero-pad the input-channel axis of the weights
+      if (transposed || c_in_real > in.C) fail(DR_ERR_ARG, "%s: channel mismatch", opname.c_str());
+      const int taps = k3d * kh * kw;
+      padded.assign((size_t)c_out * in.C * taps, 0.f);
+      for (int co = 0; co < c_out; ++co) for (int ci = 0; ci < c_in_real; ++ci) for (int t = 0; t < taps; ++t)
+        padded[((size_t)co * in.C + ci) * taps + t] = w.data[((size_t)co * c_in_real + ci) * taps + t];
+      L.weight = padded.data();
+    } else L.weight = w.data.data();
+    if (!bnname.empty()) fold_bn(bnname, c_out, L.scale, L.bias);
+    else if (conv_bias) L.bias = blob_.at(wname + ".bias").data;
+    ConvPlanOut P0;  // dims first
+    {
+      auto cz = axis_classes(k3d, sd, transposed, in.D), cy = axis_classes(kh, sh, transposed, in.H), cx = axis_classes(kw, sw, transposed, in.W);
+      P0.outD = transposed ? in.D * sd : cz[0].npos; P0.outH = transposed ? in.H * sh : cy[0].npos; P0.outW = transposed ? in.W * sw : cx[0].npos;
+    }
+    DevTensor &out = alloc(outname, P0.outD, P0.outH, P0.outW, c_out);
+    ConvPlanOut P = plan_conv(L, mode, in.d, in.D, in.H, in.W, in.C, out.d, add ? add->d : nullptr, add_mode, *plan_arena_);
+    int idx = 0;
+    for (auto &cl : P.launches) {
+      Op o; o.kind = Op::CONV; o.conv = cl; o.name = opname + (P.launches.size() > 1 ? "." + std::to_string(idx) : "");
+      o.flops = cl.flops;
+      if (idx == 0) o.bytes = 4.0 * (in.n() + out.n() + (add ? (add_mode == 2 ? add->n() : out.n()) : 0));
+      ops_.push_back(o);
+      ++idx;
+    }
+    return out;
+  }
+  DevTensor &cbr2(const std::string &name, const std::string &p, const DevTensor &in, int k, int s, ConvMode m) {
+    return add_conv(name, p + ".conv", p + ".bn", false, true, in, name, 1, k, k, 1, s, s, false, m, nullptr, 0);
+  }
+  DevTensor &cbr3(const std::string &name, const std::string &p, const DevTensor &in, int sd, int shw, ConvMode m) {
+    return add_conv(name, p + ".conv", p + ".bn", false, true, in, name, 3, 3, 3, sd, shw, shw, false, m, nullptr, 0);
+  }
+  DevTensor &dbr3(const std::string &name, const std::string &p, const DevTensor &in, int sd, const DevTensor &skip) {
+    return add_conv(name, p + ".conv", p + ".bn", false, true, in, name, 3, 3, 3, sd, 2, 2, true, CONV_NORMAL, &skip, 1);
+  }
+
+  void configure(int H, int W, int V) {
+    if (H == H_ && W == W_ && V == V_) return;
+    DR_HIP(hipStreamSynchronize(stream_));
+    release();
+    plan_arena_.reset(new DeviceArena());
+    H_ = H; W_ = W; V_ = V;
+    if (h_out_) { (void)hipHostFree(h_out_); h_out_ = nullptr; }
+    if (h_in_) { (void)hipHostFree(h_in_); h_in_ = nullptr; }
+    DR_HIP(hipHostMalloc((void **)&h_out_, (size_t)H * W * 16, hipHostMallocDefault));
+    DR_HIP(hipHostMalloc((void **)&h_in_, (size_t)V * H * W * 3, hipHostMallocDefault));
+    d_bgr_ = dalloc<uint8_t>((size_t)V * H * W * 3); misc_.push_back(d_bgr_);
+    d_state_ = dalloc<unsigned>(8); misc_.push_back(d_state_);
+    d_hist_ = dalloc<unsigned>(2048); misc_.push_back(d_hist_);
+    DR_HIP(hipMemset(d_hist_, 0, 2048 * 4));
+
+    const std::string fn = "feature_net.";
+    DevTensor &img = alloc("image", V, H, W, 4);
+    { Op o; o.kind = Op::PREPROCESS; o.name = "preprocess"; o.bytes = (double)V * H * W * (3 + 16); ops_.push_back(o); }
+    DevTensor &c3a = cbr2("fn.conv0.0", fn + "conv0.0", img, 3, 1, CONV_XPAIR);
+    DevTensor &c3 = cbr2("fn.conv0.1", fn + "conv0.1", c3a, 3, 1, CONV_XPAIR);
+    DevTensor &c2a = cbr2("fn.conv1.0", fn + "conv1.0", c3, 5, 2, CONV_NORMAL);
+    DevTensor &c2b = cbr2("fn.conv1.1", fn + "conv1.1", c2a, 3, 1, CONV_NORMAL);
+    DevTensor &c2 = cbr2("fn.conv1.2", fn + "conv1.2", c2b, 3, 1, CONV_NORMAL);
+    DevTensor &c1a = cbr2("fn.conv2.0", fn + "conv2.0", c2, 5, 2, CONV_NORMAL);
+    DevTensor &c1b = cbr2("fn.conv2.1", fn + "conv2.1", c1a, 3, 1, CONV_NORMAL);
+    DevTensor &c1 = cbr2("fn.conv2.2", fn + "conv2.2", c1b, 3, 1, CONV_NORMAL);
+    add_conv("fn.out1", fn + "out.stage1", "", false, false, c1, "feat1", 1, 1, 1, 1, 1, 1, false, CONV_NORMAL, nullptr, 0);
+    DevTensor &i2 = add_conv("fn.skip2", fn + "skip.stage2", "", true, false, c2, "inter2", 1, 1, 1, 1, 1, 1, false, CONV_NORMAL, &c1, 2);
+    add_conv("fn.out2", fn + "out.stage2", "", false, false, i2, "feat2", 1, 3, 3, 1, 1, 1, false, CONV_NORMAL, nullptr, 0);
+    DevTensor &i3 = add_conv("fn.skip3", fn + "skip.stage3", "", true, false, c3, "inter3", 1, 1, 1, 1, 1, 1, false, CONV_NORMAL, &i2, 2);
+    add_conv("fn.out3", fn + "out.stage3", "", false, false, i3, "feat3", 1, 3, 3, 1, 1, 1, false, CONV_XPAIR, nullptr, 0);
+
+    for (int s = 1; s <= 3; ++s) {
+      const int sc = 1 << (3 - s), h = H / sc, w = W / sc, D = blob_.depth_num[s - 1], C = 32 >> (s - 1);
+      if (!(D == 4 || D % 8 == 0)) fail(DR_ERR_UNSUPPORTED, "depth_num[%d]=%d must be 4 or a multiple of 8", s - 1, D);
+      const std::string S = std::to_string(s), cr = "cost_regularization_net.stage" + S + ".", pre = "s" + S + ".";
+      DevTensor &vol = alloc("volume" + S, D, h, w, C);
+      {
+        Op o; o.kind = Op::COSTVOL; o.stage = s; o.name = pre + "costvol";
+        o.bytes = 4.0 * ((double)V * h * w * C + vol.n());
+        o.flops = (double)(V - 1) * D * h * w * (3.0 * C + 2.0 * C + 8.0 * C);  // diff^2, gate dot, weighted accumulate, 4-tap lerp
+        ops_.push_back(o);
+      }
+      const bool four = D == 4;
+      DevTensor &c0 = cbr3(pre + "conv0", cr + "conv0", vol, 1, 1, CONV_XPAIR);
+      DevTensor &k1 = cbr3(pre + "conv1", cr + "conv1", c0, 2, 2, CONV_NORMAL);
+      DevTensor &k2 = cbr3(pre + "conv2", cr + "conv2", k1, 1, 1, CONV_NORMAL);
+      DevTensor &k3 = cbr3(pre + "conv3", cr + "conv3", k2, 2, 2, CONV_NORMAL);
+      DevTensor &k4 = cbr3(pre + "conv4", cr + "conv4", k3, 1, 1, CONV_NORMAL);
+      DevTensor &k5 = cbr3(pre + "conv5", cr + "conv5", k4, four ? 1 : 2, 2, CONV_NORMAL);
+      DevTensor &k6 = cbr3(pre + "conv6", cr + "conv6", k5, 1, 1, CONV_NORMAL);
+      DevTensor &x7 = dbr3(pre + "conv7", cr + "conv7", k6, four ? 1 : 2, k4);
+      DevTensor &x9 = dbr3(pre + "conv9", cr + "conv9", x7, 2, k2);
+      DevTensor &x11 = dbr3(pre + "conv11", cr + "conv11", x9, 2, c0);
+      add_conv(pre + "prob", cr + "prob", "", false, false, x11, "logits" + S, 3, 3, 3, 1, 1, 1, false, CONV_X8, nullptr, 0);
+      alloc("depth" + S, 1, h, w, 1);
+      alloc("conf" + S, 1, h, w, 1);
+      { Op o; o.kind = Op::REGRESS; o.stage = s; o.name = pre + "regress"; o.bytes = 4.0 * ((double)D * h * w + 2.0 * h * w); o.flops = 8.0 * D * h * w; ops_.push_back(o); }
+    }
+    alloc("edge", 1, H, W, 1);
+    alloc("depth", 1, H, W, 1);
+    alloc("confidence", 1, H, W, 1);
+    { Op o; o.kind = Op::EDGE; o.name = "filter.edge"; o.bytes = 8.0 * H * W; ops_.push_back(o); }
+    const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+    for (int i = 0; i < 3; ++i) {
+      Op o; o.kind = Op::HIST; o.shift = shifts[i]; o.bits = bits[i]; o.name = "filter.hist" + std::to_string(i); o.bytes = 4.0 * H * W; ops_.push_back(o);
+      Op q; q.kind = Op::SCAN; q.shift = shifts[i]; q.bits = bits[i]; q.name = "filter.scan" + std::to_string(i); ops_.push_back(q);
+    }
+    { Op o; o.kind = Op::APPLY; o.name = "filter.apply"; o.bytes = 20.0 * H * W; ops_.push_back(o); }
+  }
+
+  // Copies the window into pinned memory in model order [ref, others] (dr_mvsnet.cpp:190-197), enqueues
+  // the H2D copy and derives every per-call kernel parameter.  Caller holds mu_.
+  void stage_inputs(int H, int W, int V, int ref, const uint8_t *const *bgrs, const float *K9, const float *const *c2ws,
+                    float dmin, float dmax, float disc) {
+    DR_HIP(hipSetDevice(device_));
+    configure(H, W, V);
+    const size_t img_bytes = (size_t)H * W * 3;
+    std::vector<int> order;
+    order.push_back(ref);
+    for (int i = 0; i < V; ++i) if (i != ref) order.push_back(i);
+    for (int v = 0; v < V; ++v) memcpy(h_in_ + v * img_bytes, bgrs[order[v]], img_bytes);
+    DR_HIP(hipMemcpyAsync(d_bgr_, h_in_, V * img_bytes, hipMemcpyHostToDevice, stream_));
+
+    // stage intrinsics: rows 0-1 x 0.25 / 0.5 / 1 (the C++ rule, dr_mvsnet.cpp:226-247)
+    double w2c[8][16];
+    for (int v = 0; v < V; ++v) {
+      double c2w[16];
+      for (int i = 0; i < 16; ++i) c2w[i] = c2ws[order[v]][i];
+      inv4(c2w, w2c[v]);
+    }
+    const float base_interval = (dmax - dmin) / (float)(blob_.depth_num[0] - 1);  // module.py:1493
+    for (int s = 1; s <= 3; ++s) {
+      const float f = s == 1 ? 0.25f : (s == 2 ? 0.5f : 1.f);
+      float Ks[9];
+      for (int i = 0; i < 9; ++i) Ks[i] = i < 6 ? (float)((double)f * (double)K9[i]) : K9[i];
+      const int sc = 1 << (3 - s), h = H / sc, w = W / sc, D = blob_.depth_num[s - 1], C = 32 >> (s - 1);
+      CostVolArgs &a = cv_[s - 1];
+      memset(&a, 0, sizeof a);
+      a.feat = T("feat" + std::to_string(s)).d;
+      a.vol = T("volume" + std::to_string(s)).d;
+      a.V = V; a.h = h; a.w = w;
+      a.dchunk = s == 3 ? D : (D >= 16 ? D / 4 : D);
+      a.view_aggregation = blob_.view_aggregation;
+      a.nsrc_f = (float)(V - 1);
+      PlaneArgs &p = a.planes;
+      p.D = D; p.dmin = dmin; p.interval = base_interval;
+      if (s > 1) {
+        p.prev = T("depth" + std::to_string(s - 1)).d; p.hp = h / 2; p.wp = w / 2;
+        const float delta = blob_.ratio[s - 1] * base_interval;  // cva_mvsnet.py:151
+        p.half_range = ((float)D / 2.f) * delta;                  // module.py:1518
+        p.full_range = (float)D * delta;                          // module.py:1526
+      }
+      double r_w2p[16], r_p2w[16];
+      world_to_pixel(Ks, w2c[0], r_w2p);
+      inv4(r_w2p, r_p2w);
+      for (int v = 1; v < V; ++v) {
+        double s_w2p[16], M[16];
+        world_to_pixel(Ks, w2c[v], s_w2p);
+        mul4(s_w2p, r_p2w, M);
+        for (int i = 0; i < 12; ++i) a.M[v - 1][i] = (float)M[i];
+      }
+      if (blob_.view_aggregation) {
+        const std::string g = "volume_gates.stage" + std::to_string(s) + ".";
+        const auto &w0 = blob_.at(g + "0.weight").data;
+        for (int c = 0; c < C; ++c) a.gw[c] = w0[c];
+        auto bnf = [&](const std::string &bn, double &A, double &B) {
+          const double ga = blob_.at(bn + ".weight").data[0], be = blob_.at(bn + ".bias").data[0];
+          const double mu = blob_.at(bn + ".running_mean").data[0], var = blob_.at(bn + ".running_var").data[0];
+          A = ga / std::sqrt(var + 1e-5); B = be - mu * A;
+        };
+        double A1, B1, A2, B2;
+        bnf(g + "1", A1, B1); bnf(g + "4", A2, B2);
+        const double b0 = blob_.at(g + "0.bias").data[0], w3 = blob_.at(g + "3.weight").data[0], b3 = blob_.at(g + "3.bias").data[0];
+        a.gA1 = (float)A1; a.gB1 = (float)(b0 * A1 + B1);
+        a.gA2 = (float)(w3 * A2); a.gB2 = (float)(b3 * A2 + B2);
+      }
+      RegressArgs &r = rg_[s - 1];
+      r.logits = T("logits" + std::to_string(s)).d;
+      r.depth = T("depth" + std::to_string(s)).d;
+      r.conf = T("conf" + std::to_string(s)).d;
+      r.planes = p; r.h = h; r.w = w;
+    }
+    // quantile rank, computed in float32 like module.py:1348-1349
+    const float hw = (float)(H * W);
+    float cut = hw * (100.f - disc);
+    cut = cut / 100.f;
+    long long ci = (long long)cut;
+    if (ci < 0) ci = 0;
+    if (ci > (long long)H * W - 1) ci = (long long)H * W - 1;
+    filter_rank_ = (unsigned)ci;
+  }
+
+  // Enqueue one complete forward on stream_.  ev (optional): ops_.size()+1 events for per-op timing.
+  void forward(std::vector<hipEvent_t> *ev) {
+    size_t i = 0;
+    for (const Op &o : ops_) {
+      if (ev) DR_HIP(hipEventRecord((*ev)[i], stream_));
+      ++i;
+      switch (o.kind) {
+        case Op::PREPROCESS: {
+          const size_t npix = (size_t)V_ * H_ * W_;
+          hipLaunchKernelGGL(k_preprocess, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream_, d_bgr_,
+                             reinterpret_cast<float4 *>(T("image").d), lut_, npix);
+          break;
+        }
+        case Op::CONV: launch_conv(o.conv, stream_); break;
+        case Op::COSTVOL: {
+          const CostVolArgs &a = cv_[o.stage - 1];
+          const int C = 32 >> (o.stage - 1), pxb = 256 / (C / 4);
+          dim3 grid(cdiv(a.w, pxb), a.h, cdiv(a.planes.D, a.dchunk));
+          if (C == 32) hipLaunchKernelGGL(k_costvol<32>, grid, dim3(256), 0, stream_, a);
+          else if (C == 16) hipLaunchKernelGGL(k_costvol<16>, grid, dim3(256), 0, stream_, a);
+          else hipLaunchKernelGGL(k_costvol<8>, grid, dim3(256), 0, stream_, a);
+          break;
+        }
+        case Op::REGRESS: {
+          const RegressArgs &r = rg_[o.stage - 1];
+          hipLaunchKernelGGL(k_regress, dim3(cdiv(r.h * r.w, 256)), dim3(256), 0, stream_, r);
+          break;
+        }
+        case Op::EDGE:
+          hipLaunchKernelGGL(k_filter_init, dim3(1), dim3(64), 0, stream_, d_state_, filter_rank_);
+          hipLaunchKernelGGL(k_edge, dim3(cdiv(H_ * W_, 256)), dim3(256), 0, stream_, T("depth3").d, T("edge").d, H_, W_);
+          break;
+        case Op::HIST:
+          hipLaunchKernelGGL(k_hist, dim3(std::min(cdiv(H_ * W_, 256), 512)), dim3(256), 0, stream_, T("edge").d, H_ * W_, o.shift, o.bits, d_state_, d_hist_);
+          break;
+        case Op::SCAN:
+          hipLaunchKernelGGL(k_scan, dim3(1), dim3(256), 0, stream_, d_state_, d_hist_, o.shift, o.bits);
+          break;
+        case Op::APPLY:
+          hipLaunchKernelGGL(k_apply, dim3(cdiv(H_ * W_, 256)), dim3(256), 0, stream_, T("edge").d, d_state_, T("depth3").d, T("conf3").d,
+                             T("depth").d, T("confidence").d, H_ * W_);
+          break;
+      }
+    }
+    if (ev) DR_HIP(hipEventRecord((*ev)[i], stream_));
+    DR_HIP(hipGetLastError());
+  }
+
+  int device_;
+  Blob blob_;
+  hipStream_t stream_ = nullptr;
+  DeviceArena consts_;
+  const float *lut_ = nullptr;
+  std::unique_ptr<DeviceArena> plan_arena_;
+  std::map<std::string, DevTensor> tensors_;
+  std::vector<Op> ops_;
+  std::vector<void *> misc_;
+  CostVolArgs cv_[3];
+  RegressArgs rg_[3];
+  uint8_t *d_bgr_ = nullptr, *h_in_ = nullptr;
+  float *h_out_ = nullptr;
+  unsigned *d_state_ = nullptr, *d_hist_ = nullptr;
+  unsigned filter_rank_ = 0;
+  int H_ = 0, W_ = 0, V_ = 0;
+
+  std::thread worker_;
+  std::mutex mu_;
+  std::condition_variable input_cv_, done_cv_;
+  bool running_ = true;
+  volatile bool unprocessed_ = false;
+  bool has_output_ = false;
+  std::string worker_error_;
+};
+
+}  // namespace dr
+
+// ==================================================================== C ABI
+using dr::guarded;
+struct drm_s {
+  std::unique_ptr<dr::MvsEngine> e;
+};
+
+extern "C" {
+
+const char *dr_last_error(void) { return dr::last_error_slot().c_str(); }
+const char *dr_version(void) { return "dr_mi355x 0.1 gfx950"; }
+
+int drm_create(const char *weights_path, int device, drm_t **out) {
+  return guarded([&] {
+    if (!weights_path || !out) dr::fail(DR_ERR_ARG, "drm_create: null argument");
+    auto *h = new drm_s();
+    try { h->e.reset(new dr::MvsEngine(weights_path, device)); } catch (...) { delete h; throw; }
+    *out = h;
+  });
+}
+void drm_destroy(drm_t *h) { delete h; }
+int drm_call_async(drm_t *h, int height, int width, int view_num, int ref_index, const uint8_t *const *bgrs, const float *K9,
+                   const float *const *c2ws, float depth_min, float depth_max, float discard_percentage) {
+  return guarded([&] { h->e->call_async(height, width, view_num, ref_index, bgrs, K9, c2ws, depth_min, depth_max, discard_percentage); });
+}
+int drm_ready(drm_t *h) { return h->e->ready() ? 1 : 0; }
+int drm_wait(drm_t *h) { return guarded([&] { h->e->wait(); }); }
+int drm_get_result(drm_t *h, float *depth, float *confidence, float *depth_dense, float *confidence_dense) {
+  return guarded([&] { h->e->get_result(depth, confidence, depth_dense, confidence_dense); });
+}
+int drm_upload(drm_t *h, int height, int width, int view_num, int ref_index, const uint8_t *const *bgrs, const float *K9,
+               const float *const *c2ws, float depth_min, float depth_max, float discard_percentage) {
+  return guarded([&] { h->e->upload(height, width, view_num, ref_index, bgrs, K9, c2ws, depth_min, depth_max, discard_percentage); });
+}
+int drm_forward(drm_t *h, int iters, float *ms_total) { return guarded([&] { h->e->forward_n(iters, ms_total); }); }
+int drm_download(drm_t *h, float *depth, float *confidence, float *depth_dense, float *confidence_dense) {
+  return guarded([&] { h->e->download(depth, confidence, depth_dense, confidence_dense); });
+}
+int drm_get_stage_output(drm_t *h, int stage, float *depth, float *confidence) {
+  return guarded([&] {
+    if (stage < 1 || stage > 3) dr::fail(DR_ERR_ARG, "stage must be 1..3");
+    size_t n; int dims[4];
+    h->e->get_tensor(("depth" + std::to_string(stage)).c_str(), nullptr, 0, &n, dims);
+    h->e->get_tensor(("depth" + std::to_string(stage)).c_str(), depth, n, &n, dims);
+    h->e->get_tensor(("conf" + std::to_string(stage)).c_str(), confidence, n, &n, dims);
+  });
+}
+int drm_get_tensor(drm_t *h, const char *name, float *out, size_t n_max, size_t *n, int dims[4]) {
+  return guarded([&] { h->e->get_tensor(name, out, n_max, n, dims); });
+}
+int drm_profile(drm_t *h, char *names, size_t names_cap, float *ms, int cap, int *count) {
+  return guarded([&] {
+    std::string nm; std::vector<float> t;
+    h->e->profile(nm, t);
+    if (count) *count = (int)t.size();
+    if (names && names_cap) { strncpy(names, nm.c_str(), names_cap - 1); names[names_cap - 1] = 0; }
+    for (int i = 0; i < (int)t.size() && i < cap; ++i) ms[i] = t[i];
+  });
+}
+int drm_work(drm_t *h, double *flops, double *bytes) { return guarded([&] { h->e->work(flops, bytes); }); }
+
+int drm_debug_conv(int device, const float *in, int D, int H, int W, int Cin, const float *weight, int Cout, int kd, int kh, int kw,
+                   int sd, int sh, int sw, int transposed, const float *scale, const float *bias, int relu, const float *add,
+                   int add_up2, float *out, int out_dims[3]) {
+  return guarded([&] {
+    using namespace dr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= device) fail(DR_ERR_DEVICE, "no HIP device %d", device);
+    DR_HIP(hipSetDevice(device));
+    DeviceArena arena;
+    ConvLayer L;
+    L.Cin = Cin; L.Cout = Cout; L.kd = kd; L.kh = kh; L.kw = kw; L.sd = sd; L.sh = sh; L.sw = sw;
+    L.transposed = transposed != 0; L.weight = weight; L.relu = relu != 0;
+    if (scale) L.scale.assign(scale, scale + Cout);
+    if (bias) L.bias.assign(bias, bias + Cout);
+    const ConvMode mode = (!transposed && sw == 1 && Cout == 8) ? CONV_XPAIR : ((!transposed && sw == 1 && Cout == 1) ? CONV_X8 : CONV_NORMAL);
+    auto cz = axis_classes(kd, sd, L.transposed, D), cy = axis_classes(kh, sh, L.transposed, H), cx = axis_classes(kw, sw, L.transposed, W);
+    const int oD = L.transposed ? D * sd : cz[0].npos, oH = L.transposed ? H * sh : cy[0].npos, oW = L.transposed ? W * sw : cx[0].npos;
+    std::vector<float> hin(in, in + (size_t)D * H * W * Cin);
+    float *d_in = arena.upload(hin);
+    const size_t on = (size_t)oD * oH * oW * Cout;
+    std::vector<float> zero(on, 0.f);
+    float *d_out = arena.upload(zero);
+    float *d_add = nullptr;
+    if (add) {
+      const size_t an = add_up2 ? (size_t)oD * (oH / 2) * (oW / 2) * Cout : on;
+      std::vector<float> ha(add, add + an);
+      d_add = arena.upload(ha);
+    }
+    ConvPlanOut P = plan_conv(L, mode, d_in, D, H, W, Cin, d_out, d_add, add_up2 ? 2 : 1, arena);
+    for (auto &cl : P.launches) launch_conv(cl, nullptr);
+    DR_HIP(hipDeviceSynchronize());
+    DR_HIP(hipGetLastError());
+    DR_HIP(hipMemcpy(out, d_out, on * 4, hipMemcpyDeviceToHost));
+    if (out_dims) { out_dims[0] = oD; out_dims[1] = oH; out_dims[2] = oW; }
+  });
+}
+
+}  // extern "C"

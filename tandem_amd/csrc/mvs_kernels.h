@@ -1,0 +1,294 @@
+// mvs_kernels.h -- the non-convolution kernels of the CVA-MVSNet depth pipeline (gfx950):
+//   k_preprocess : u8 BGR HWC -> f32 RGB0 channels-last          (dr_mvsnet.cpp:184-217)
+//   k_costvol    : depth hypotheses + homography warp + bilinear fetch + view-aggregation gate,
+//                  accumulated over all source views in registers  (module.py:764-908, :1061-1110,
+//                  cva_mvsnet.py:133-152, :73-83)
+//   k_regress    : softmax over D, depth expectation, 4-neighbour confidence (module.py:1116-1133)
+//   k_edge / k_hist / k_scan / k_apply : 5x5 order-statistic edge filter with an exact
+//                  radix-select quantile                            (module.py:1320-1361)
+// All HBM-bound: coalesced float4 channels-last accesses, no re-materialised intermediates
+// (the reference writes and re-reads a (C,D,h,w) volume ~7 times per source view).
+#pragma once
+#include "dr_common.h"
+
+namespace dr {
+
+constexpr int kMaxSrc = 7;  // view_num <= 8
+
+// ------------------------------------------------------------------ pre-processing
+// lut[b] = float(double(float(b)) / 255.0)  (the reference divides in double, dr_mvsnet.cpp:212-214)
+__global__ void k_preprocess(const uint8_t *__restrict__ bgr, float4 *__restrict__ img, const float *__restrict__ lut,
+                             size_t npix) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix) return;
+  const uint8_t *p = bgr + 3 * i;
+  img[i] = make_float4(lut[p[2]], lut[p[1]], lut[p[0]], 0.f);
+}
+
+// ------------------------------------------------------------------ depth hypotheses
+struct PlaneArgs {
+  const float *prev;  // previous stage depth (hp x wp) or nullptr for the uniform stage
+  int hp, wp;
+  int D;
+  float dmin, interval;          // stage 1: d_k = dmin + interval * k            (module.py:1494-1496)
+  float half_range, full_range;  // later : lo = max(cur - half_range, 1e-3), hi = lo + full_range
+};
+
+// F.interpolate(scale 2, bilinear, align_corners=False): src = 0.5*(dst+0.5)-0.5 clamped at 0  (cva_mvsnet.py:144-147)
+__device__ inline float up2_bilinear(const float *__restrict__ prev, int hp, int wp, int y, int x) {
+  const float sy = fmaxf(0.5f * ((float)y + 0.5f) - 0.5f, 0.f);
+  const float sx = fmaxf(0.5f * ((float)x + 0.5f) - 0.5f, 0.f);
+  const int y0 = (int)sy, x0 = (int)sx;
+  const int y1 = y0 + (y0 < hp - 1 ? 1 : 0), x1 = x0 + (x0 < wp - 1 ? 1 : 0);
+  const float ly = sy - (float)y0, lx = sx - (float)x0;
+  const float v00 = prev[y0 * wp + x0], v01 = prev[y0 * wp + x1], v10 = prev[y1 * wp + x0], v11 = prev[y1 * wp + x1];
+  return (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+}
+
+struct PixelPlanes {  // per-pixel hypothesis generator
+  float lo, rng, invD;
+  bool uniform;
+  __device__ inline float at(const PlaneArgs &p, int k) const {
+    return uniform ? p.dmin + p.interval * (float)k : lo + rng * ((float)k * invD);
+  }
+};
+
+__device__ inline PixelPlanes make_planes(const PlaneArgs &p, int y, int x) {
+  PixelPlanes r;
+  r.uniform = p.prev == nullptr;
+  r.lo = 0.f; r.rng = 0.f; r.invD = 1.f / (float)p.D;
+  if (!r.uniform) {
+    const float cur = up2_bilinear(p.prev, p.hp, p.wp, y, x);
+    r.lo = fmaxf(cur - p.half_range, 0.001f);      // module.py:1518-1523
+    const float hi = r.lo + p.full_range;          // module.py:1526
+    r.rng = hi - r.lo;                             // module.py:1531 (depth_max - depth_min)
+  }
+  return r;
+}
+
+// ------------------------------------------------------------------ cost volume
+struct CostVolArgs {
+  const float *feat;  // (V,h,w,C) channels-last, view 0 = reference
+  float *vol;         // (D,h,w,C)
+  PlaneArgs planes;
+  int V, h, w, dchunk;
+  float M[kMaxSrc][12];  // per source view: rows of [rot | trans] of ref-pixel -> src-pixel (module.py:795-809)
+  float gw[32];          // gate conv weight per channel
+  float gA1, gB1, gA2, gB2;  // folded gate affine: g = relu(A2*relu(A1*s + B1) + B2)
+  float nsrc_f;          // float(V-1)
+  int view_aggregation;
+};
+
+__device__ inline float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+template <int C>
+__global__ __launch_bounds__(256) void k_costvol(const CostVolArgs a) {
+  constexpr int LPV = C / 4;        // lanes per pixel (each owns 4 channels)
+  constexpr int PXB = 256 / LPV;    // pixels per block
+  const int tid = threadIdx.x, q = tid % LPV;
+  const int x = blockIdx.x * PXB + tid / LPV, y = blockIdx.y;
+  const int d0 = blockIdx.z * a.dchunk, d1 = min(a.planes.D, d0 + a.dchunk);
+  const bool live = x < a.w;
+  const int xc = live ? x : a.w - 1;  // keep dead lanes running for the cross-lane gate sum
+  const int h = a.h, w = a.w, nsrc = a.V - 1;
+  const size_t plane = (size_t)h * w * C;
+
+  const float4 ref = ld4(a.feat + ((size_t)y * w + xc) * C + q * 4);
+  const PixelPlanes pp = make_planes(a.planes, y, xc);
+  float rx[kMaxSrc], ry[kMaxSrc], rz[kMaxSrc];
+#pragma unroll
+  for (int v = 0; v < kMaxSrc; ++v) {
+    if (v < nsrc) {
+      const float *m = a.M[v];
+      rx[v] = m[0] * (float)xc + m[1] * (float)y + m[2];
+      ry[v] = m[4] * (float)xc + m[5] * (float)y + m[6];
+      rz[v] = m[8] * (float)xc + m[9] * (float)y + m[10];
+    }
+  }
+  const float4 gw = make_float4(a.gw[q * 4], a.gw[q * 4 + 1], a.gw[q * 4 + 2], a.gw[q * 4 + 3]);
+
+  for (int d = d0; d < d1; ++d) {
+    const float depth = pp.at(a.planes, d);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 s1 = ref, s2 = make_float4(ref.x * ref.x, ref.y * ref.y, ref.z * ref.z, ref.w * ref.w);
+#pragma unroll
+    for (int v = 0; v < kMaxSrc; ++v) {
+      if (v >= nsrc) break;
+      const float *m = a.M[v];
+      const float px = rx[v] * depth + m[3], py = ry[v] * depth + m[7], pz = rz[v] * depth + m[11];
+      float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pz >= 0.001f) {  // module.py:861,887: negative / tiny depth -> 0
+        const float u = px / pz, vv = py / pz;
+        if (u > -1.f && u < (float)w && vv > -1.f && vv < (float)h) {  // else all four taps are padding zeros
+          const float fx0 = floorf(u), fy0 = floorf(vv);
+          const int x0 = (int)fx0, y0 = (int)fy0;
+          const float ax = u - fx0, ay = vv - fy0;
+          const float *f = a.feat + (size_t)(v + 1) * plane + q * 4;
+          const bool xl = x0 >= 0, xr = x0 + 1 < w, yt = y0 >= 0, yb = y0 + 1 < h;
+          const float w00 = (1.f - ax) * (1.f - ay), w01 = ax * (1.f - ay), w10 = (1.f - ax) * ay, w11 = ax * ay;
+          if (xl && yt) { const float4 t = ld4(f + ((size_t)y0 * w + x0) * C); wv.x += t.x * w00; wv.y += t.y * w00; wv.z += t.z * w00; wv.w += t.w * w00; }
+          if (xr && yt) { const float4 t = ld4(f + ((size_t)y0 * w + x0 + 1) * C); wv.x += t.x * w01; wv.y += t.y * w01; wv.z += t.z * w01; wv.w += t.w * w01; }
+          if (xl && yb) { const float4 t = ld4(f + ((size_t)(y0 + 1) * w + x0) * C); wv.x += t.x * w10; wv.y += t.y * w10; wv.z += t.z * w10; wv.w += t.w * w10; }
+          if (xr && yb) { const float4 t = ld4(f + ((size_t)(y0 + 1) * w + x0 + 1) * C); wv.x += t.x * w11; wv.y += t.y * w11; wv.z += t.z * w11; wv.w += t.w * w11; }
+        }
+      }
+      if (a.view_aggregation) {
+        const float4 df = make_float4(wv.x - ref.x, wv.y - ref.y, wv.z - ref.z, wv.w - ref.w);
+        const float4 d2 = make_float4(df.x * df.x, df.y * df.y, df.z * df.z, df.w * df.w);
+        float s = gw.x * d2.x + gw.y * d2.y + gw.z * d2.z + gw.w * d2.w;
+#pragma unroll
+        for (int msk = 1; msk < LPV; msk <<= 1) s += __shfl_xor(s, msk);
+        const float g1 = fmaxf(a.gA1 * s + a.gB1, 0.f);
+        const float g = fmaxf(a.gA2 * g1 + a.gB2, 0.f) + 1.f;
+        acc.x += g * d2.x; acc.y += g * d2.y; acc.z += g * d2.z; acc.w += g * d2.w;
+      } else {  // plain variance incl. the reference view (module.py:1074-1075,1094-1096,1110)
+        s1.x += wv.x; s1.y += wv.y; s1.z += wv.z; s1.w += wv.w;
+        s2.x += wv.x * wv.x; s2.y += wv.y * wv.y; s2.z += wv.z * wv.z; s2.w += wv.w * wv.w;
+      }
+    }
+    float4 o;
+    if (a.view_aggregation) {
+      o = make_float4(acc.x / a.nsrc_f, acc.y / a.nsrc_f, acc.z / a.nsrc_f, acc.w / a.nsrc_f);
+    } else {
+      const float V = a.nsrc_f + 1.f;
+      const float4 mu = make_float4(s1.x / V, s1.y / V, s1.z / V, s1.w / V);
+      o = make_float4(s2.x / V - mu.x * mu.x, s2.y / V - mu.y * mu.y, s2.z / V - mu.z * mu.z, s2.w / V - mu.w * mu.w);
+    }
+    if (live) *reinterpret_cast<float4 *>(a.vol + (size_t)d * plane + ((size_t)y * w + x) * C + q * 4) = o;
+  }
+}
+
+// ------------------------------------------------------------------ regression
+struct RegressArgs {
+  const float *logits;  // (D,h,w)
+  float *depth, *conf;  // (h,w)
+  PlaneArgs planes;
+  int h, w;
+};
+
+__global__ __launch_bounds__(256) void k_regress(const RegressArgs a) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x, hw = a.h * a.w;
+  if (n >= hw) return;
+  const int y = n / a.w, x = n - y * a.w, D = a.planes.D;
+  const PixelPlanes pp = make_planes(a.planes, y, x);
+  float mx = -INFINITY;
+  for (int k = 0; k < D; ++k) mx = fmaxf(mx, a.logits[(size_t)k * hw + n]);
+  float sum = 0.f;
+  for (int k = 0; k < D; ++k) sum += expf(a.logits[(size_t)k * hw + n] - mx);
+  float dep = 0.f, ek = 0.f;
+  for (int k = 0; k < D; ++k) {
+    const float p = expf(a.logits[(size_t)k * hw + n] - mx) / sum;
+    dep += p * pp.at(a.planes, k);
+    ek += p * (float)k;
+  }
+  int idx = (int)ek;  // .long() truncation, module.py:1131
+  idx = min(max(idx, 0), D - 1);
+  float c = 0.f;
+  for (int k = idx - 1; k <= idx + 2; ++k)
+    if (k >= 0 && k < D) c += expf(a.logits[(size_t)k * hw + n] - mx) / sum;
+  a.depth[n] = dep;
+  a.conf[n] = c;
+}
+
+// ------------------------------------------------------------------ edge filter
+// edge(x,y) = 15th smallest of |d(nb) - d(c)| over the zero-padded 5x5 window (incl. the centre's 0).
+__global__ __launch_bounds__(256) void k_edge(const float *__restrict__ depth, float *__restrict__ edge, int h, int w) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= h * w) return;
+  const int y = n / w, x = n - y * w;
+  const float c = depth[n];
+  float v[25];
+#pragma unroll
+  for (int dy = -2; dy <= 2; ++dy)
+#pragma unroll
+    for (int dx = -2; dx <= 2; ++dx) {
+      const int yy = y + dy, xx = x + dx;
+      const float nb = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? depth[yy * w + xx] : 0.f;
+      v[(dy + 2) * 5 + dx + 2] = fabsf(nb - c);
+    }
+  float kth = 0.f;
+#pragma unroll
+  for (int i = 0; i < 25; ++i) {
+    int less = 0, leq = 0;
+#pragma unroll
+    for (int jx = 0; jx < 25; ++jx) {
+      less += v[jx] < v[i] ? 1 : 0;
+      leq += v[jx] <= v[i] ? 1 : 0;
+    }
+    if (less <= 14 && leq > 14) kth = v[i];  // k = 15 (1-based), module.py:1336,1343
+  }
+  edge[n] = kth;
+}
+
+// Exact k-th smallest of non-negative floats by a 3-level radix select on the bit pattern
+// (monotone for x >= 0).  state: [0] prefix value, [1] prefix mask, [2] remaining rank, [3] threshold bits.
+__global__ void k_filter_init(unsigned *__restrict__ state, unsigned rank) {
+  if (threadIdx.x < 4) state[threadIdx.x] = threadIdx.x == 2 ? rank : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_hist(const float *__restrict__ edge, int n, int shift, int bits,
+                                              const unsigned *__restrict__ state, unsigned *__restrict__ hist) {
+  __shared__ unsigned sh[2048];
+  for (int i = threadIdx.x; i < 2048; i += blockDim.x) sh[i] = 0;
+  __syncthreads();
+  const unsigned pv = state[0], pm = state[1], mask = (1u << bits) - 1u;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const unsigned key = __float_as_uint(edge[i]);
+    if ((key & pm) == pv) atomicAdd(&sh[(key >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2048; i += blockDim.x)
+    if (sh[i]) atomicAdd(&hist[i], sh[i]);
+}
+
+__global__ __launch_bounds__(256) void k_scan(unsigned *__restrict__ state, unsigned *__restrict__ hist, int shift, int bits) {
+  // one block of 256 threads, 8 bins each: block prefix sum, locate the bin holding rank state[2]
+  __shared__ unsigned part[256];
+  __shared__ unsigned sel[2];
+  const int t = threadIdx.x;
+  const unsigned nb = 1u << bits;
+  unsigned loc[8], s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { loc[i] = hist[t * 8 + i]; s += loc[i]; }
+  part[t] = s;
+  if (t == 0) { sel[0] = nb - 1u; sel[1] = 0; }
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {  // Hillis-Steele inclusive scan
+    const unsigned add = t >= off ? part[t - off] : 0u;
+    __syncthreads();
+    part[t] += add;
+    __syncthreads();
+  }
+  const unsigned rank = state[2], excl = part[t] - s;
+  if (s && excl <= rank && rank < excl + s) {
+    unsigned cum = excl;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (cum + loc[i] > rank) { sel[0] = t * 8 + i; sel[1] = cum; break; }
+      cum += loc[i];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) hist[t * 8 + i] = 0;
+  if (t == 0) {
+    const unsigned v = state[0] | (sel[0] << shift);
+    state[0] = v;
+    state[1] |= ((nb - 1u) << shift);
+    state[2] = rank - sel[1];
+    state[3] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_apply(const float *__restrict__ edge, const unsigned *__restrict__ state,
+                                               const float *__restrict__ depth_dense, const float *__restrict__ conf_dense,
+                                               float *__restrict__ depth, float *__restrict__ conf, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float thr = __uint_as_float(state[3]);
+  const bool m = edge[i] > thr;  // strict, module.py:1357
+  depth[i] = m ? 0.f : depth_dense[i];
+  conf[i] = m ? 0.f : conf_dense[i];
+}
+
+}  // namespace dr

@@ -1,0 +1,137 @@
+"""Python mirror of TANDEM's `DrMvsnet` operator (tandem/libdr/dr_mvsnet/src/dr_mvsnet/dr_mvsnet.h:12-68)
+on top of the C ABI of libdr_mi355x.so.  Same method names, argument meaning and error behaviour
+(errors raise DrError instead of exit(EXIT_FAILURE)); results come from the HIP engine only."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, fptr, u8p, f32p
+
+
+class DrMvsnetOutput:
+    """dr_mvsnet.h:12-34: four H*W float arrays."""
+
+    def __init__(self, height, width):
+        self.height, self.width = height, width
+        self.depth = np.empty((height, width), np.float32)
+        self.confidence = np.empty((height, width), np.float32)
+        self.depth_dense = np.empty((height, width), np.float32)
+        self.confidence_dense = np.empty((height, width), np.float32)
+
+
+def _marshal(bgrs, intrinsic_matrix, cam_to_worlds):
+    bgrs = [np.ascontiguousarray(b, dtype=np.uint8) for b in bgrs]
+    c2ws = [np.ascontiguousarray(c, dtype=np.float32).reshape(16) for c in cam_to_worlds]
+    K = np.ascontiguousarray(intrinsic_matrix, dtype=np.float32).reshape(9)
+    V = len(bgrs)
+    pb = (u8p * V)(*[b.ctypes.data_as(u8p) for b in bgrs])
+    pc = (f32p * V)(*[fptr(c) for c in c2ws])
+    return bgrs, c2ws, K, pb, pc
+
+
+class DrMvsnet:
+    def __init__(self, filename, device=0):
+        """dr_mvsnet.h:38 `explicit DrMvsnet(char const* filename)`; filename = TDMW weight blob."""
+        self._h = C.c_void_p()
+        check(_lib.lib().drm_create(str(filename).encode(), int(device), C.byref(self._h)))
+        self._hw = None
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            _lib.lib().drm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def CallAsync(self, height, width, view_num, ref_index, bgrs, intrinsic_matrix, cam_to_worlds, depth_min,
+                  depth_max, discard_percentage, debug_print=False):
+        """dr_mvsnet.h:43-53.  Blocking for the last input, non-blocking for this one."""
+        assert len(bgrs) == view_num and len(cam_to_worlds) == view_num
+        keep = _marshal(bgrs, intrinsic_matrix, cam_to_worlds)
+        check(_lib.lib().drm_call_async(self._h, height, width, view_num, ref_index, keep[3], fptr(keep[2]), keep[4],
+                                        depth_min, depth_max, discard_percentage))
+        self._hw = (height, width)
+
+    def Ready(self):
+        return bool(_lib.lib().drm_ready(self._h))
+
+    def Wait(self):
+        check(_lib.lib().drm_wait(self._h))
+
+    def GetResult(self):
+        """dr_mvsnet.h:56 -- blocking; a second call without a new CallAsync is a protocol error."""
+        if self._hw is None:
+            raise _lib.DrError(2, "GetResult before CallAsync")
+        out = DrMvsnetOutput(*self._hw)
+        check(_lib.lib().drm_get_result(self._h, fptr(out.depth), fptr(out.confidence), fptr(out.depth_dense),
+                                        fptr(out.confidence_dense)))
+        return out
+
+    # ---- device-resident / introspection hooks (no reference counterpart) ----
+    def upload(self, height, width, view_num, ref_index, bgrs, intrinsic_matrix, cam_to_worlds, depth_min, depth_max,
+               discard_percentage):
+        keep = _marshal(bgrs, intrinsic_matrix, cam_to_worlds)
+        check(_lib.lib().drm_upload(self._h, height, width, view_num, ref_index, keep[3], fptr(keep[2]), keep[4],
+                                    depth_min, depth_max, discard_percentage))
+        self._hw = (height, width)
+
+    def forward(self, iters=1):
+        ms = C.c_float()
+        check(_lib.lib().drm_forward(self._h, iters, C.byref(ms)))
+        return ms.value
+
+    def download(self):
+        out = DrMvsnetOutput(*self._hw)
+        check(_lib.lib().drm_download(self._h, fptr(out.depth), fptr(out.confidence), fptr(out.depth_dense),
+                                      fptr(out.confidence_dense)))
+        return out
+
+    def stage_output(self, stage):
+        sc = 2 ** (3 - stage)
+        h, w = self._hw[0] // sc, self._hw[1] // sc
+        d, c = np.empty((h, w), np.float32), np.empty((h, w), np.float32)
+        check(_lib.lib().drm_get_stage_output(self._h, stage, fptr(d), fptr(c)))
+        return d, c
+
+    def tensor(self, name):
+        n, dims = C.c_size_t(), (C.c_int * 4)()
+        check(_lib.lib().drm_get_tensor(self._h, name.encode(), None, 0, C.byref(n), dims))
+        out = np.empty(tuple(dims), np.float32)
+        check(_lib.lib().drm_get_tensor(self._h, name.encode(), fptr(out), n.value, C.byref(n), dims))
+        return out
+
+    def profile(self):
+        names = C.create_string_buffer(1 << 16)
+        ms = (C.c_float * 512)()
+        cnt = C.c_int()
+        check(_lib.lib().drm_profile(self._h, names, len(names), ms, 512, C.byref(cnt)))
+        return list(zip(names.value.decode().strip().split("\n"), list(ms)[:cnt.value]))
+
+    def work(self):
+        f, b = C.c_double(), C.c_double()
+        check(_lib.lib().drm_work(self._h, C.byref(f), C.byref(b)))
+        return f.value, b.value
+
+
+def debug_conv(x, weight, stride=(1, 1, 1), transposed=False, scale=None, bias=None, relu=False, add=None,
+               add_up2=False, device=0):
+    """Kernel unit-test hook: x (D,H,W,Cin) channels-last, weight in torch layout; returns (Do,Ho,Wo,Cout)."""
+    x = np.ascontiguousarray(x, np.float32)
+    w = np.ascontiguousarray(weight, np.float32)
+    D, H, W, Cin = x.shape
+    Cout = w.shape[1] if transposed else w.shape[0]
+    kd, kh, kw = w.shape[2:]
+    sd, sh, sw = stride
+    oD, oH, oW = ((D * sd, H * sh, W * sw) if transposed else
+                  ((D + 2 * (kd // 2) - kd) // sd + 1, (H + 2 * (kh // 2) - kh) // sh + 1, (W + 2 * (kw // 2) - kw) // sw + 1))
+    out = np.empty((oD, oH, oW, Cout), np.float32)
+    dims = (C.c_int * 3)()
+    opt = lambda a: fptr(np.ascontiguousarray(a, np.float32)) if a is not None else None
+    keep = [np.ascontiguousarray(a, np.float32) if a is not None else None for a in (scale, bias, add)]
+    check(_lib.lib().drm_debug_conv(device, fptr(x), D, H, W, Cin, fptr(w), Cout, kd, kh, kw, sd, sh, sw,
+                                    int(transposed), fptr(keep[0]) if keep[0] is not None else None,
+                                    fptr(keep[1]) if keep[1] is not None else None, int(relu),
+                                    fptr(keep[2]) if keep[2] is not None else None, int(add_up2), fptr(out), dims))
+    assert tuple(dims) == (oD, oH, oW)
+    return out

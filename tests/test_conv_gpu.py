@@ -1,0 +1,83 @@
+"""-m gpu: the MFMA tap-table convolution kernel (tandem_amd/csrc/conv_mfma.h) through the C ABI
+(drm_debug_conv) against torch fp32 CPU convolutions of the same op -- every layer shape class the
+depth pipeline uses (FeatureNet module.py:461-494, CostRegNet module.py:546-575)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # name, (D,H,W), Cin, Cout, (kd,kh,kw), stride, transposed, relu, add ("none"|"same"|"up2")
+    ("fn.conv0.0 rgb0->8 xpair", (2, 32, 64), 4, 8, (1, 3, 3), (1, 1, 1), False, True, "none"),
+    ("fn.conv0.1 8->8 xpair", (2, 32, 64), 8, 8, (1, 3, 3), (1, 1, 1), False, True, "none"),
+    ("fn.conv1.0 5x5s2 8->16", (2, 32, 64), 8, 16, (1, 5, 5), (1, 2, 2), False, True, "none"),
+    ("fn.conv2.0 5x5s2 16->32", (2, 32, 32), 16, 32, (1, 5, 5), (1, 2, 2), False, True, "none"),
+    ("fn.conv2.1 32->32", (2, 16, 24), 32, 32, (1, 3, 3), (1, 1, 1), False, True, "none"),
+    ("fn.out1 1x1 32->32", (3, 8, 24), 32, 32, (1, 1, 1), (1, 1, 1), False, False, "none"),
+    ("fn.skip2 1x1 16->32 +up2", (2, 16, 48), 16, 32, (1, 1, 1), (1, 1, 1), False, False, "up2"),
+    ("fn.skip3 1x1 8->32 +up2", (2, 16, 48), 8, 32, (1, 1, 1), (1, 1, 1), False, False, "up2"),
+    ("fn.out2 32->16", (2, 16, 24), 32, 16, (1, 3, 3), (1, 1, 1), False, False, "none"),
+    ("fn.out3 32->8 xpair", (2, 16, 32), 32, 8, (1, 3, 3), (1, 1, 1), False, False, "none"),
+    ("cr.conv0 32->8 xpair", (12, 16, 24), 32, 8, (3, 3, 3), (1, 1, 1), False, True, "none"),
+    ("cr.conv0 16->8 xpair", (8, 12, 24), 16, 8, (3, 3, 3), (1, 1, 1), False, True, "none"),
+    ("cr.conv1 8->16 s2", (12, 16, 24), 8, 16, (3, 3, 3), (2, 2, 2), False, True, "none"),
+    ("cr.conv2 16->16", (6, 8, 12), 16, 16, (3, 3, 3), (1, 1, 1), False, True, "none"),
+    ("cr.conv3 16->32 s2", (6, 8, 12), 16, 32, (3, 3, 3), (2, 2, 2), False, True, "none"),
+    ("cr.conv5 32->64 s2 odd", (6, 15, 20), 32, 64, (3, 3, 3), (2, 2, 2), False, True, "none"),
+    ("cr.conv5 32->64 s(1,2,2)", (1, 8, 12), 32, 64, (3, 3, 3), (1, 2, 2), False, True, "none"),
+    ("cr.conv6 64->64", (3, 4, 6), 64, 64, (3, 3, 3), (1, 1, 1), False, True, "none"),
+    ("cr.conv7 deconv 64->32 +skip", (3, 4, 6), 64, 32, (3, 3, 3), (2, 2, 2), True, True, "same"),
+    ("cr.conv7 deconv s(1,2,2)", (1, 4, 6), 64, 32, (3, 3, 3), (1, 2, 2), True, True, "same"),
+    ("cr.conv9 deconv 32->16 +skip", (3, 5, 10), 32, 16, (3, 3, 3), (2, 2, 2), True, True, "same"),
+    ("cr.conv11 deconv 16->8 +skip", (6, 8, 12), 16, 8, (3, 3, 3), (2, 2, 2), True, True, "same"),
+    ("cr.prob 8->1 x8", (12, 16, 24), 8, 1, (3, 3, 3), (1, 1, 1), False, False, "none"),
+    ("cr.prob 8->1 x8 D=4", (4, 16, 16), 8, 1, (3, 3, 3), (1, 1, 1), False, False, "none"),
+]
+
+
+def torch_ref(x, w, stride, transposed, scale, bias, relu, add, add_mode):
+    xt = torch.from_numpy(x).permute(3, 0, 1, 2)[None]  # (1,C,D,H,W)
+    wt = torch.from_numpy(w)
+    pad = tuple(k // 2 for k in w.shape[2:])
+    if transposed:
+        y = F.conv_transpose3d(xt, wt, None, stride, pad, tuple(s - 1 for s in stride))
+    else:
+        y = F.conv3d(xt, wt, None, stride, pad)
+    y = y * torch.from_numpy(scale).view(1, -1, 1, 1, 1) + torch.from_numpy(bias).view(1, -1, 1, 1, 1)
+    if relu:
+        y = F.relu(y)
+    if add_mode == "same":
+        y = y + torch.from_numpy(add).permute(3, 0, 1, 2)[None]
+    elif add_mode == "up2":
+        a = torch.from_numpy(add).permute(0, 3, 1, 2)  # (D,C,h,w) nearest x2 in (h,w)
+        y = y + F.interpolate(a, scale_factor=2, mode="nearest").permute(1, 0, 2, 3)[None]
+    return y[0].permute(1, 2, 3, 0).contiguous().numpy()
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_matches_torch(case):
+    from tandem_amd.dr_mvsnet import debug_conv
+    name, dims, cin, cout, k, stride, transposed, relu, add_mode = case
+    rng = np.random.RandomState(abs(hash(name)) % (2 ** 31))
+    x = rng.randn(*dims, cin).astype(np.float32)
+    wshape = (cin, cout) + k if transposed else (cout, cin) + k
+    w = (rng.randn(*wshape) / np.sqrt(cin * np.prod(k))).astype(np.float32)
+    scale = (1.0 + 0.3 * rng.randn(cout)).astype(np.float32)
+    bias = (0.2 * rng.randn(cout)).astype(np.float32)
+    if transposed:
+        od = tuple(d * s for d, s in zip(dims, stride))
+    else:
+        od = tuple((d + 2 * (kk // 2) - kk) // s + 1 for d, kk, s in zip(dims, k, stride))
+    add = None
+    if add_mode == "same":
+        add = rng.randn(*od, cout).astype(np.float32)
+    elif add_mode == "up2":
+        add = rng.randn(od[0], od[1] // 2, od[2] // 2, cout).astype(np.float32)
+    got = debug_conv(x, w, stride, transposed, scale, bias, relu, add, add_mode == "up2")
+    ref = torch_ref(x, w, stride, transposed, scale, bias, relu, add, add_mode)
+    assert got.shape == ref.shape
+    err = np.abs(got - ref).max()
+    tol = 2e-5 * max(1.0, np.abs(ref).max())  # fp32 reassociation only (MFMA fp32 == fmaf chain)
+    assert err <= tol, f"{name}: max|err| {err:.3e} > {tol:.3e}"
