@@ -48,11 +48,13 @@ struct ConvArgs {
 };
 
 constexpr int kConvThreads = 256;
-constexpr int kPT = 4;  // position tiles (16 positions each) per wave
 constexpr size_t kConvMaxLds = 160 * 1024;  // gfx950: 160 KiB LDS per CU, one workgroup may take all of it
 
-template <int CI, int CT>
+// PT = position tiles (16 positions each) per wave: 4 normally, 1 for strided layers whose halo tile
+// would not fit LDS otherwise.
+template <int CI, int CT, int PT>
 __global__ __launch_bounds__(kConvThreads) void k_conv(const ConvArgs a) {
+  constexpr int kPT = PT;
   extern __shared__ float4 lds4[];
   float *lds = reinterpret_cast<float *>(lds4);
   constexpr int CIS = CI + 4;  // LDS floats per staged position (+4: spreads b128 reads over bank slots)
@@ -171,7 +173,7 @@ struct ConvLayer {  // logical description (torch semantics)
 
 struct ConvLaunch {
   ConvArgs args;
-  int ci, ct;
+  int ci, ct, pt;
   int grid;
   size_t lds_bytes;
   double flops;  // useful (algorithmic) flops of this launch
@@ -280,19 +282,24 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
     for (int o : Y.off) exy = std::max(exy, o + 1);
     for (int o : X.off) exx = std::max(exx, o + 1);
 
-    // ---- tile plan: 16 position tiles (4 per wave) arranged TZ x TY x TXT, LDS <= 64 KB ----
-    static const int cand[][3] = {{1, 1, 16}, {1, 2, 8}, {1, 4, 4}, {1, 8, 2}, {1, 16, 1}, {2, 1, 8}, {2, 2, 4},
-                                  {2, 4, 2}, {2, 8, 1}, {4, 1, 4}, {4, 2, 2}, {4, 4, 1}, {8, 1, 2}, {8, 2, 1}, {16, 1, 1}};
+    // ---- tile plan: 4*PT position tiles arranged TZ x TY x TXT; prefer <= 80 KB LDS (2 workgroups/CU) ----
+    static const int cand16[][3] = {{1, 1, 16}, {1, 2, 8}, {1, 4, 4}, {1, 8, 2}, {1, 16, 1}, {2, 1, 8}, {2, 2, 4},
+                                    {2, 4, 2}, {2, 8, 1}, {4, 1, 4}, {4, 2, 2}, {4, 4, 1}, {8, 1, 2}, {8, 2, 1}, {16, 1, 1}};
+    static const int cand4[][3] = {{1, 1, 4}, {1, 2, 2}, {1, 4, 1}, {2, 1, 2}, {2, 2, 1}, {4, 1, 1}};
     double best = 1e300;
-    int TZ = 0, TY = 0, TXT = 0, TZI = 0, TYI = 0, TXI = 0;
-    for (size_t limit : {size_t(64) * 1024, kConvMaxLds}) {  // prefer >= 2 workgroups per CU
-      for (auto &c : cand) {
+    int TZ = 0, TY = 0, TXT = 0, TZI = 0, TYI = 0, TXI = 0, PT = 0;
+    struct Try { int pt; size_t limit; };
+    for (const Try &tr : {Try{4, size_t(80) * 1024}, Try{1, size_t(80) * 1024}, Try{4, kConvMaxLds}, Try{1, kConvMaxLds}}) {
+      const int (*cand)[3] = tr.pt == 4 ? cand16 : cand4;
+      const int ncand = tr.pt == 4 ? 15 : 6;
+      for (int ci = 0; ci < ncand; ++ci) {
+        const int *c = cand[ci];
         const int tzi = (c[0] - 1) * Z.s + exz, tyi = (c[1] - 1) * Y.s + exy, txi = (c[2] * 16 - 1) * X.s + exx;
         const size_t bytes = (size_t)tzi * tyi * txi * CIS * 4;
-        if (bytes > limit) continue;
+        if (bytes > tr.limit) continue;
         const double tiles = (double)cdiv(Z.npos, c[0]) * cdiv(Y.npos, c[1]) * cdiv(X.npos, c[2] * 16);
-        const double cost = tiles * ((double)NU * npass * CT * kPT * 4 * 32.0 + (double)tzi * tyi * txi * (CI / 4) * npass / 256.0 * 160.0);
-        if (cost < best) { best = cost; TZ = c[0]; TY = c[1]; TXT = c[2]; TZI = tzi; TYI = tyi; TXI = txi; }
+        const double cost = tiles * ((double)NU * npass * CT * tr.pt * 4 * 32.0 + (double)tzi * tyi * txi * (CI / 4) * npass / 256.0 * 160.0);
+        if (cost < best) { best = cost; TZ = c[0]; TY = c[1]; TXT = c[2]; TZI = tzi; TYI = tyi; TXI = txi; PT = tr.pt; }
       }
       if (TZ) break;
     }
@@ -339,7 +346,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
     a.add_mode = add ? add_mode : 0;
     a.addH = R.outH / 2; a.addW = (mode == CONV_NORMAL ? R.outW : outWv) / 2;
     a.tilesD = cdiv(Z.npos, TZ); a.tilesH = cdiv(Y.npos, TY); a.tilesW = cdiv(X.npos, TXT * 16);
-    cl.ci = CI; cl.ct = CT;
+    cl.ci = CI; cl.ct = CT; cl.pt = PT;
     cl.grid = a.tilesD * a.tilesH * a.tilesW;
     cl.lds_bytes = (size_t)TZI * TYI * TXI * CIS * 4;
     cl.flops = 2.0 * Z.npos * Y.npos * X.npos * (mode == CONV_NORMAL ? 1 : shifts) * (double)ntz * nty *
@@ -349,18 +356,23 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   return R;
 }
 
+template <int CI, int CT, int PT>
+inline void launch_conv_inst(const ConvLaunch &c, hipStream_t st) {
+  static bool big = false;
+  if (c.lds_bytes > 64 * 1024 && !big) {
+    DR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv<CI, CT, PT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)kConvMaxLds));
+    big = true;
+  }
+  hipLaunchKernelGGL((k_conv<CI, CT, PT>), dim3(c.grid), dim3(kConvThreads), c.lds_bytes, st, c.args);
+}
+
 inline void launch_conv(const ConvLaunch &c, hipStream_t st) {
-  dim3 grid(c.grid), block(kConvThreads);
-#define DR_CONV_CASE(CI_, CT_)                                                          \
-  if (c.ci == CI_ && c.ct == CT_) {                                                     \
-    static bool big = false;                                                            \
-    if (c.lds_bytes > 64 * 1024 && !big) {                                              \
-      DR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv<CI_, CT_>),     \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvMaxLds)); \
-      big = true;                                                                       \
-    }                                                                                   \
-    hipLaunchKernelGGL((k_conv<CI_, CT_>), grid, block, c.lds_bytes, st, c.args);       \
-    return;                                                                             \
+#define DR_CONV_CASE(CI_, CT_)                                                  \
+  if (c.ci == CI_ && c.ct == CT_) {                                             \
+    if (c.pt == 4) launch_conv_inst<CI_, CT_, 4>(c, st);                        \
+    else launch_conv_inst<CI_, CT_, 1>(c, st);                                  \
+    return;                                                                     \
   }
   DR_CONV_CASE(4, 1)
   DR_CONV_CASE(8, 1)
