@@ -1,0 +1,83 @@
+"""ctypes wrapper of oracle/libtsdf_oracle.so (CPU ORACLE of the DrFusion path -- TEST INFRASTRUCTURE).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libtsdf_oracle.so")
+
+
+class Options(C.Structure):
+    _fields_ = [("voxel_size", C.c_float), ("num_buckets", C.c_int), ("bucket_size", C.c_int),
+                ("num_blocks", C.c_int), ("block_size", C.c_int), ("max_sdf_weight", C.c_int),
+                ("truncation_distance", C.c_float), ("max_sensor_depth", C.c_float),
+                ("min_sensor_depth", C.c_float), ("num_render_streams", C.c_int),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("height", C.c_int), ("width", C.c_int)]
+
+
+def build():
+    src = os.path.join(_HERE, "tsdf_oracle.c")
+    if not os.path.isfile(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-std=c99", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+                               src, "-o", _SO, "-lm"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        L.tsdf_create.restype = C.c_void_p
+        L.tsdf_create.argtypes = [C.POINTER(Options)]
+        L.tsdf_destroy.argtypes = [C.c_void_p]
+        L.tsdf_integrate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.tsdf_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.tsdf_num_blocks.argtypes = [C.c_void_p]
+        L.tsdf_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+        L.tsdf_export_blocks.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.tsdf_inverse4.argtypes = [C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+class TsdfOracle:
+    def __init__(self, **opts):
+        self.o = Options(**opts)
+        self._h = lib().tsdf_create(C.byref(self.o))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().tsdf_destroy(self._h)
+            self._h = None
+
+    def integrate(self, bgr, depth, pose):
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        depth = np.ascontiguousarray(depth, np.float32)
+        pose = np.ascontiguousarray(pose, np.float32).reshape(16)
+        return lib().tsdf_integrate(self._h, bgr.ctypes.data, depth.ctypes.data, pose.ctypes.data)
+
+    def render(self, pose):
+        H, W = self.o.height, self.o.width
+        pose = np.ascontiguousarray(pose, np.float32).reshape(16)
+        bgr, depth = np.empty((H, W, 3), np.uint8), np.empty((H, W), np.float32)
+        lib().tsdf_render(self._h, pose.ctypes.data, bgr.ctypes.data, depth.ctypes.data)
+        return bgr, depth
+
+    def stats(self):
+        out = (C.c_ulonglong * 4)()
+        lib().tsdf_stats(self._h, out)
+        return dict(blocks=int(out[0]), updated_last=int(out[1]), updated_total=int(out[2]), mismatches=int(out[3]))
+
+    def export_blocks(self):
+        n = lib().tsdf_num_blocks(self._h)
+        coords = np.empty((max(n, 1), 3), np.int32)
+        vox = np.empty((max(n, 1), 4096), np.uint8)
+        got = lib().tsdf_export_blocks(self._h, n, coords.ctypes.data, vox.ctypes.data)
+        return {tuple(int(v) for v in coords[i]): vox[i] for i in range(got)}

@@ -1,23 +1,646 @@
-// TEMPORARY STUB (replaced by the real TSDF engine in the next commit).
+// dr_fusion.hip -- MI355X engine behind the DrFusion operator API (C ABI: include/dr_mi355x.h).
+//
+// Replaces tandem/libdr/dr_fusion/src (CUDA, managed memory, try-lock hash inserts):
+//   HashTable / Heap        tsdfvh/hash_table.cu, heap.cu  -> lock-free open-addressing table keyed by the
+//                                                           packed block coordinate (64-bit CAS), bump pool
+//   AllocateFromDepthKernel tsdfvh/tsdf_volume.cu:317-434 -> k_allocate   (one lane per pixel, DDA)
+//   IntegrateScanKernel     tsdfvh/tsdf_volume.cu:436-513 -> k_integrate  (one 512-thread workgroup per
+//                                                           ALLOCATED block, one voxel per lane, coalesced 4 KB)
+//   GenerateRgbDepthKernel  tsdfvh/tsdf_volume.cu:600-632 -> k_raycast    (one lane per pixel, sphere tracing)
+//   TsdfVolume::{IntegrateScanAsync,RenderAsync,GetRenderResult}  tsdf_volume.cu:515-737 -> FusionEngine
+//
+// Semantics follow the canonical form fixed by the CPU oracle (oracle/tsdf_oracle.c header): the voxel
+// state keyed by block coordinate is bit-identical; hash slots and pool indices are implementation detail.
+// fp32 arithmetic is written in the reference's expression order and compiled with -ffp-contract=off;
+// divisions and square roots are IEEE-correct (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
+#include <cfloat>
+#include <memory>
+
 #include "dr_common.h"
-struct drf_s { int dummy; };
-#define UNSUP(name) return dr::guarded([&] { dr::fail(DR_ERR_UNSUPPORTED, name ": not implemented yet"); })
-extern "C" {
-int drf_create(const drf_options_t *, int, drf_t **) { UNSUP("drf_create"); }
-void drf_destroy(drf_t *) {}
-int drf_integrate_scan_async(drf_t *, const uint8_t *, const float *, const float *) { UNSUP("drf_integrate_scan_async"); }
-int drf_render_async(drf_t *, const float *const *, int) { UNSUP("drf_render_async"); }
-int drf_get_render_result(drf_t *, uint8_t **, float **, int) { UNSUP("drf_get_render_result"); }
-int drf_extract_mesh_async(drf_t *, const float *, const float *) { UNSUP("drf_extract_mesh_async"); }
-int drf_get_mesh_sync(drf_t *, size_t, size_t *, float *, float *) { UNSUP("drf_get_mesh_sync"); }
-int drf_save_mesh(drf_t *, const char *, const float *, const float *) { UNSUP("drf_save_mesh"); }
-int drf_synchronize(drf_t *) { UNSUP("drf_synchronize"); }
-int drf_stats(drf_t *, uint64_t *) { UNSUP("drf_stats"); }
-int drf_export_blocks(drf_t *, int, int32_t *, uint8_t *, int *) { UNSUP("drf_export_blocks"); }
-int drf_integrate_device(drf_t *, const void *, const void *, const float *) { UNSUP("drf_integrate_device"); }
-int dr_device_alloc(int, size_t, void **) { UNSUP("dr_device_alloc"); }
-int dr_device_free(void *) { UNSUP("dr_device_free"); }
-int dr_memcpy_h2d(void *, const void *, size_t) { UNSUP("dr_memcpy_h2d"); }
-int dr_memcpy_d2h(void *, const void *, size_t) { UNSUP("dr_memcpy_d2h"); }
-int drf_bench_integrate(drf_t *, const void *, const void *, const float *, int, float *, float *) { UNSUP("drf_bench_integrate"); }
+
+namespace dr {
+
+constexpr int kMaxDDA = 4096;  // cap on DDA steps per ray (the reference loops unboundedly)
+constexpr unsigned long long kEmptyKey = ~0ull;
+
+struct Voxel {  // tsdfvh/voxel.h:13-19 -- 8 bytes
+  float sdf;
+  unsigned char c[3];
+  unsigned char weight;
+};
+static_assert(sizeof(Voxel) == 8, "voxel layout");
+
+struct FusionDev {  // everything the kernels need, passed by value
+  drf_options_t o;
+  unsigned long long *keys;  // [cap] packed block coordinate or kEmptyKey
+  int *vals;                 // [cap] pool index
+  unsigned cmask;            // cap - 1
+  unsigned long long *blk_key;  // [num_blocks] key of pool block i
+  Voxel *vox;                // [num_blocks * 512]
+  int *n_alloc;              // allocated pool blocks
+  int *err;                  // [0] pool exhausted, [1] coordinate out of packing range
+  unsigned long long *cnt;   // [0] voxels updated by the current scan, [1] total, [2] round-trip mismatches
+};
+
+// ---- CUDA float->int conversion semantics (cvt.rzi: saturate, NaN -> 0), see oracle header (4) ----
+__device__ inline int f2i(float f) {
+  if (f != f) return 0;
+  if (f >= 2147483648.0f) return 2147483647;
+  if (f <= -2147483648.0f) return -2147483647 - 1;
+  return (int)f;
 }
+__device__ inline unsigned char f2u8(float f) {
+  if (!(f > 0.0f)) return 0;
+  if (f >= 255.0f) return 255;
+  return (unsigned char)f;
+}
+
+struct F3 { float x, y, z; };
+struct I3 { int x, y, z; };
+struct Mat { float m[16]; };
+
+__device__ inline float norm3(F3 v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }  // utils.h:44-46
+__device__ inline F3 xform(const Mat &T, F3 v) {                                          // matrix_utils.h:914-922
+  F3 r;
+  r.x = T.m[0] * v.x + T.m[1] * v.y + T.m[2] * v.z + T.m[3] * 1.0f;
+  r.y = T.m[4] * v.x + T.m[5] * v.y + T.m[6] * v.z + T.m[7] * 1.0f;
+  r.z = T.m[8] * v.x + T.m[9] * v.y + T.m[10] * v.z + T.m[11] * 1.0f;
+  return r;
+}
+__device__ inline F3 point3d(const drf_options_t &o, int i, float depth) {  // utils.h:93-101
+  const int v = i / o.width, u = i - o.width * v;
+  F3 p;
+  p.z = depth;
+  p.x = ((float)u - o.cx) * p.z / o.fx;
+  p.y = ((float)v - o.cy) * p.z / o.fy;
+  return p;
+}
+__device__ inline void project(const drf_options_t &o, F3 p, int &px, int &py) {  // utils.h:103-108
+  const float x = (o.fx * p.x) / p.z + o.cx;
+  const float y = (o.fy * p.y) / p.z + o.cy;
+  px = f2i(roundf(x));
+  py = f2i(roundf(y));
+}
+__device__ inline float signf_(float n) { return (float)((n > 0) - (n < 0)); }
+__device__ inline int signi(float n) { return (n > 0) - (n < 0); }
+
+// ---- block-coordinate hash table ----
+__device__ inline bool pack_key(I3 p, unsigned long long &k) {
+  const int B = 1 << 20;
+  if (p.x < -B || p.x >= B || p.y < -B || p.y >= B || p.z < -B || p.z >= B) return false;
+  k = ((unsigned long long)(unsigned)(p.x + B) << 42) | ((unsigned long long)(unsigned)(p.y + B) << 21) | (unsigned long long)(unsigned)(p.z + B);
+  return true;
+}
+__device__ inline I3 unpack_key(unsigned long long k) {
+  const int B = 1 << 20;
+  I3 p;
+  p.x = (int)((k >> 42) & 0x1fffff) - B;
+  p.y = (int)((k >> 21) & 0x1fffff) - B;
+  p.z = (int)(k & 0x1fffff) - B;
+  return p;
+}
+__device__ inline unsigned hash_key(unsigned long long k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+  return (unsigned)k;
+}
+__device__ inline int find_block(const FusionDev &d, I3 p) {
+  unsigned long long key;
+  if (!pack_key(p, key)) return -1;
+  unsigned s = hash_key(key) & d.cmask;
+  for (unsigned probe = 0; probe <= d.cmask; ++probe) {
+    const unsigned long long cur = d.keys[s];
+    if (cur == key) return d.vals[s];
+    if (cur == kEmptyKey) return -1;
+    s = (s + 1) & d.cmask;
+  }
+  return -1;
+}
+// Insert-if-absent (HashTable::AllocateBlock, hash_table.cu:80-115, without the try-lock drop).
+__device__ inline void allocate_block(const FusionDev &d, I3 p) {
+  unsigned long long key;
+  if (!pack_key(p, key)) { d.err[1] = 1; return; }
+  unsigned s = hash_key(key) & d.cmask;
+  for (unsigned probe = 0; probe <= d.cmask; ++probe) {
+    unsigned long long cur = __hip_atomic_load(&d.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == key) return;
+    if (cur == kEmptyKey) {
+      cur = atomicCAS(&d.keys[s], kEmptyKey, key);
+      if (cur == kEmptyKey) {  // we own the slot: take a pool block
+        const int idx = atomicAdd(d.n_alloc, 1);
+        if (idx >= d.o.num_blocks) { d.err[0] = 1; d.vals[s] = -1; return; }
+        d.vals[s] = idx;
+        d.blk_key[idx] = key;
+        return;
+      }
+      if (cur == key) return;
+    }
+    s = (s + 1) & d.cmask;
+  }
+  d.err[0] = 1;
+}
+
+// ---- coordinate maps, tsdf_volume.cu:109-145 ----
+__device__ inline I3 world_to_global_voxel(const drf_options_t &o, F3 p) {
+  const float vs = o.voxel_size;
+  I3 r;
+  r.x = f2i(p.x / vs + signf_(p.x) * 0.5f);
+  r.y = f2i(p.y / vs + signf_(p.y) * 0.5f);
+  r.z = f2i(p.z / vs + signf_(p.z) * 0.5f);
+  return r;
+}
+__device__ inline int floor_div(int v, int bs) { return v < 0 ? (v - bs + 1) / bs : v / bs; }
+__device__ inline int pos_mod(int v, int bs) { const int r = v % bs; return r < 0 ? r + bs : r; }
+__device__ inline void world_to_block_local(const drf_options_t &o, F3 p, I3 &blk, int &local) {
+  const I3 v = world_to_global_voxel(o, p);
+  const int bs = o.block_size;
+  blk.x = floor_div(v.x, bs); blk.y = floor_div(v.y, bs); blk.z = floor_div(v.z, bs);
+  local = pos_mod(v.x, bs) * bs * bs + pos_mod(v.y, bs) * bs + pos_mod(v.z, bs);  // voxel_block.h:37-41
+}
+
+// ------------------------------------------------------------------ allocation
+__global__ __launch_bounds__(256) void k_allocate(const FusionDev d, const float *__restrict__ depth, const Mat T) {
+  const drf_options_t &o = d.o;
+  const int size = o.height * o.width;
+  const float trunc = o.truncation_distance;
+  const float bsz = o.block_size * o.voxel_size;
+  F3 start; start.x = T.m[3]; start.y = T.m[7]; start.z = T.m[11];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < size; i += gridDim.x * blockDim.x) {
+    const float dep = depth[i];
+    if (dep < o.min_sensor_depth || dep > o.max_sensor_depth) continue;
+    const F3 point = xform(T, point3d(o, i, dep));
+    if (point.x == 0 && point.y == 0 && point.z == 0) continue;
+    F3 dv; dv.x = point.x - start.x; dv.y = point.y - start.y; dv.z = point.z - start.z;
+    const float dn = norm3(dv);
+    F3 dir; dir.x = dv.x / dn; dir.y = dv.y / dn; dir.z = dv.z / dn;
+    const float surf = norm3(dv);
+    const float reach = surf + trunc;
+    F3 re; re.x = start.x + dir.x * reach; re.y = start.y + dir.y * reach; re.z = start.z + dir.z * reach;
+    I3 bp, be, st;
+    bp.x = f2i(floorf(start.x / bsz)); bp.y = f2i(floorf(start.y / bsz)); bp.z = f2i(floorf(start.z / bsz));
+    be.x = f2i(floorf(re.x / bsz)); be.y = f2i(floorf(re.y / bsz)); be.z = f2i(floorf(re.z / bsz));
+    st.x = signi(dir.x); st.y = signi(dir.y); st.z = signi(dir.z);
+    F3 dt, mt;
+    dt.x = (dir.x != 0) ? fabsf(bsz / dir.x) : FLT_MAX;
+    dt.y = (dir.y != 0) ? fabsf(bsz / dir.y) : FLT_MAX;
+    dt.z = (dir.z != 0) ? fabsf(bsz / dir.z) : FLT_MAX;
+    const float bdx = (bp.x + (float)st.x) * bsz, bdy = (bp.y + (float)st.y) * bsz, bdz = (bp.z + (float)st.z) * bsz;
+    mt.x = (dir.x != 0) ? (bdx - start.x) / dir.x : FLT_MAX;
+    mt.y = (dir.y != 0) ? (bdy - start.y) / dir.y : FLT_MAX;
+    mt.z = (dir.z != 0) ? (bdz - start.z) / dir.z : FLT_MAX;
+    I3 diff; diff.x = diff.y = diff.z = 0;
+    bool neg = false;
+    if (bp.x != be.x && dir.x < 0) { diff.x--; neg = true; }
+    if (bp.y != be.y && dir.y < 0) { diff.y--; neg = true; }
+    if (bp.z != be.z && dir.z < 0) { diff.z--; neg = true; }
+    allocate_block(d, bp);
+    if (neg) { bp.x += diff.x; bp.y += diff.y; bp.z += diff.z; allocate_block(d, bp); }
+    int steps = 0;
+    while ((bp.x != be.x || bp.y != be.y || bp.z != be.z) && steps++ < kMaxDDA) {
+      if (mt.x < mt.y) {
+        if (mt.x < mt.z) { bp.x += st.x; mt.x += dt.x; } else { bp.z += st.z; mt.z += dt.z; }
+      } else {
+        if (mt.y < mt.z) { bp.y += st.y; mt.y += dt.y; } else { bp.z += st.z; mt.z += dt.z; }
+      }
+      allocate_block(d, bp);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ integration
+__device__ inline void combine(Voxel &a, const Voxel &b, unsigned char max_weight) {  // voxel.h:21-50
+  const float w = (float)a.weight, vw = (float)b.weight;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) a.c[k] = f2u8(((float)a.c[k] * w + (float)b.c[k] * vw) / (w + vw));
+  a.sdf = (a.sdf * w + b.sdf * vw) / (w + vw);
+  unsigned char nw = (unsigned char)(a.weight + b.weight);
+  if (nw > max_weight) nw = max_weight;
+  a.weight = nw;
+}
+
+// One workgroup (bs^3 = 512 lanes) walks allocated pool blocks [0, n_blocks); lane = voxel index x*64+y*8+z.
+__global__ __launch_bounds__(512) void k_integrate(const FusionDev d, const unsigned char *__restrict__ bgr,
+                                                   const float *__restrict__ depth, const Mat T, const Mat Ti) {
+  const drf_options_t &o = d.o;
+  const int bs = o.block_size;
+  const float vs = o.voxel_size, trunc = o.truncation_distance;
+  const int li = threadIdx.x;
+  const int bx = li / (bs * bs), by = (li / bs) % bs, bz = li % bs;
+  unsigned upd = 0;
+  const int n_blocks = min(*d.n_alloc, o.num_blocks);  // written by k_allocate earlier on this stream
+  for (int e = blockIdx.x; e < n_blocks; e += gridDim.x) {
+    const I3 P = unpack_key(d.blk_key[e]);
+    F3 position; position.x = P.x * vs * bs; position.y = P.y * vs * bs; position.z = P.z * vs * bs;
+    const F3 pc = xform(Ti, position);
+    if (pc.z < 0) continue;  // uniform per block
+    F3 center;  // tsdf_volume.cu:461-465 -- the half-block offset is added in double
+    center.x = (float)((double)pc.x + 0.5 * (double)vs * (double)bs);
+    center.y = (float)((double)pc.y + 0.5 * (double)vs * (double)bs);
+    center.z = (float)((double)pc.z + 0.5 * (double)vs * (double)bs);
+    int ix, iy;
+    project(o, center, ix, iy);
+    if (!(ix >= 0 && iy >= 0 && ix < o.width && iy < o.height)) continue;
+    F3 vp; vp.x = position.x + bx * vs; vp.y = position.y + by * vs; vp.z = position.z + bz * vs;
+    vp = xform(Ti, vp);
+    project(o, vp, ix, iy);
+    if (!(ix >= 0 && iy >= 0 && ix < o.width && iy < o.height)) continue;
+    const int idx = iy * o.width + ix;
+    const float dep = depth[idx];
+    if (dep <= 0) continue;
+    if (dep < o.min_sensor_depth) continue;
+    if (dep > o.max_sensor_depth) continue;
+    const float sd = norm3(point3d(o, idx, dep));
+    const float vd = norm3(vp);
+    Voxel v;
+    bool hit = false;
+    if (vd > sd - trunc && vd < sd + trunc && dep < o.max_sensor_depth) { v.sdf = sd - vd; hit = true; }
+    else if (vd < sd - trunc) { v.sdf = trunc; hit = true; }
+    if (!hit) continue;
+    v.c[0] = bgr[3 * idx]; v.c[1] = bgr[3 * idx + 1]; v.c[2] = bgr[3 * idx + 2];
+    v.weight = 1;
+    // UpdateVoxel re-derives block and voxel from the world position (tsdf_volume.cu:303-315); the
+    // round trip normally lands on this very lane's voxel -- verified, with the slow path kept literal.
+    I3 blk; int local;
+    world_to_block_local(o, xform(T, vp), blk, local);
+    int target = e;
+    if (blk.x != P.x || blk.y != P.y || blk.z != P.z || local != li) {
+      atomicAdd(&d.cnt[2], 1ull);
+      target = find_block(d, blk);
+      if (target < 0) continue;
+    }
+    Voxel *dst = d.vox + (size_t)target * (bs * bs * bs) + local;
+    Voxel cur = *dst;
+    combine(cur, v, (unsigned char)o.max_sdf_weight);
+    *dst = cur;
+    ++upd;
+  }
+  // workgroup reduction of the update count -> one atomic per workgroup
+  __shared__ unsigned red[8];
+  for (int off = 32; off > 0; off >>= 1) upd += __shfl_down(upd, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = upd;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned s = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+    if (s) atomicAdd(&d.cnt[0], (unsigned long long)s);
+  }
+}
+
+// ------------------------------------------------------------------ raycast
+__device__ inline Voxel get_voxel(const FusionDev &d, F3 p) {  // tsdf_volume.cu:147-160
+  Voxel z; z.sdf = 0.f; z.c[0] = z.c[1] = z.c[2] = 0; z.weight = 0;
+  I3 blk; int local;
+  world_to_block_local(d.o, p, blk, local);
+  const int b = find_block(d, blk);
+  if (b < 0) return z;
+  const int bs = d.o.block_size;
+  return d.vox[(size_t)b * (bs * bs * bs) + local];
+}
+
+__device__ inline Voxel get_interpolated_voxel(const FusionDev &d, F3 pos) {  // tsdf_volume.cu:161-289
+  const Voxel v0 = get_voxel(d, pos);
+  if (v0.weight == 0) return v0;
+  const float vs = d.o.voxel_size, hv = vs / 2.0f;
+  F3 pd; pd.x = pos.x - hv; pd.y = pos.y - hv; pd.z = pos.z - hv;
+  F3 vp; vp.x = pos.x / vs; vp.y = pos.y / vs; vp.z = pos.z / vs;
+  F3 w; w.x = vp.x - floorf(vp.x); w.y = vp.y - floorf(vp.y); w.z = vp.z - floorf(vp.z);
+  float dist = 0.0f, cx = 0.0f, cy = 0.0f, cz = 0.0f;
+  Voxel v = v0;
+  // corner order of the reference: 000 100 010 001 110 011 101 111
+  const int order[8] = {0, 1, 2, 4, 3, 6, 5, 7};  // bit0 = x, bit1 = y, bit2 = z
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = order[k];
+    F3 q; q.x = pd.x + ((c & 1) ? vs : 0.0f); q.y = pd.y + ((c & 2) ? vs : 0.0f); q.z = pd.z + ((c & 4) ? vs : 0.0f);
+    v = get_voxel(d, q);
+    const float a = (c & 1) ? w.x : (1.0f - w.x), b = (c & 2) ? w.y : (1.0f - w.y), cc = (c & 4) ? w.z : (1.0f - w.z);
+    const float wt = a * b * cc;
+    const Voxel &src = v.weight == 0 ? v0 : v;
+    dist += wt * src.sdf;
+    cx = cx + (float)src.c[0] * wt;
+    cy = cy + (float)src.c[1] * wt;
+    cz = cz + (float)src.c[2] * wt;
+  }
+  v.c[0] = f2u8(cx); v.c[1] = f2u8(cy); v.c[2] = f2u8(cz);
+  v.weight = v0.weight;
+  v.sdf = dist;
+  return v;
+}
+
+__global__ __launch_bounds__(64) void k_raycast(const FusionDev d, const Mat pose, unsigned char *__restrict__ bgr,
+                                                float *__restrict__ depth_out) {
+  const drf_options_t &o = d.o;
+  const int size = o.height * o.width;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < size; i += gridDim.x * blockDim.x) {
+    float cur = 0.f;
+    while (cur < o.max_sensor_depth) {
+      const Voxel v = get_interpolated_voxel(d, xform(pose, point3d(o, i, cur)));
+      if (v.weight == 0) cur += o.truncation_distance; else cur += v.sdf;
+      if (v.weight != 0 && v.sdf < o.voxel_size) break;
+    }
+    if (cur < o.max_sensor_depth) {
+      const Voxel v = get_interpolated_voxel(d, xform(pose, point3d(o, i, cur)));
+      bgr[3 * i] = v.c[0]; bgr[3 * i + 1] = v.c[1]; bgr[3 * i + 2] = v.c[2];
+      depth_out[i] = cur;
+    } else {
+      bgr[3 * i] = bgr[3 * i + 1] = bgr[3 * i + 2] = 0;
+      depth_out[i] = 0.0f;
+    }
+  }
+}
+
+__global__ void k_fold_counter(unsigned long long *cnt) {  // end of scan: last -> total
+  if (threadIdx.x == 0 && blockIdx.x == 0) { cnt[1] += cnt[0]; cnt[3] = cnt[0]; cnt[0] = 0; }
+}
+__global__ void k_fill_keys(unsigned long long *keys, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) keys[i] = kEmptyKey;
+}
+
+// cofactor inverse on the host in the reference's term order (matrix_utils.h:958-1083), fp32, no contraction
+static void inverse4_host(const float *e, float *out) {
+  float inv[16];
+  auto t3 = [&](int a, int b, int c) { return e[a] * e[b] * e[c]; };
+  inv[0] = t3(5, 10, 15) - t3(5, 11, 14) - t3(9, 6, 15) + t3(9, 7, 14) + t3(13, 6, 11) - t3(13, 7, 10);
+  inv[4] = -t3(4, 10, 15) + t3(4, 11, 14) + t3(8, 6, 15) - t3(8, 7, 14) - t3(12, 6, 11) + t3(12, 7, 10);
+  inv[8] = t3(4, 9, 15) - t3(4, 11, 13) - t3(8, 5, 15) + t3(8, 7, 13) + t3(12, 5, 11) - t3(12, 7, 9);
+  inv[12] = -t3(4, 9, 14) + t3(4, 10, 13) + t3(8, 5, 14) - t3(8, 6, 13) - t3(12, 5, 10) + t3(12, 6, 9);
+  inv[1] = -t3(1, 10, 15) + t3(1, 11, 14) + t3(9, 2, 15) - t3(9, 3, 14) - t3(13, 2, 11) + t3(13, 3, 10);
+  inv[5] = t3(0, 10, 15) - t3(0, 11, 14) - t3(8, 2, 15) + t3(8, 3, 14) + t3(12, 2, 11) - t3(12, 3, 10);
+  inv[9] = -t3(0, 9, 15) + t3(0, 11, 13) + t3(8, 1, 15) - t3(8, 3, 13) - t3(12, 1, 11) + t3(12, 3, 9);
+  inv[13] = t3(0, 9, 14) - t3(0, 10, 13) - t3(8, 1, 14) + t3(8, 2, 13) + t3(12, 1, 10) - t3(12, 2, 9);
+  inv[2] = t3(1, 6, 15) - t3(1, 7, 14) - t3(5, 2, 15) + t3(5, 3, 14) + t3(13, 2, 7) - t3(13, 3, 6);
+  inv[6] = -t3(0, 6, 15) + t3(0, 7, 14) + t3(4, 2, 15) - t3(4, 3, 14) - t3(12, 2, 7) + t3(12, 3, 6);
+  inv[10] = t3(0, 5, 15) - t3(0, 7, 13) - t3(4, 1, 15) + t3(4, 3, 13) + t3(12, 1, 7) - t3(12, 3, 5);
+  inv[14] = -t3(0, 5, 14) + t3(0, 6, 13) + t3(4, 1, 14) - t3(4, 2, 13) - t3(12, 1, 6) + t3(12, 2, 5);
+  inv[3] = -t3(1, 6, 11) + t3(1, 7, 10) + t3(5, 2, 11) - t3(5, 3, 10) - t3(9, 2, 7) + t3(9, 3, 6);
+  inv[7] = t3(0, 6, 11) - t3(0, 7, 10) - t3(4, 2, 11) + t3(4, 3, 10) + t3(8, 2, 7) - t3(8, 3, 6);
+  inv[11] = -t3(0, 5, 11) + t3(0, 7, 9) + t3(4, 1, 11) - t3(4, 3, 9) - t3(8, 1, 7) + t3(8, 3, 5);
+  inv[15] = t3(0, 5, 10) - t3(0, 6, 9) - t3(4, 1, 10) + t3(4, 2, 9) + t3(8, 1, 6) - t3(8, 2, 5);
+  const float det = e[0] * inv[0] + e[1] * inv[4] + e[2] * inv[8] + e[3] * inv[12];
+  const float detr = 1.0f / det;
+  for (int i = 0; i < 16; ++i) out[i] = inv[i] * detr;
+}
+
+// ------------------------------------------------------------------ engine
+class FusionEngine {
+ public:
+  FusionEngine(const drf_options_t &o, int device) : device_(device), o_(o) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= device) fail(DR_ERR_DEVICE, "DrFusion: no HIP device %d (found %d) -- the MI355X path has no CPU fallback", device, n);
+    if (o.block_size != 8) fail(DR_ERR_UNSUPPORTED, "DrFusion: block_size must be 8 (got %d)", o.block_size);
+    if (o.height <= 0 || o.width <= 0 || o.num_blocks <= 0 || o.num_buckets <= 0 || o.bucket_size <= 0 || o.num_render_streams < 0)
+      fail(DR_ERR_ARG, "DrFusion: invalid options");
+    DR_HIP(hipSetDevice(device_));
+    int lo, hi;
+    DR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    DR_HIP(hipStreamCreateWithPriority(&int_stream_, hipStreamNonBlocking, lo));  // tsdf_volume.cu:64-70
+    npix_ = (size_t)o.height * o.width;
+    size_t cap = 1024;
+    const size_t want = std::max((size_t)o.num_buckets * (size_t)o.bucket_size, (size_t)2 * o.num_blocks);
+    while (cap < want) cap <<= 1;
+    d_.o = o;
+    d_.keys = dalloc<unsigned long long>(cap);
+    d_.vals = dalloc<int>(cap);
+    d_.cmask = (unsigned)(cap - 1);
+    d_.blk_key = dalloc<unsigned long long>(o.num_blocks);
+    d_.vox = dalloc<Voxel>((size_t)o.num_blocks * 512);
+    d_.n_alloc = dalloc<int>(4);
+    d_.err = d_.n_alloc + 1;
+    d_.cnt = dalloc<unsigned long long>(4);
+    hipLaunchKernelGGL(k_fill_keys, dim3(1024), dim3(256), 0, int_stream_, d_.keys, cap);
+    DR_HIP(hipMemsetAsync(d_.vox, 0, (size_t)o.num_blocks * 512 * sizeof(Voxel), int_stream_));  // hash_table.cu:28-32
+    DR_HIP(hipMemsetAsync(d_.n_alloc, 0, 16, int_stream_));
+    DR_HIP(hipMemsetAsync(d_.cnt, 0, 32, int_stream_));
+    d_bgr_in_ = dalloc<unsigned char>(npix_ * 3);
+    d_depth_in_ = dalloc<float>(npix_);
+    DR_HIP(hipHostMalloc((void **)&h_bgr_in_, npix_ * 3, hipHostMallocDefault));
+    DR_HIP(hipHostMalloc((void **)&h_depth_in_, npix_ * 4, hipHostMallocDefault));
+    integrate_grid_ = std::min(o.num_blocks, 8192);
+    DR_HIP(hipEventCreateWithFlags(&int_done_, hipEventDisableTiming));
+    for (int i = 0; i < o.num_render_streams; ++i) {
+      Render r;
+      DR_HIP(hipStreamCreateWithPriority(&r.stream, hipStreamNonBlocking, lo));
+      r.d_bgr = dalloc<unsigned char>(npix_ * 3);
+      r.d_depth = dalloc<float>(npix_);
+      for (int k = 0; k < 2; ++k) {  // double-buffered host results ("blocked"/"free", tsdf_volume.cu:846-872)
+        DR_HIP(hipHostMalloc((void **)&r.h_bgr[k], npix_ * 3, hipHostMallocDefault));
+        DR_HIP(hipHostMalloc((void **)&r.h_depth[k], npix_ * 4, hipHostMallocDefault));
+      }
+      DR_HIP(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
+      renders_.push_back(r);
+    }
+    DR_HIP(hipStreamSynchronize(int_stream_));
+  }
+  ~FusionEngine() {
+    (void)hipSetDevice(device_);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(d_.keys); (void)hipFree(d_.vals); (void)hipFree(d_.blk_key); (void)hipFree(d_.vox);
+    (void)hipFree(d_.n_alloc); (void)hipFree(d_.cnt); (void)hipFree(d_bgr_in_); (void)hipFree(d_depth_in_);
+    (void)hipHostFree(h_bgr_in_); (void)hipHostFree(h_depth_in_);
+    for (auto &r : renders_) {
+      (void)hipFree(r.d_bgr); (void)hipFree(r.d_depth);
+      for (int k = 0; k < 2; ++k) { (void)hipHostFree(r.h_bgr[k]); (void)hipHostFree(r.h_depth[k]); }
+      (void)hipEventDestroy(r.done); (void)hipStreamDestroy(r.stream);
+    }
+    (void)hipEventDestroy(int_done_);
+    (void)hipStreamDestroy(int_stream_);
+  }
+
+  // tsdf_volume.cu:515-598
+  void integrate_scan_async(const uint8_t *bgr, const float *depth, const float *pose16) {
+    if (!bgr || !depth || !pose16) fail(DR_ERR_ARG, "IntegrateScanAsync: null argument");
+    expect(kIntegrate, "Please call the functions like Integration -> RenderAsync -> GetRenderResults.");
+    next_ = kRender;
+    DR_HIP(hipSetDevice(device_));
+    DR_HIP(hipEventSynchronize(int_done_));  // previous scan's use of the pinned staging buffers
+    memcpy(h_bgr_in_, bgr, npix_ * 3);
+    memcpy(h_depth_in_, depth, npix_ * 4);
+    DR_HIP(hipMemcpyAsync(d_bgr_in_, h_bgr_in_, npix_ * 3, hipMemcpyHostToDevice, int_stream_));
+    DR_HIP(hipMemcpyAsync(d_depth_in_, h_depth_in_, npix_ * 4, hipMemcpyHostToDevice, int_stream_));
+    for (auto &r : renders_) DR_HIP(hipStreamWaitEvent(int_stream_, r.done, 0));  // renders read the volume
+    enqueue_scan(d_bgr_in_, d_depth_in_, pose16);
+    DR_HIP(hipEventRecord(int_done_, int_stream_));
+  }
+  // tsdf_volume.cu:634-700
+  void render_async(const float *const *poses, int n) {
+    expect(kRender, "Please call the functions like IntegrateScanAsync -> RenderAsync -> GetRenderResult.");
+    if (n != (int)renders_.size()) fail(DR_ERR_PROTOCOL, "Can only render exactly as many poses as streams. Streams: %zu, Poses: %d.", renders_.size(), n);
+    next_ = kGetRender;
+    DR_HIP(hipSetDevice(device_));
+    free_slot_ ^= 1;  // write into the buffers NOT handed out by the last GetRenderResult
+    for (int i = 0; i < n; ++i) {
+      Render &r = renders_[i];
+      Mat P; memcpy(P.m, poses[i], 64);
+      DR_HIP(hipStreamWaitEvent(r.stream, int_done_, 0));
+      hipLaunchKernelGGL(k_raycast, dim3(cdiv((int)npix_, 64)), dim3(64), 0, r.stream, d_, P, r.d_bgr, r.d_depth);
+      DR_HIP(hipMemcpyAsync(r.h_bgr[free_slot_], r.d_bgr, npix_ * 3, hipMemcpyDeviceToHost, r.stream));
+      DR_HIP(hipMemcpyAsync(r.h_depth[free_slot_], r.d_depth, npix_ * 4, hipMemcpyDeviceToHost, r.stream));
+      DR_HIP(hipEventRecord(r.done, r.stream));
+    }
+  }
+  // tsdf_volume.cu:702-737
+  void get_render_result(uint8_t **bgr, float **depth, int n) {
+    expect(kGetRender, "Please call the functions in a loop: IntegrateScanAsync -> RenderAsync -> GetRenderResult.");
+    if (n != (int)renders_.size()) fail(DR_ERR_ARG, "GetRenderResult: expected %zu outputs", renders_.size());
+    next_ = kIntegrate;
+    DR_HIP(hipSetDevice(device_));
+    for (int i = 0; i < n; ++i) {
+      DR_HIP(hipEventSynchronize(renders_[i].done));
+      bgr[i] = renders_[i].h_bgr[free_slot_];
+      depth[i] = renders_[i].h_depth[free_slot_];
+    }
+    check_device_flags();
+  }
+  void synchronize() {
+    DR_HIP(hipSetDevice(device_));
+    DR_HIP(hipDeviceSynchronize());
+    check_device_flags();
+  }
+  void stats(uint64_t out[4]) {
+    DR_HIP(hipSetDevice(device_));
+    DR_HIP(hipDeviceSynchronize());
+    unsigned long long c[4]; int na[2];
+    DR_HIP(hipMemcpy(c, d_.cnt, 32, hipMemcpyDeviceToHost));
+    DR_HIP(hipMemcpy(na, d_.n_alloc, 8, hipMemcpyDeviceToHost));
+    out[0] = (uint64_t)std::min(na[0], o_.num_blocks); out[1] = c[3]; out[2] = c[1]; out[3] = c[2];
+  }
+  void export_blocks(int max_blocks, int32_t *coords, uint8_t *voxels, int *n) {
+    DR_HIP(hipSetDevice(device_));
+    DR_HIP(hipDeviceSynchronize());
+    int na = 0;
+    DR_HIP(hipMemcpy(&na, d_.n_alloc, 4, hipMemcpyDeviceToHost));
+    na = std::min(std::min(na, o_.num_blocks), max_blocks);
+    std::vector<unsigned long long> keys(na);
+    DR_HIP(hipMemcpy(keys.data(), d_.blk_key, (size_t)na * 8, hipMemcpyDeviceToHost));
+    const int B = 1 << 20;
+    for (int i = 0; i < na; ++i) {
+      coords[3 * i] = (int)((keys[i] >> 42) & 0x1fffff) - B;
+      coords[3 * i + 1] = (int)((keys[i] >> 21) & 0x1fffff) - B;
+      coords[3 * i + 2] = (int)(keys[i] & 0x1fffff) - B;
+    }
+    DR_HIP(hipMemcpy(voxels, d_.vox, (size_t)na * 4096, hipMemcpyDeviceToHost));
+    if (n) *n = na;
+  }
+  // bench path: inputs already resident in HBM
+  void integrate_device(const void *d_bgr, const void *d_depth, const float *pose16) {
+    DR_HIP(hipSetDevice(device_));
+    enqueue_scan((const unsigned char *)d_bgr, (const float *)d_depth, pose16);
+  }
+  void bench_integrate(const void *d_bgr, const void *d_depth, const float *poses, int nscans, float *ms, float *kernel_ms) {
+    DR_HIP(hipSetDevice(device_));
+    std::vector<hipEvent_t> ev(2 * (size_t)nscans + 2);
+    for (auto &e : ev) DR_HIP(hipEventCreate(&e));
+    DR_HIP(hipEventRecord(ev[0], int_stream_));
+    for (int s = 0; s < nscans; ++s) {
+      kernel_events_[0] = ev[2 + 2 * s]; kernel_events_[1] = ev[3 + 2 * s];
+      enqueue_scan((const unsigned char *)d_bgr + (size_t)s * npix_ * 3, (const float *)d_depth + (size_t)s * npix_, poses + 16 * s);
+    }
+    kernel_events_[0] = kernel_events_[1] = nullptr;
+    DR_HIP(hipEventRecord(ev[1], int_stream_));
+    DR_HIP(hipStreamSynchronize(int_stream_));
+    float t = 0, k = 0;
+    DR_HIP(hipEventElapsedTime(&t, ev[0], ev[1]));
+    for (int s = 0; s < nscans; ++s) { float q = 0; DR_HIP(hipEventElapsedTime(&q, ev[2 + 2 * s], ev[3 + 2 * s])); k += q; }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    if (ms) *ms = t;
+    if (kernel_ms) *kernel_ms = k;
+    check_device_flags();
+  }
+
+ private:
+  enum Next { kIntegrate, kRender, kGetRender };
+  void expect(Next want, const char *msg) {
+    static const char *names[] = {"IntegrateScanAsync", "RenderAsync", "GetRenderResult"};
+    if (next_ != want) fail(DR_ERR_PROTOCOL, "%s You should have called %s", msg, names[next_]);
+  }
+  // allocate -> integrate on int_stream_, no host round trip: the number of allocated blocks lives on the
+  // device, so the integrate grid is fixed (a few workgroups per CU) and strides over [0, *n_alloc).
+  void enqueue_scan(const unsigned char *d_bgr, const float *d_depth, const float *pose16) {
+    Mat T, Ti;
+    memcpy(T.m, pose16, 64);
+    inverse4_host(T.m, Ti.m);
+    hipLaunchKernelGGL(k_allocate, dim3(cdiv((int)npix_, 256)), dim3(256), 0, int_stream_, d_, d_depth, T);
+    if (kernel_events_[0]) DR_HIP(hipEventRecord(kernel_events_[0], int_stream_));
+    hipLaunchKernelGGL(k_integrate, dim3(integrate_grid_), dim3(512), 0, int_stream_, d_, d_bgr, d_depth, T, Ti);
+    if (kernel_events_[1]) DR_HIP(hipEventRecord(kernel_events_[1], int_stream_));
+    hipLaunchKernelGGL(k_fold_counter, dim3(1), dim3(1), 0, int_stream_, d_.cnt);
+    DR_HIP(hipGetLastError());
+  }
+  void check_device_flags() {
+    int f[4];
+    DR_HIP(hipMemcpy(f, d_.n_alloc, 16, hipMemcpyDeviceToHost));
+    if (f[1] || f[2]) fail(DR_ERR_CAPACITY, "DrFusion: block pool exhausted (num_blocks=%d) or block coordinate out of range", o_.num_blocks);
+  }
+
+  struct Render {
+    hipStream_t stream;
+    unsigned char *d_bgr, *h_bgr[2];
+    float *d_depth, *h_depth[2];
+    hipEvent_t done;
+  };
+  int device_;
+  drf_options_t o_;
+  FusionDev d_{};
+  size_t npix_ = 0;
+  hipStream_t int_stream_ = nullptr;
+  hipEvent_t int_done_ = nullptr;
+  hipEvent_t kernel_events_[2] = {nullptr, nullptr};
+  unsigned char *d_bgr_in_ = nullptr, *h_bgr_in_ = nullptr;
+  float *d_depth_in_ = nullptr, *h_depth_in_ = nullptr;
+  int integrate_grid_ = 4096;
+  std::vector<Render> renders_;
+  int free_slot_ = 0;
+  Next next_ = kIntegrate;
+};
+
+}  // namespace dr
+
+// ==================================================================== C ABI
+using dr::guarded;
+struct drf_s {
+  std::unique_ptr<dr::FusionEngine> e;
+};
+
+extern "C" {
+
+int drf_create(const drf_options_t *opt, int device, drf_t **out) {
+  return guarded([&] {
+    if (!opt || !out) dr::fail(DR_ERR_ARG, "drf_create: null argument");
+    auto *h = new drf_s();
+    try { h->e.reset(new dr::FusionEngine(*opt, device)); } catch (...) { delete h; throw; }
+    *out = h;
+  });
+}
+void drf_destroy(drf_t *h) { delete h; }
+int drf_integrate_scan_async(drf_t *h, const uint8_t *bgr, const float *depth, const float *pose16) {
+  return guarded([&] { h->e->integrate_scan_async(bgr, depth, pose16); });
+}
+int drf_render_async(drf_t *h, const float *const *poses16, int n) { return guarded([&] { h->e->render_async(poses16, n); }); }
+int drf_get_render_result(drf_t *h, uint8_t **bgr, float **depth, int n) { return guarded([&] { h->e->get_render_result(bgr, depth, n); }); }
+int drf_extract_mesh_async(drf_t *, const float *, const float *) {
+  return guarded([&] { dr::fail(DR_ERR_UNSUPPORTED, "ExtractMeshAsync: marching cubes is a SURVEY 8(f) 'next' row, not built in round 1"); });
+}
+int drf_get_mesh_sync(drf_t *, size_t, size_t *, float *, float *) {
+  return guarded([&] { dr::fail(DR_ERR_UNSUPPORTED, "GetMeshSync: marching cubes is a SURVEY 8(f) 'next' row, not built in round 1"); });
+}
+int drf_save_mesh(drf_t *, const char *, const float *, const float *) {
+  return guarded([&] { dr::fail(DR_ERR_UNSUPPORTED, "SaveMeshToFile: marching cubes is a SURVEY 8(f) 'next' row, not built in round 1"); });
+}
+int drf_synchronize(drf_t *h) { return guarded([&] { h->e->synchronize(); }); }
+int drf_stats(drf_t *h, uint64_t out[4]) { return guarded([&] { h->e->stats(out); }); }
+int drf_export_blocks(drf_t *h, int max_blocks, int32_t *coords, uint8_t *voxels, int *n) {
+  return guarded([&] { h->e->export_blocks(max_blocks, coords, voxels, n); });
+}
+int drf_integrate_device(drf_t *h, const void *d_bgr, const void *d_depth, const float *pose16) {
+  return guarded([&] { h->e->integrate_device(d_bgr, d_depth, pose16); });
+}
+int dr_device_alloc(int device, size_t bytes, void **dptr) {
+  return guarded([&] { DR_HIP(hipSetDevice(device)); DR_HIP(hipMalloc(dptr, bytes)); });
+}
+int dr_device_free(void *dptr) { return guarded([&] { DR_HIP(hipFree(dptr)); }); }
+int dr_memcpy_h2d(void *dptr, const void *src, size_t bytes) { return guarded([&] { DR_HIP(hipMemcpy(dptr, src, bytes, hipMemcpyHostToDevice)); }); }
+int dr_memcpy_d2h(void *dst, const void *dptr, size_t bytes) { return guarded([&] { DR_HIP(hipMemcpy(dst, dptr, bytes, hipMemcpyDeviceToHost)); }); }
+int drf_bench_integrate(drf_t *h, const void *d_bgr, const void *d_depth, const float *poses16, int nscans, float *ms, float *kernel_ms) {
+  return guarded([&] { h->e->bench_integrate(d_bgr, d_depth, poses16, nscans, ms, kernel_ms); });
+}
+
+}  // extern "C"

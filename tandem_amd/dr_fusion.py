@@ -1,0 +1,108 @@
+"""Python mirror of TANDEM's `DrFusion` operator (tandem/libdr/dr_fusion/src/dr_fusion/dr_fusion.h:18-73)
+on top of the C ABI of libdr_mi355x.so: same method names, call order contract and argument meaning.
+Protocol violations raise DrError (the reference prints and exit()s)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FusionOptions, check, fptr, u8p, f32p
+
+
+def DrFusionOptions(**kw):
+    """struct DrFusionOptions (dr_fusion.h:18-36).  Defaults = what TANDEM runs (FullSystem.cpp:259-276)."""
+    d = dict(voxel_size=0.01, num_buckets=1000000, bucket_size=10, num_blocks=1000000, block_size=8,
+             max_sdf_weight=64, truncation_distance=0.04, max_sensor_depth=10.0, min_sensor_depth=0.1,
+             num_render_streams=1, fx=500.0, fy=500.0, cx=319.5, cy=239.5, height=480, width=640)
+    d.update(kw)
+    return FusionOptions(**d)
+
+
+class DrFusion:
+    def __init__(self, options, device=0):
+        self.options = options
+        self._h = C.c_void_p()
+        check(_lib.lib().drf_create(C.byref(options), int(device), C.byref(self._h)))
+        self._hw = (options.height, options.width)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            _lib.lib().drf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def IntegrateScanAsync(self, bgr, depth, pose):
+        """dr_fusion.h:50: bgr H*W*3 u8, depth H*W f32 metres (0 invalid), pose 16 f32 row-major cam-to-world."""
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        depth = np.ascontiguousarray(depth, np.float32)
+        pose = np.ascontiguousarray(pose, np.float32).reshape(16)
+        assert bgr.size == self._hw[0] * self._hw[1] * 3 and depth.size == self._hw[0] * self._hw[1]
+        check(_lib.lib().drf_integrate_scan_async(self._h, bgr.ctypes.data_as(u8p), fptr(depth), fptr(pose)))
+
+    def RenderAsync(self, camera_poses):
+        """dr_fusion.h:52: exactly num_render_streams poses."""
+        poses = [np.ascontiguousarray(p, np.float32).reshape(16) for p in camera_poses]
+        arr = (f32p * max(len(poses), 1))(*[fptr(p) for p in poses])
+        check(_lib.lib().drf_render_async(self._h, arr, len(poses)))
+
+    def GetRenderResult(self):
+        """dr_fusion.h:54: returns (bgr list, depth list); arrays are copies of the library-owned pinned buffers."""
+        n = self.options.num_render_streams
+        pb, pd = (u8p * max(n, 1))(), (f32p * max(n, 1))()
+        check(_lib.lib().drf_get_render_result(self._h, pb, pd, n))
+        H, W = self._hw
+        bgrs = [np.ctypeslib.as_array(pb[i], shape=(H, W, 3)).copy() for i in range(n)]
+        depths = [np.ctypeslib.as_array(pd[i], shape=(H, W)).copy() for i in range(n)]
+        return bgrs, depths
+
+    def ExtractMeshAsync(self, lower_corner, upper_corner):
+        lo, up = (np.ascontiguousarray(a, np.float32) for a in (lower_corner, upper_corner))
+        check(_lib.lib().drf_extract_mesh_async(self._h, fptr(lo), fptr(up)))
+
+    def GetMeshSync(self):
+        num = C.c_size_t()
+        check(_lib.lib().drf_get_mesh_sync(self._h, 0, C.byref(num), None, None))
+
+    def SaveMeshToFile(self, filename, lower_corner, upper_corner):
+        lo, up = (np.ascontiguousarray(a, np.float32) for a in (lower_corner, upper_corner))
+        check(_lib.lib().drf_save_mesh(self._h, str(filename).encode(), fptr(lo), fptr(up)))
+
+    def Synchronize(self):
+        check(_lib.lib().drf_synchronize(self._h))
+
+    # ---- introspection / measurement hooks (no reference counterpart) ----
+    def stats(self):
+        out = (C.c_uint64 * 4)()
+        check(_lib.lib().drf_stats(self._h, out))
+        return dict(blocks=int(out[0]), updated_last=int(out[1]), updated_total=int(out[2]), mismatches=int(out[3]))
+
+    def export_blocks(self):
+        """Canonical dump: dict {(bx,by,bz): uint8[4096]} (512 voxels x {f32 sdf, u8 b,g,r, u8 weight})."""
+        n = self.stats()["blocks"]
+        coords = np.empty((max(n, 1), 3), np.int32)
+        vox = np.empty((max(n, 1), 4096), np.uint8)
+        got = C.c_int()
+        check(_lib.lib().drf_export_blocks(self._h, n, coords.ctypes.data_as(C.POINTER(C.c_int32)),
+                                           vox.ctypes.data_as(u8p), C.byref(got)))
+        return {tuple(int(v) for v in coords[i]): vox[i] for i in range(got.value)}
+
+    def bench_integrate(self, bgrs, depths, poses):
+        """Uploads the scans once, then times back-to-back allocate+integrate of all of them (HBM-resident)."""
+        L = _lib.lib()
+        n = len(bgrs)
+        bg = np.ascontiguousarray(np.stack(bgrs), np.uint8)
+        dp = np.ascontiguousarray(np.stack(depths), np.float32)
+        ps = np.ascontiguousarray(np.stack([np.asarray(p, np.float32).reshape(16) for p in poses]), np.float32)
+        d_b, d_d = C.c_void_p(), C.c_void_p()
+        check(L.dr_device_alloc(0, bg.nbytes, C.byref(d_b)))
+        check(L.dr_device_alloc(0, dp.nbytes, C.byref(d_d)))
+        try:
+            check(L.dr_memcpy_h2d(d_b, bg.ctypes.data_as(C.c_void_p), bg.nbytes))
+            check(L.dr_memcpy_h2d(d_d, dp.ctypes.data_as(C.c_void_p), dp.nbytes))
+            ms, kms = C.c_float(), C.c_float()
+            check(L.drf_bench_integrate(self._h, d_b, d_d, fptr(ps), n, C.byref(ms), C.byref(kms)))
+        finally:
+            L.dr_device_free(d_b)
+            L.dr_device_free(d_d)
+        return ms.value, kms.value
