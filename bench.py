@@ -1,0 +1,206 @@
+#!/usr/bin/env python
+"""bench.py -- the hot path's headline metric on MI355X (BASELINE.json):
+    "depth-maps/sec @ 640x480x7-view x 3-stage; TSDF voxels integrated/sec".
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the DrMvsnet hot path (pre-process .. edge filter) over one synthetic keyframe window
+that is already resident in HBM when the timed region starts.  Workload at every N = BASELINE configs[1]:
+640x480, ref + 6 src views, 3-stage cascade with (48,32,8) depth planes, fp32, view aggregation on.
+Multi-GPU: independent replicas, one window stream per rank, no data-path collective ("scaling": "weak");
+value = depth maps of all ranks / max-over-ranks time.  Rank 0 prints ONE JSON line; the TSDF half of the
+metric (BASELINE configs[3] shape: 640x480 scans into a 5 mm hashed grid) rides along in its "tsdf" object.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA (== fp32 vector) peak
+PEAK_HBM_GBPS = 8000.0          # HBM3E spec peak (6.3 TB/s measured achievable)
+H, W, V = 480, 640, 7
+DISCARD = 10.0                  # TANDEM's mvsnet_discard_percentage default (settings.cpp:300)
+
+
+def mvsnet_leg(args, rank, dev, world):
+    import torch
+    from oracle import scene  # synthetic input generator (test infrastructure, not the measured path)
+    from tandem_amd import replicas
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    blob = os.path.join(ROOT, "weights", "tandem_va.tdmw")
+    win = scene.make_window(H, W, V, seed=rank)
+    m = DrMvsnet(blob, device=dev)
+    m.upload(H, W, V, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), win["depth_min"], win["depth_max"], DISCARD)
+    if args.warmup > 0:
+        m.forward(args.warmup)
+    replicas.barrier(dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev_ms = m.forward(args.steps)  # enqueues exactly K forwards on the engine stream, then stream-synchronises
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    replicas.barrier(dev)
+    tmax, units = replicas.reduce_max_sum(t1 - t0, args.steps, dev)
+    res = dict(value=units / tmax, ms_per_step=1e3 * tmax / args.steps, event_ms_per_step=ev_ms / args.steps)
+    if rank == 0:
+        flops, nbytes = m.work()
+        prof = m.profile()  # hipEvents around every launch of one forward, on the engine's own stream
+        by = {}
+        for r in prof:
+            k = by.setdefault(r["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, n=0))
+            k["ms"] += r["ms"]; k["flops"] += r["flops"]; k["bytes"] += r["bytes"]; k["n"] += 1
+        name, dom = max(by.items(), key=lambda kv: kv[1]["ms"])
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        res["roofline"] = dict(bound="mfma", kernel=name, launches_per_step=dom["n"],
+                               avg_launch_ms=dom["ms"] / dom["n"], flops_per_launch=dom["flops"] / dom["n"],
+                               achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_FP32_MFMA_TFLOPS,
+                               traffic=None)
+        step_s = res["ms_per_step"] * 1e-3
+        res["pipeline"] = dict(gflop_per_depth_map=flops / 1e9, gb_per_depth_map=nbytes / 1e9,
+                               tflops=flops / step_s / 1e12, frac_mfma=flops / step_s / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                               gbps=nbytes / step_s / 1e9, frac_hbm=nbytes / step_s / 1e9 / PEAK_HBM_GBPS,
+                               kernels={k: round(v["ms"], 4) for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])})
+        if world == 1 and not args.no_cpu:
+            res["cpu_baseline"] = mvsnet_cpu_baseline(win, blob)
+    m.close()
+    return res
+
+
+def mvsnet_cpu_baseline(win, blob):
+    """The CPU restatement of the reference model (oracle, kind "port": same ATen op family as the reference's
+    eval path) on the host cores of this box, same window, model forward only."""
+    import torch
+    from oracle import mvsnet_oracle as O
+    from tandem_amd import weights as Wt
+    meta, tens = Wt.read_blob(blob)
+    w = O.Weights(meta, tens)
+    cores = torch.get_num_threads()
+    run = lambda: O.forward(w, win["bgrs"], win["K"], win["c2ws"], win["ref_index"], win["depth_min"], win["depth_max"], DISCARD)
+    run()  # warm-up
+    times = []
+    while len(times) < 3 and sum(times) < 20.0:
+        t0 = time.perf_counter(); run(); times.append(time.perf_counter() - t0)
+    best = min(times)
+    return dict(value=1.0 / best, unit="depth-maps/s", cores=cores, kind="port",
+                sample="%d timed forwards of the same 640x480x7-view (48,32,8) window after 1 warm-up, torch CPU fp32, best %.2f s" % (len(times), best))
+
+
+def tsdf_leg(args, rank, dev, world):
+    import torch
+    from oracle import scene
+    from tandem_amd import replicas
+    from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
+    distinct, cycles = args.tsdf_scans, args.tsdf_cycles
+    sc = scene.make_scans(distinct, H, W, seed=100 + rank, texture_terms=3)
+    opt = dict(voxel_size=0.005, num_buckets=400000, bucket_size=10, num_blocks=2000000, block_size=8, max_sdf_weight=64,
+               truncation_distance=0.02, max_sensor_depth=10.0, min_sensor_depth=0.1, num_render_streams=1,
+               fx=sc["fx"], fy=sc["fy"], cx=sc["cx"], cy=sc["cy"], height=H, width=W)
+    f = DrFusion(DrFusionOptions(**opt), device=dev)
+    bgrs = [s[0] for s in sc["scans"]] * cycles
+    depths = [s[1] for s in sc["scans"]] * cycles
+    poses = [s[2] for s in sc["scans"]] * cycles
+    f.bench_integrate(bgrs[:distinct], depths[:distinct], poses[:distinct])  # warm-up pass: allocates the map once
+    before = f.stats()
+    replicas.barrier(dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ms, kms = f.bench_integrate(bgrs, depths, poses)  # resident scans; hipEvents on the integration stream
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    replicas.barrier(dev)
+    after = f.stats()
+    vox = after["updated_total"] - before["updated_total"]
+    tmax, units = replicas.reduce_max_sum(ms * 1e-3, vox, dev)
+    res = dict(metric="TSDF voxels integrated/sec", value=units / tmax, unit="voxels/s", scans=len(bgrs),
+               ms_per_scan=1e3 * tmax / len(bgrs), wall_ms_per_scan_incl_upload=1e3 * (t1 - t0) / len(bgrs),
+               blocks=after["blocks"], voxels_per_scan=vox / len(bgrs),
+               config=dict(workload="%d integrations (%d distinct synthetic 640x480 scans x %d cycles) into a 5 mm hashed voxel grid, truncation 20 mm, "
+                                    "allocate + integrate kernels, scans resident in HBM" % (len(bgrs), distinct, cycles)))
+    if rank == 0:
+        n = len(bgrs)
+        ach = 16.0 * vox / (kms * 1e-3) / 1e9
+        res["roofline"] = dict(bound="hbm", kernel="k_integrate", avg_launch_ms=kms / n, bytes_per_launch=16.0 * vox / n,
+                               achieved=ach, peak=PEAK_HBM_GBPS, unit="GB/s", frac=ach / PEAK_HBM_GBPS, traffic=None)
+        # raycast (DrFusion::RenderAsync) of the fused map, one 640x480 view
+        f.IntegrateScanAsync(*sc["scans"][0])
+        t0 = time.perf_counter(); f.RenderAsync([poses[0]]); f.GetRenderResult(); t1 = time.perf_counter()
+        res["raycast_ms_incl_d2h"] = 1e3 * (t1 - t0)
+        if world == 1 and not args.no_cpu:
+            res["cpu_baseline"] = tsdf_cpu_baseline(sc, opt)
+    f.close()
+    return res
+
+
+def tsdf_cpu_baseline(sc, opt):
+    from oracle.tsdf_oracle import TsdfOracle
+    o = TsdfOracle(**dict(opt, num_blocks=400000))
+    n, t, upd = 0, 0.0, 0
+    for bgr, depth, pose in sc["scans"]:
+        t0 = time.perf_counter(); o.integrate(bgr, depth, pose); t += time.perf_counter() - t0
+        n += 1
+        if t > 15.0:
+            break
+    upd = o.stats()["updated_total"]
+    return dict(value=upd / t, unit="voxels/s", cores=1, kind="port",
+                sample="first %d of the same 640x480 scans, single-threaded C restatement (oracle/tsdf_oracle.c), %.1f s" % (n, t))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--tsdf-scans", type=int, default=50, help="distinct synthetic scans for the TSDF leg")
+    ap.add_argument("--tsdf-cycles", type=int, default=20, help="times the scan set is re-integrated (default 50 x 20 = 1000 integrations)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
+    ap.add_argument("--no-tsdf", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from tandem_amd import replicas
+    rank, local_rank, world = replicas.env_world()
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run (running %d replica%s)"
+              % (args.gpus, world, world, "" if world == 1 else "s"), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    replicas.init("nccl", local_rank)
+
+    mv = mvsnet_leg(args, rank, local_rank, world)
+    ts = None if args.no_tsdf else tsdf_leg(args, rank, local_rank, world)
+    if rank == 0:
+        out = {
+            "metric": "depth-maps/sec @ 640x480x7-view x3-stage; TSDF voxels integrated/sec",
+            "value": mv["value"], "unit": "depth-maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": mv["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "640x480 ref+6-src keyframe window, 3-stage cascade (48/32/8 hypotheses), view aggregation, fp32; "
+                                   "one independent window per GPU (replicas); trained weights recovered from the reference's exported "
+                                   "tandem_512x320 model (same architecture), inputs resident in HBM",
+                       "height": H, "width": W, "views": V, "planes": [48, 32, 8], "discard_percentage": DISCARD,
+                       "parallelism": "replicas x%d" % world,
+                       "reference_published": "2.70 FPS (abl03, unstated GPU, incl. data loading) -- not the same clock, so vs_baseline is null"},
+            "event_ms_per_step": mv["event_ms_per_step"],
+        }
+        for k in ("roofline", "cpu_baseline", "pipeline"):
+            if k in mv:
+                out[k] = mv[k]
+        if ts is not None:
+            out["tsdf"] = ts
+        print(json.dumps(out))
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

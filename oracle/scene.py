@@ -15,10 +15,9 @@ Pure numpy; deterministic for a given seed.
 import numpy as np
 
 
-def _texture(X, Y, Z, seed):
+def _texture(X, Y, Z, seed, n=20):
     """Band-limited procedural RGB texture evaluated at world points (values in [0,1])."""
     rng = np.random.RandomState(seed)
-    n = 20
     out = np.zeros(X.shape + (3,), np.float64)
     for c in range(3):
         f = rng.uniform(4.0, 110.0, size=(n, 3)) * rng.choice([-1, 1], size=(n, 3))
@@ -42,7 +41,7 @@ def _pose(rx, ry, rz, t):
     return T
 
 
-def _render(K, c2w, H, W, seed):
+def _render(K, c2w, H, W, seed, terms=20):
     """Ray-cast a tilted back plane plus a nearer rectangular slab; returns (rgb float HxWx3, z-depth HxW)."""
     v, u = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
     d_cam = np.stack([(u - K[0, 2]) / K[0, 0], (v - K[1, 2]) / K[1, 1], np.ones_like(u)], -1)
@@ -57,8 +56,8 @@ def _render(K, c2w, H, W, seed):
     hit1 = (np.abs(P1[..., 0] - 0.05) < 0.45) & (np.abs(P1[..., 1] + 0.02) < 0.30) & (t1 > 0)
     t = np.where(hit1, t1, t0)
     P = o + d_w * t[..., None]
-    rgb = np.where(hit1[..., None], _texture(P[..., 0], P[..., 1], P[..., 2], seed + 1),
-                   _texture(P[..., 0], P[..., 1], P[..., 2], seed))
+    rgb = np.where(hit1[..., None], _texture(P[..., 0], P[..., 1], P[..., 2], seed + 1, terms),
+                   _texture(P[..., 0], P[..., 1], P[..., 2], seed, terms))
     return rgb, t  # d_cam.z == 1 so t is z-depth in the camera
 
 
@@ -87,7 +86,7 @@ def make_window(height=480, width=640, view_num=7, seed=0):
                 depth_min=0.5, depth_max=5.0, gt_depth=gt, height=height, width=width, view_num=view_num)
 
 
-def make_scans(n, height=480, width=640, seed=0, drop_fraction=0.025):
+def make_scans(n, height=480, width=640, seed=0, drop_fraction=0.025, texture_terms=20):
     """n scans of the analytic scene from a smooth seeded camera loop.
     Returns dict(K (fx,fy,cx,cy), scans=[(bgr u8 HxWx3, depth f32 HxW, pose f32 4x4 row-major c2w)])."""
     f = 0.78125 * width
@@ -98,7 +97,7 @@ def make_scans(n, height=480, width=640, seed=0, drop_fraction=0.025):
         a = 2 * np.pi * i / max(n, 8)
         T = _pose(0.05 * np.sin(a), 0.12 * np.sin(a * 0.5), 0.02 * np.cos(a),
                   [0.25 * np.sin(a), 0.10 * np.cos(a), 0.15 * np.sin(2 * a)])
-        rgb, z = _render(K, T, height, width, seed)
+        rgb, z = _render(K, T, height, width, seed, texture_terms)
         depth = z.astype(np.float32)
         drop = rng.rand(height, width) < drop_fraction  # mimics the MVSNet edge filter's zeros
         depth[drop] = 0.0

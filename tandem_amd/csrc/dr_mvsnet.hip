@@ -227,7 +227,16 @@ class MvsEngine {
       float t = 0;
       DR_HIP(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
       ms.push_back(t);
-      names += ops_[i].name; names += '\n';
+      const Op &o = ops_[i];
+      char kn[64] = "misc";
+      if (o.kind == Op::CONV) snprintf(kn, sizeof kn, "k_conv<%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt);
+      else if (o.kind == Op::COSTVOL) snprintf(kn, sizeof kn, "k_costvol<%d>", 32 >> (o.stage - 1));
+      else if (o.kind == Op::REGRESS) snprintf(kn, sizeof kn, "k_regress");
+      else if (o.kind == Op::PREPROCESS) snprintf(kn, sizeof kn, "k_preprocess");
+      else snprintf(kn, sizeof kn, "k_filter");
+      char line[256];
+      snprintf(line, sizeof line, "%s\t%s\t%.6e\t%.6e\n", o.name.c_str(), kn, o.flops, o.bytes);
+      names += line;
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
   }

@@ -106,7 +106,11 @@ class DrMvsnet:
         ms = (C.c_float * 512)()
         cnt = C.c_int()
         check(_lib.lib().drm_profile(self._h, names, len(names), ms, 512, C.byref(cnt)))
-        return list(zip(names.value.decode().strip().split("\n"), list(ms)[:cnt.value]))
+        rows = []
+        for line, t in zip(names.value.decode().strip().split("\n"), list(ms)[:cnt.value]):
+            op, kern, fl, by = line.split("\t")
+            rows.append(dict(op=op, kernel=kern, flops=float(fl), bytes=float(by), ms=t))
+        return rows
 
     def work(self):
         f, b = C.c_double(), C.c_double()

@@ -68,8 +68,8 @@ def main():
           float((out.depth == 0).mean()), "ref", float((ref["depth"] == 0).mean()))
     print("reference criterion mean|depth-ref| =", float(np.abs(out.depth - ref["depth"]).mean()),
           " mean|conf-ref| =", float(np.abs(out.confidence - ref["confidence"]).mean()))
-    for name, t in m.profile():
-        print("  %-18s %8.3f ms" % (name, t))
+    for r in m.profile():
+        print("  %-18s %8.3f ms  %-16s %8.2f GF %8.1f MB" % (r["op"], r["ms"], r["kernel"], r["flops"] / 1e9, r["bytes"] / 1e6))
     f, b = m.work()
     print("work: %.2f GFLOP  %.3f GB" % (f / 1e9, b / 1e9))
     ms = m.forward(5)
