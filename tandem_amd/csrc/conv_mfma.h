@@ -31,36 +31,45 @@ namespace dr {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+struct ConvClass {  // one output-parity class of a launch (plain convs have exactly one)
+  int NU;        // K chunks per channel pass
+  int tap_base;  // offset into tapoff[]
+  int w_base;    // offset into wpk[] (float4 units)
+  int ooz, ooy, oox;
+};
+
 struct ConvArgs {
   const float *in;
   float *out;
   const float4 *wpk;
   const float *scale, *bias, *add;
   const int *tapoff;
+  const ConvClass *cls;
   int inD, inH, inW, inC;
   int outD, outH, outW, outC;
   int nPD, nPH, nPW;
   int sz, sy, sx, pz, py, px;
-  int omz, omy, omx, ooz, ooy, oox;
+  int omz, omy, omx;
   int TZ, TY, TXT, TZI, TYI, TXI;
-  int NU, npass, rows_valid, relu, add_mode, addH, addW;
+  int npass, ctTot, rows_valid, relu, add_mode, addH, addW;
+  unsigned magicX, magicY;  // ceil(2^32 / TXI), ceil(2^32 / TYI): exact division of tile positions (< 2^16)
   int tilesD, tilesH, tilesW;
 };
 
 constexpr int kConvThreads = 256;
 constexpr size_t kConvMaxLds = 160 * 1024;  // gfx950: 160 KiB LDS per CU, one workgroup may take all of it
 
-// PT = position tiles (16 positions each) per wave: 4 normally, 1 for strided layers whose halo tile
-// would not fit LDS otherwise.
+// grid = (tiles, parity classes, output-row groups).  PT = position tiles (16 positions each) per wave.
 template <int CI, int CT, int PT>
 __global__ __launch_bounds__(kConvThreads) void k_conv(const ConvArgs a) {
-  constexpr int kPT = PT;
   extern __shared__ float4 lds4[];
   float *lds = reinterpret_cast<float *>(lds4);
   constexpr int CIS = CI + 4;  // LDS floats per staged position (+4: spreads b128 reads over bank slots)
   constexpr int TPC = 16 / CI; // taps per 16-wide K chunk
   constexpr int C4 = CI / 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  const ConvClass cls = a.cls[blockIdx.y];
+  const int ct0 = blockIdx.z * CT;
 
   int b = blockIdx.x;
   const int tw = b % a.tilesW;
@@ -69,73 +78,116 @@ __global__ __launch_bounds__(kConvThreads) void k_conv(const ConvArgs a) {
   const int pz0 = td * a.TZ, py0 = th * a.TY, px0 = tw * a.TXT * 16;
   const int iz0 = pz0 * a.sz - a.pz, iy0 = py0 * a.sy - a.py, ix0 = px0 * a.sx - a.px;
 
-  int base[kPT];
+  int base[PT];
 #pragma unroll
-  for (int pt = 0; pt < kPT; ++pt) {
-    const int tau = wave * kPT + pt;
+  for (int pt = 0; pt < PT; ++pt) {
+    const int tau = wave * PT + pt;
     const int xt = tau % a.TXT, yt = (tau / a.TXT) % a.TY, zt = tau / (a.TXT * a.TY);
-    base[pt] = ((zt * a.sz) * a.TYI + yt * a.sy) * a.TXI + (xt * 16 + j) * a.sx;
+    base[pt] = (((zt * a.sz) * a.TYI + yt * a.sy) * a.TXI + (xt * 16 + j) * a.sx) * CIS + (4 * g) % CI;
   }
-  const int sub = (4 * g) / CI, coff = (4 * g) % CI;
+  const int sub = (4 * g) / CI;
 
-  floatx4 acc[CT][kPT];
+  floatx4 acc[CT][PT];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-    for (int pt = 0; pt < kPT; ++pt) acc[ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-  const int NP = a.TZI * a.TYI * a.TXI;
+  const int NP = a.TZI * a.TYI * a.TXI, NU = cls.NU;
+  // tap table of this class -> LDS (pre-multiplied by the position stride) so the K loop has no dependent global load
+  int *tapl = reinterpret_cast<int *>(lds + (size_t)NP * CIS);
+  for (int i = tid; i < NU * TPC; i += kConvThreads) tapl[i] = a.tapoff[cls.tap_base + i] * CIS;
+  const int *tp = tapl + sub;
+  const unsigned total = (unsigned)NP * C4;
   for (int p = 0; p < a.npass; ++p) {
-    // ---- stage CI channels of the input halo tile into LDS (zero outside the tensor) ----
-    for (int e = tid; e < NP * C4; e += kConvThreads) {
-      const int pos = e / C4, c4 = e - pos * C4;
-      const int x = pos % a.TXI, t = pos / a.TXI;
-      const int y = t % a.TYI, z = t / a.TYI;
-      const int gz = iz0 + z, gy = iy0 + y, gx = ix0 + x;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gz >= 0 && gz < a.inD && gy >= 0 && gy < a.inH && gx >= 0 && gx < a.inW)
-        v = *reinterpret_cast<const float4 *>(a.in + (((size_t)gz * a.inH + gy) * a.inW + gx) * a.inC + p * CI + c4 * 4);
-      *reinterpret_cast<float4 *>(lds + pos * CIS + c4 * 4) = v;
+    // ---- stage CI channels of the input halo tile into LDS (zero outside the tensor).  Loads are issued in
+    // batches of kStageBatch per lane BEFORE the first LDS write so their HBM/L2 latencies overlap. ----
+    constexpr int kStageBatch = 4;
+    for (unsigned e0 = 0; e0 < total; e0 += kConvThreads * kStageBatch) {
+      float4 v[kStageBatch];
+      int dst[kStageBatch];
+#pragma unroll
+      for (int k = 0; k < kStageBatch; ++k) {
+        const unsigned e = e0 + k * kConvThreads + tid;
+        const unsigned pos = e / C4, c4 = e - pos * C4;
+        const unsigned t = __umulhi(pos, a.magicX), x = pos - t * a.TXI;   // exact for pos < 2^16
+        const unsigned z = __umulhi(t, a.magicY), y = t - z * a.TYI;
+        const int gz = iz0 + (int)z, gy = iy0 + (int)y, gx = ix0 + (int)x;
+        v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dst[k] = e < total ? (int)(pos * CIS + c4 * 4) : -1;
+        if (e < total && gz >= 0 && gz < a.inD && gy >= 0 && gy < a.inH && gx >= 0 && gx < a.inW)
+          v[k] = *reinterpret_cast<const float4 *>(a.in + (((size_t)gz * a.inH + gy) * a.inW + gx) * a.inC + p * CI + c4 * 4);
+      }
+#pragma unroll
+      for (int k = 0; k < kStageBatch; ++k)
+        if (dst[k] >= 0) *reinterpret_cast<float4 *>(lds + dst[k]) = v[k];
     }
     __syncthreads();
-    // ---- K loop over (tap-group) chunks of this channel pass ----
-    const float4 *wp = a.wpk + (size_t)p * a.NU * CT * 64 + lane;
-    for (int u = 0; u < a.NU; ++u) {
-      float4 av[CT];
+    // ---- K loop over the chunks of this channel pass, operands of chunk u+1 fetched under the MFMAs of u ----
+    const float4 *wp = a.wpk + cls.w_base + ((size_t)p * NU * a.ctTot + ct0) * 64 + lane;
+    float4 av[CT], bv[PT];
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) av[ct] = wp[(u * CT + ct) * 64];
-      const int toff = a.tapoff[u * TPC + sub];
-      float4 bv[kPT];
+    for (int ct = 0; ct < CT; ++ct) av[ct] = wp[ct * 64];
+    {
+      const int toff = tp[0];
 #pragma unroll
-      for (int pt = 0; pt < kPT; ++pt)
-        bv[pt] = *reinterpret_cast<const float4 *>(lds + (base[pt] + toff) * CIS + coff);
+      for (int pt = 0; pt < PT; ++pt) bv[pt] = *reinterpret_cast<const float4 *>(lds + base[pt] + toff);
+    }
+    for (int u = 0; u < NU; ++u) {
+      const int un = min(u + 1, NU - 1);
+      float4 an[CT], bn[PT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) an[ct] = wp[((size_t)un * a.ctTot + ct) * 64];
+      const int toff = tp[un * TPC];
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) bn[pt] = *reinterpret_cast<const float4 *>(lds + base[pt] + toff);
+      // consecutive MFMAs go to different accumulators (16x16x4: 32-cycle issue, 40-cycle dependent latency)
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int pt = 0; pt < kPT; ++pt) {
-          acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct].x, bv[pt].x, acc[ct][pt], 0, 0, 0);
-          acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct].y, bv[pt].y, acc[ct][pt], 0, 0, 0);
-          acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct].z, bv[pt].z, acc[ct][pt], 0, 0, 0);
-          acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct].w, bv[pt].w, acc[ct][pt], 0, 0, 0);
-        }
+        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct].x, bv[pt].x, acc[ct][pt], 0, 0, 0);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct].y, bv[pt].y, acc[ct][pt], 0, 0, 0);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct].z, bv[pt].z, acc[ct][pt], 0, 0, 0);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct].w, bv[pt].w, acc[ct][pt], 0, 0, 0);
+      // Anchor the prefetched operands at the END of this iteration: without a use here hipcc sinks the loads
+      // into the next iteration, right in front of their MFMAs, and every chunk eats a full L2 round trip.
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        asm volatile("" ::"v"(an[ct].x), "v"(an[ct].y), "v"(an[ct].z), "v"(an[ct].w));
+        av[ct] = an[ct];
+      }
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        asm volatile("" ::"v"(bn[pt].x), "v"(bn[pt].y), "v"(bn[pt].z), "v"(bn[pt].w));
+        bv[pt] = bn[pt];
+      }
     }
     __syncthreads();
   }
 
   // ---- epilogue: folded BN, ReLU, residual / upsample add, one float4 (4 channels) per lane ----
 #pragma unroll
-  for (int pt = 0; pt < kPT; ++pt) {
-    const int tau = wave * kPT + pt;
+  for (int pt = 0; pt < PT; ++pt) {
+    const int tau = wave * PT + pt;
     const int xt = tau % a.TXT, yt = (tau / a.TXT) % a.TY, zt = tau / (a.TXT * a.TY);
     const int qz = pz0 + zt, qy = py0 + yt, qx = px0 + xt * 16 + j;
     if (qz >= a.nPD || qy >= a.nPH || qx >= a.nPW) continue;
-    const int oz = qz * a.omz + a.ooz, oy = qy * a.omy + a.ooy, ox = qx * a.omx + a.oox;
+    const int oz = qz * a.omz + cls.ooz, oy = qy * a.omy + cls.ooy, ox = qx * a.omx + cls.oox;
     const size_t obase = (((size_t)oz * a.outH + oy) * a.outW + ox) * a.outC;
     size_t abase = obase;
     if (a.add_mode == 2) abase = (((size_t)oz * a.addH + (oy >> 1)) * a.addW + (ox >> 1)) * a.outC;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-      const int c0 = ct * 16 + 4 * g;
+      const int c0 = (ct0 + ct) * 16 + 4 * g;
       if (c0 >= a.rows_valid) continue;
       const float4 sc = *reinterpret_cast<const float4 *>(a.scale + c0);
       const float4 bi = *reinterpret_cast<const float4 *>(a.bias + c0);
@@ -174,12 +226,12 @@ struct ConvLayer {  // logical description (torch semantics)
 struct ConvLaunch {
   ConvArgs args;
   int ci, ct, pt;
-  int grid;
+  dim3 grid;
   size_t lds_bytes;
   double flops;  // useful (algorithmic) flops of this launch
 };
 
-struct DimTaps {               // per-axis decomposition of one launch
+struct DimTaps {               // per-axis decomposition of one parity class
   std::vector<int> t, off;     // kernel index, input offset (>= 0)
   int s = 1, p = 0, om = 1, oo = 0, npos = 0;
 };
@@ -224,12 +276,13 @@ struct DeviceArena {  // owns small device buffers created while planning (weigh
   ~DeviceArena() { for (void *p : ptrs) (void)hipFree(p); }
 };
 
+inline bool conv_instance_exists(int ci, int ct) {
+  return (ci == 4 && ct == 1) || ((ci == 8 || ci == 16) && (ct == 1 || ct == 2 || ct == 4));
+}
+
 inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in, int inD, int inH, int inW, int inC,
                              float *out, const float *add, int add_mode, DeviceArena &arena) {
   if (L.Cin % 4 != 0 || inC < L.Cin) fail(DR_ERR_ARG, "plan_conv: Cin=%d must be a multiple of 4 (tensor C=%d)", L.Cin, inC);
-  const int CI = L.Cin >= 16 ? 16 : L.Cin;  // 4, 8 or 16
-  if (L.Cin % CI != 0 || (CI != 4 && CI != 8 && CI != 16)) fail(DR_ERR_ARG, "plan_conv: unsupported Cin=%d", L.Cin);
-  const int npass = L.Cin / CI, TPC = 16 / CI, CIS = CI + 4;
   auto cz = axis_classes(L.kd, L.sd, L.transposed, inD);
   auto cy = axis_classes(L.kh, L.sh, L.transposed, inH);
   auto cx = axis_classes(L.kw, L.sw, L.transposed, inW);
@@ -248,10 +301,66 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
     rows = cdiv(L.Cout, 16) * 16; rows_valid = L.Cout; outCv = L.Cout;
     if (L.Cout % 4) fail(DR_ERR_ARG, "plan_conv: Cout=%d must be a multiple of 4", L.Cout);
   }
-  const int CT = rows / 16;
-  if (!((CI == 4 && CT == 1) || (CI == 8 && CT <= 2) || (CI == 16 && (CT == 1 || CT == 2 || CT == 4))))
-    fail(DR_ERR_ARG, "plan_conv: no kernel instance for CI=%d CT=%d", CI, CT);
+  const int CTtot = rows / 16;
   const int shifts = mode == CONV_XPAIR ? 2 : (mode == CONV_X8 ? 8 : 1);
+  if (shifts > 1) {  // widen the x taps: in = pos*shifts - pad + t', t' in [0, kw + shifts - 1)
+    DimTaps &X = cx[0];
+    X.t.clear(); X.off.clear();
+    for (int t = 0; t < L.kw + shifts - 1; ++t) { X.t.push_back(t); X.off.push_back(t); }
+    X.s = shifts; X.npos = outWv;
+  }
+  // geometry shared by all parity classes: strides, padding, extents = union over classes
+  const int SZ = cz[0].s, SY = cy[0].s, SX = cx[0].s, PZ = cz[0].p, PY = cy[0].p, PX = cx[0].p;
+  const int nPD = cz[0].npos, nPH = cy[0].npos, nPW = cx[0].npos;
+  int exz = 0, exy = 0, exx = 0;
+  for (auto &c : cz) for (int o : c.off) exz = std::max(exz, o + 1);
+  for (auto &c : cy) for (int o : c.off) exy = std::max(exy, o + 1);
+  for (auto &c : cx) for (int o : c.off) exx = std::max(exx, o + 1);
+  struct Cls { const DimTaps *z, *y, *x; int ntaps; };
+  std::vector<Cls> classes;
+  for (auto &Z : cz) for (auto &Y : cy) for (auto &X : cx) classes.push_back({&Z, &Y, &X, (int)(Z.t.size() * Y.t.size() * X.t.size())});
+  const int ncls = (int)classes.size();
+
+  // ---- plan: channel pass width CI, position tiles per wave PT, tile shape, output-row split ----
+  static const int cand16[][3] = {{1, 1, 16}, {1, 2, 8}, {1, 4, 4}, {1, 8, 2}, {1, 16, 1}, {2, 1, 8}, {2, 2, 4},
+                                  {2, 4, 2}, {2, 8, 1}, {4, 1, 4}, {4, 2, 2}, {4, 4, 1}, {8, 1, 2}, {8, 2, 1}, {16, 1, 1}};
+  static const int cand4[][3] = {{1, 1, 4}, {1, 2, 2}, {1, 4, 1}, {2, 1, 2}, {2, 2, 1}, {4, 1, 1}};
+  double best = 1e300;
+  int CI = 0, PT = 0, CT = 0, TZ = 0, TY = 0, TXT = 0, TZI = 0, TYI = 0, TXI = 0;
+  for (int ci : {16, 8, 4}) {
+    if (L.Cin % ci || (ci == 4 && L.Cin != 4)) continue;
+    const int npass = L.Cin / ci, tpc = 16 / ci;
+    double chunks = 0;  // K chunks per pass summed over classes
+    for (auto &c : classes) chunks += cdiv(c.ntaps, tpc);
+    for (int pt : {4, 1}) {
+      const int (*cand)[3] = pt == 4 ? cand16 : cand4;
+      const int ncand = pt == 4 ? 15 : 6;
+      for (int k = 0; k < ncand; ++k) {
+        const int *c = cand[k];
+        const int tzi = (c[0] - 1) * SZ + exz, tyi = (c[1] - 1) * SY + exy, txi = (c[2] * 16 - 1) * SX + exx;
+        const size_t bytes = (size_t)tzi * tyi * txi * (ci + 4) * 4 + 1024;  // + tap table
+        if (bytes > kConvMaxLds) continue;
+        const double tiles = (double)cdiv(nPD, c[0]) * cdiv(nPH, c[1]) * cdiv(nPW, c[2] * 16);
+        for (int ct : {4, 2, 1}) {
+          if (CTtot % ct || !conv_instance_exists(ci, ct)) continue;
+          const int split = CTtot / ct;
+          // cost model (cycles): MFMA issue, staging, and a latency floor per chunk; see DESIGN.md
+          const double wg_per_cu = std::max(1.0, std::min({(double)(kConvMaxLds / bytes), 8.0, (ct == 4 && pt == 4) ? 5.0 : 8.0}));
+          const double stage = npass * ((double)tzi * tyi * txi * (ci / 4) / 256.0 * 60.0 + 900.0);
+          const double chunk_mfma = 4.0 * ct * pt * 32.0;
+          const double n_wg = tiles * split;  // per class
+          const double mfma_total = n_wg * npass * chunks * chunk_mfma, stage_total = n_wg * ncls * stage;
+          const double lat_wg = npass * (chunks / ncls) * std::max(chunk_mfma, 400.0) + stage;
+          const double waves = std::ceil(n_wg * ncls / (256.0 * wg_per_cu));
+          const double thr = (mfma_total + stage_total) / 256.0 / (wg_per_cu >= 2 ? 0.8 : 0.5);
+          const double cost = std::max(thr, waves * lat_wg);
+          if (cost < best) { best = cost; CI = ci; PT = pt; CT = ct; TZ = c[0]; TY = c[1]; TXT = c[2]; TZI = tzi; TYI = tyi; TXI = txi; }
+        }
+      }
+    }
+  }
+  if (!CI) fail(DR_ERR_ARG, "plan_conv: no kernel instance / tile shape for Cin=%d Cout=%d", L.Cin, L.Cout);
+  const int npass = L.Cin / CI, TPC = 16 / CI, CIS = CI + 4;
 
   // per-row epilogue affine
   std::vector<float> sc(rows, 1.f), bi(rows, 0.f);
@@ -260,63 +369,35 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
     if (!L.scale.empty()) sc[r] = L.scale[c];
     if (!L.bias.empty()) bi[r] = L.bias[c];
   }
-  const float *d_scale = arena.upload(sc), *d_bias = arena.upload(bi);
-
   auto weight_at = [&](int co, int ci, int tz, int ty, int tx) -> float {
     if (!L.transposed) return L.weight[((((size_t)co * L.Cin + ci) * L.kd + tz) * L.kh + ty) * L.kw + tx];
     return L.weight[((((size_t)ci * L.Cout + co) * L.kd + tz) * L.kh + ty) * L.kw + tx];
   };
 
-  for (const DimTaps &Z : cz) for (const DimTaps &Y : cy) for (const DimTaps &X0 : cx) {
-    DimTaps X = X0;
-    if (shifts > 1) {  // widen the x taps: in = pos*shifts - pad + t', t' in [0, kw + shifts - 1)
-      X.t.clear(); X.off.clear();
-      for (int t = 0; t < L.kw + shifts - 1; ++t) { X.t.push_back(t); X.off.push_back(t); }
-      X.s = shifts; X.npos = outWv;
-    }
-    const int ntz = (int)Z.t.size(), nty = (int)Y.t.size(), ntx = (int)X.t.size();
-    const int ntaps = ntz * nty * ntx;
+  // ---- tap tables (LDS position offsets) and packed weights, class after class ----
+  std::vector<int> tapoff;
+  std::vector<float> pk;
+  std::vector<ConvClass> cls(ncls);
+  double flops = 0;
+  for (int ic = 0; ic < ncls; ++ic) {
+    const DimTaps &Z = *classes[ic].z, &Y = *classes[ic].y, &X = *classes[ic].x;
+    const int ntz = (int)Z.t.size(), nty = (int)Y.t.size(), ntx = (int)X.t.size(), ntaps = classes[ic].ntaps;
     const int NU = cdiv(ntaps, TPC);
-    int exz = 0, exy = 0, exx = 0;
-    for (int o : Z.off) exz = std::max(exz, o + 1);
-    for (int o : Y.off) exy = std::max(exy, o + 1);
-    for (int o : X.off) exx = std::max(exx, o + 1);
-
-    // ---- tile plan: 4*PT position tiles arranged TZ x TY x TXT; prefer <= 80 KB LDS (2 workgroups/CU) ----
-    static const int cand16[][3] = {{1, 1, 16}, {1, 2, 8}, {1, 4, 4}, {1, 8, 2}, {1, 16, 1}, {2, 1, 8}, {2, 2, 4},
-                                    {2, 4, 2}, {2, 8, 1}, {4, 1, 4}, {4, 2, 2}, {4, 4, 1}, {8, 1, 2}, {8, 2, 1}, {16, 1, 1}};
-    static const int cand4[][3] = {{1, 1, 4}, {1, 2, 2}, {1, 4, 1}, {2, 1, 2}, {2, 2, 1}, {4, 1, 1}};
-    double best = 1e300;
-    int TZ = 0, TY = 0, TXT = 0, TZI = 0, TYI = 0, TXI = 0, PT = 0;
-    struct Try { int pt; size_t limit; };
-    for (const Try &tr : {Try{4, size_t(80) * 1024}, Try{1, size_t(80) * 1024}, Try{4, kConvMaxLds}, Try{1, kConvMaxLds}}) {
-      const int (*cand)[3] = tr.pt == 4 ? cand16 : cand4;
-      const int ncand = tr.pt == 4 ? 15 : 6;
-      for (int ci = 0; ci < ncand; ++ci) {
-        const int *c = cand[ci];
-        const int tzi = (c[0] - 1) * Z.s + exz, tyi = (c[1] - 1) * Y.s + exy, txi = (c[2] * 16 - 1) * X.s + exx;
-        const size_t bytes = (size_t)tzi * tyi * txi * CIS * 4;
-        if (bytes > tr.limit) continue;
-        const double tiles = (double)cdiv(Z.npos, c[0]) * cdiv(Y.npos, c[1]) * cdiv(X.npos, c[2] * 16);
-        const double cost = tiles * ((double)NU * npass * CT * tr.pt * 4 * 32.0 + (double)tzi * tyi * txi * (CI / 4) * npass / 256.0 * 160.0);
-        if (cost < best) { best = cost; TZ = c[0]; TY = c[1]; TXT = c[2]; TZI = tzi; TYI = tyi; TXI = txi; PT = tr.pt; }
-      }
-      if (TZ) break;
-    }
-    if (!TZ) fail(DR_ERR_ARG, "plan_conv: no tile shape fits LDS");
-
-    // ---- tap table (LDS position offsets) and packed weights ----
-    std::vector<int> tapoff((size_t)NU * TPC, 0);
+    cls[ic].NU = NU; cls[ic].tap_base = (int)tapoff.size(); cls[ic].w_base = (int)(pk.size() / 4);
+    cls[ic].ooz = Z.oo; cls[ic].ooy = Y.oo; cls[ic].oox = X.oo;
     std::vector<int> tz(ntaps), ty(ntaps), tx(ntaps);
+    const size_t t0 = tapoff.size();
+    tapoff.resize(t0 + (size_t)NU * TPC, 0);
     {
       int n = 0;
       for (int iz = 0; iz < ntz; ++iz) for (int iy = 0; iy < nty; ++iy) for (int ix = 0; ix < ntx; ++ix, ++n) {
-        tapoff[n] = (Z.off[iz] * TYI + Y.off[iy]) * TXI + X.off[ix];
+        tapoff[t0 + n] = (Z.off[iz] * TYI + Y.off[iy]) * TXI + X.off[ix];
         tz[n] = Z.t[iz]; ty[n] = Y.t[iy]; tx[n] = X.t[ix];
       }
     }
-    std::vector<float> pk((size_t)npass * NU * CT * 64 * 4, 0.f);
-    for (int p = 0; p < npass; ++p) for (int u = 0; u < NU; ++u) for (int ct = 0; ct < CT; ++ct)
+    const size_t w0 = pk.size();
+    pk.resize(w0 + (size_t)npass * NU * CTtot * 64 * 4, 0.f);
+    for (int p = 0; p < npass; ++p) for (int u = 0; u < NU; ++u) for (int ct = 0; ct < CTtot; ++ct)
       for (int l = 0; l < 64; ++l) for (int s = 0; s < 4; ++s) {
         const int g = l >> 4, i = l & 15, k16 = 4 * g + s;
         const int tap = u * TPC + k16 / CI, cin = p * CI + k16 % CI, row = ct * 16 + i;
@@ -329,30 +410,35 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
             if (kx >= 0 && kx < L.kw) v = weight_at(co, cin, tz[tap], ty[tap], kx);
           }
         }
-        pk[((((size_t)p * NU + u) * CT + ct) * 64 + l) * 4 + s] = v;
+        pk[w0 + ((((size_t)p * NU + u) * CTtot + ct) * 64 + l) * 4 + s] = v;
       }
-
-    ConvLaunch cl{};
-    ConvArgs &a = cl.args;
-    a.in = in; a.out = out; a.wpk = reinterpret_cast<const float4 *>(arena.upload(pk));
-    a.scale = d_scale; a.bias = d_bias; a.add = add; a.tapoff = arena.upload(tapoff);
-    a.inD = inD; a.inH = inH; a.inW = inW; a.inC = inC;
-    a.outD = R.outD; a.outH = R.outH; a.outW = outWv; a.outC = outCv;
-    a.nPD = Z.npos; a.nPH = Y.npos; a.nPW = X.npos;
-    a.sz = Z.s; a.sy = Y.s; a.sx = X.s; a.pz = Z.p; a.py = Y.p; a.px = X.p;
-    a.omz = Z.om; a.omy = Y.om; a.omx = X.om; a.ooz = Z.oo; a.ooy = Y.oo; a.oox = X.oo;
-    a.TZ = TZ; a.TY = TY; a.TXT = TXT; a.TZI = TZI; a.TYI = TYI; a.TXI = TXI;
-    a.NU = NU; a.npass = npass; a.rows_valid = rows_valid; a.relu = L.relu ? 1 : 0;
-    a.add_mode = add ? add_mode : 0;
-    a.addH = R.outH / 2; a.addW = (mode == CONV_NORMAL ? R.outW : outWv) / 2;
-    a.tilesD = cdiv(Z.npos, TZ); a.tilesH = cdiv(Y.npos, TY); a.tilesW = cdiv(X.npos, TXT * 16);
-    cl.ci = CI; cl.ct = CT; cl.pt = PT;
-    cl.grid = a.tilesD * a.tilesH * a.tilesW;
-    cl.lds_bytes = (size_t)TZI * TYI * TXI * CIS * 4;
-    cl.flops = 2.0 * Z.npos * Y.npos * X.npos * (mode == CONV_NORMAL ? 1 : shifts) * (double)ntz * nty *
-               (mode == CONV_NORMAL ? ntx : L.kw) * L.Cin * L.Cout;
-    R.launches.push_back(cl);
+    flops += 2.0 * nPD * nPH * nPW * (mode == CONV_NORMAL ? 1 : shifts) * (double)ntz * nty * (mode == CONV_NORMAL ? ntx : L.kw) * L.Cin * L.Cout;
   }
+
+  ConvLaunch cl{};
+  ConvArgs &a = cl.args;
+  a.in = in; a.out = out; a.wpk = reinterpret_cast<const float4 *>(arena.upload(pk));
+  a.scale = arena.upload(sc); a.bias = arena.upload(bi); a.add = add; a.tapoff = arena.upload(tapoff);
+  a.cls = arena.upload(cls);
+  a.inD = inD; a.inH = inH; a.inW = inW; a.inC = inC;
+  a.outD = R.outD; a.outH = R.outH; a.outW = outWv; a.outC = outCv;
+  a.nPD = nPD; a.nPH = nPH; a.nPW = nPW;
+  a.sz = SZ; a.sy = SY; a.sx = SX; a.pz = PZ; a.py = PY; a.px = PX;
+  a.omz = cz[0].om; a.omy = cy[0].om; a.omx = cx[0].om;
+  a.TZ = TZ; a.TY = TY; a.TXT = TXT; a.TZI = TZI; a.TYI = TYI; a.TXI = TXI;
+  a.magicX = (unsigned)((0x100000000ull + TXI - 1) / TXI); a.magicY = (unsigned)((0x100000000ull + TYI - 1) / TYI);
+  if ((size_t)TZI * TYI * TXI >= 65536) fail(DR_ERR_ARG, "plan_conv: halo tile too large");
+  a.npass = npass; a.ctTot = CTtot; a.rows_valid = rows_valid; a.relu = L.relu ? 1 : 0;
+  a.add_mode = add ? add_mode : 0;
+  a.addH = R.outH / 2; a.addW = (mode == CONV_NORMAL ? R.outW : outWv) / 2;
+  a.tilesD = cdiv(nPD, TZ); a.tilesH = cdiv(nPH, TY); a.tilesW = cdiv(nPW, TXT * 16);
+  cl.ci = CI; cl.ct = CT; cl.pt = PT;
+  cl.grid = dim3(a.tilesD * a.tilesH * a.tilesW, ncls, CTtot / CT);
+  int nu_max = 0;
+  for (auto &c : cls) nu_max = std::max(nu_max, c.NU);
+  cl.lds_bytes = (size_t)TZI * TYI * TXI * CIS * 4 + (size_t)nu_max * TPC * 4;
+  cl.flops = flops;
+  R.launches.push_back(cl);
   return R;
 }
 
@@ -364,7 +450,7 @@ inline void launch_conv_inst(const ConvLaunch &c, hipStream_t st) {
                                (int)kConvMaxLds));
     big = true;
   }
-  hipLaunchKernelGGL((k_conv<CI, CT, PT>), dim3(c.grid), dim3(kConvThreads), c.lds_bytes, st, c.args);
+  hipLaunchKernelGGL((k_conv<CI, CT, PT>), c.grid, dim3(kConvThreads), c.lds_bytes, st, c.args);
 }
 
 inline void launch_conv(const ConvLaunch &c, hipStream_t st) {
@@ -377,6 +463,7 @@ inline void launch_conv(const ConvLaunch &c, hipStream_t st) {
   DR_CONV_CASE(4, 1)
   DR_CONV_CASE(8, 1)
   DR_CONV_CASE(8, 2)
+  DR_CONV_CASE(8, 4)
   DR_CONV_CASE(16, 1)
   DR_CONV_CASE(16, 2)
   DR_CONV_CASE(16, 4)

@@ -103,7 +103,10 @@ struct DevTensor {
 };
 
 struct Op {
-  enum Kind { PREPROCESS, CONV, COSTVOL, REGRESS, EDGE, HIST, SCAN, APPLY } kind;
+  enum Kind { PREPROCESS, CONV, PROB, COSTVOL, REGRESS, EDGE, HIST, SCAN, APPLY } kind;
+  const float *p0 = nullptr, *p1 = nullptr;
+  float *p2 = nullptr;
+  int d0 = 0, d1 = 0, d2 = 0;
   std::string name;
   ConvLaunch conv;
   int stage = 0, shift = 0, bits = 0;
@@ -231,6 +234,7 @@ class MvsEngine {
       char kn[64] = "misc";
       if (o.kind == Op::CONV) snprintf(kn, sizeof kn, "k_conv<%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt);
       else if (o.kind == Op::COSTVOL) snprintf(kn, sizeof kn, "k_costvol<%d>", 32 >> (o.stage - 1));
+      else if (o.kind == Op::PROB) snprintf(kn, sizeof kn, "k_prob");
       else if (o.kind == Op::REGRESS) snprintf(kn, sizeof kn, "k_regress");
       else if (o.kind == Op::PREPROCESS) snprintf(kn, sizeof kn, "k_preprocess");
       else snprintf(kn, sizeof kn, "k_filter");
@@ -419,7 +423,16 @@ class MvsEngine {
       DevTensor &x7 = dbr3(pre + "conv7", cr + "conv7", k6, four ? 1 : 2, k4);
       DevTensor &x9 = dbr3(pre + "conv9", cr + "conv9", x7, 2, k2);
       DevTensor &x11 = dbr3(pre + "conv11", cr + "conv11", x9, 2, c0);
-      add_conv(pre + "prob", cr + "prob", "", false, false, x11, "logits" + S, 3, 3, 3, 1, 1, 1, false, CONV_X8, nullptr, 0);
+      {
+        const HostTensor &pw = blob_.at(cr + "prob.weight");  // (1,8,3,3,3) -> [tap][cin]
+        std::vector<float> wt(27 * 8);
+        for (int ci = 0; ci < 8; ++ci) for (int t = 0; t < 27; ++t) wt[t * 8 + ci] = pw.data[ci * 27 + t];
+        DevTensor &lg = alloc("logits" + S, D, h, w, 1);
+        Op o; o.kind = Op::PROB; o.stage = s; o.name = pre + "prob";
+        o.p0 = x11.d; o.p1 = plan_arena_->upload(wt); o.p2 = lg.d; o.d0 = D; o.d1 = h; o.d2 = w;
+        o.flops = 2.0 * 216 * D * h * w; o.bytes = 4.0 * (x11.n() + lg.n());
+        ops_.push_back(o);
+      }
       alloc("depth" + S, 1, h, w, 1);
       alloc("conf" + S, 1, h, w, 1);
       { Op o; o.kind = Op::REGRESS; o.stage = s; o.name = pre + "regress"; o.bytes = 4.0 * ((double)D * h * w + 2.0 * h * w); o.flops = 8.0 * D * h * w; ops_.push_back(o); }
@@ -532,6 +545,9 @@ class MvsEngine {
           break;
         }
         case Op::CONV: launch_conv(o.conv, stream_); break;
+        case Op::PROB:
+          hipLaunchKernelGGL(k_prob, dim3(cdiv(o.d0 * o.d1 * (o.d2 / 4), 256)), dim3(256), 0, stream_, o.p0, o.p1, o.p2, o.d0, o.d1, o.d2);
+          break;
         case Op::COSTVOL: {
           const CostVolArgs &a = cv_[o.stage - 1];
           const int C = 32 >> (o.stage - 1), pxb = 256 / (C / 4);

@@ -158,6 +158,46 @@ __global__ __launch_bounds__(256) void k_costvol(const CostVolArgs a) {
   }
 }
 
+// ------------------------------------------------------------------ prob conv (Cout = 1)
+// CostRegNet.prob = Conv3d(8, 1, 3, padding=1, bias=False) (module.py:575): 216 MACs per voxel and a single output
+// channel -- no matrix shape to speak of, so it runs on the vector pipe: one lane = 4 consecutive x outputs,
+// weights are wave-uniform (scalar loads), inputs are float4 channels-last reads served by L1.
+__global__ __launch_bounds__(256) void k_prob(const float *__restrict__ x, const float *__restrict__ wt /*[27][8]*/,
+                                              float *__restrict__ out, int D, int h, int w) {
+  const int wq = w >> 2;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= D * h * wq) return;
+  const int xq = n % wq, t = n / wq;
+  const int y = t % h, d = t / h, x0 = xq * 4;
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+  for (int kd = 0; kd < 3; ++kd) {
+    const int zz = d + kd - 1;
+    if (zz < 0 || zz >= D) continue;
+    for (int kh = 0; kh < 3; ++kh) {
+      const int yy = y + kh - 1;
+      if (yy < 0 || yy >= h) continue;
+      const float *row = x + ((size_t)zz * h + yy) * w * 8;
+      float4 lo[6], hi[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int xx = x0 - 1 + i;
+        if (xx >= 0 && xx < w) { lo[i] = ld4(row + (size_t)xx * 8); hi[i] = ld4(row + (size_t)xx * 8 + 4); }
+        else { lo[i] = make_float4(0.f, 0.f, 0.f, 0.f); hi[i] = lo[i]; }
+      }
+      const float *wk = wt + (kd * 3 + kh) * 3 * 8;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const float w0 = wk[kw * 8], w1 = wk[kw * 8 + 1], w2 = wk[kw * 8 + 2], w3 = wk[kw * 8 + 3];
+        const float w4 = wk[kw * 8 + 4], w5 = wk[kw * 8 + 5], w6 = wk[kw * 8 + 6], w7 = wk[kw * 8 + 7];
+#define DR_DOT8(A, I) A += lo[I].x * w0 + lo[I].y * w1 + lo[I].z * w2 + lo[I].w * w3 + hi[I].x * w4 + hi[I].y * w5 + hi[I].z * w6 + hi[I].w * w7
+        DR_DOT8(acc0, kw); DR_DOT8(acc1, kw + 1); DR_DOT8(acc2, kw + 2); DR_DOT8(acc3, kw + 3);
+#undef DR_DOT8
+      }
+    }
+  }
+  *reinterpret_cast<float4 *>(out + ((size_t)d * h + y) * w + x0) = make_float4(acc0, acc1, acc2, acc3);
+}
+
 // ------------------------------------------------------------------ regression
 struct RegressArgs {
   const float *logits;  // (D,h,w)
