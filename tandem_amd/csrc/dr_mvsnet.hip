@@ -480,7 +480,7 @@ class MvsEngine {
       a.feat = T("feat" + std::to_string(s)).d;
       a.vol = T("volume" + std::to_string(s)).d;
       a.V = V; a.h = h; a.w = w;
-      a.dchunk = s == 3 ? D : (D >= 16 ? D / 4 : D);
+      a.dchunk = s == 1 ? 4 : (D >= 16 ? 8 : D);  // enough workgroups to fill 256 CUs at every stage
       a.view_aggregation = blob_.view_aggregation;
       a.nsrc_f = (float)(V - 1);
       PlaneArgs &p = a.planes;
@@ -546,11 +546,15 @@ class MvsEngine {
         }
         case Op::CONV: launch_conv(o.conv, stream_); break;
         case Op::PROB:
-          hipLaunchKernelGGL(k_prob, dim3(cdiv(o.d0 * o.d1 * (o.d2 / 4), 256)), dim3(256), 0, stream_, o.p0, o.p1, o.p2, o.d0, o.d1, o.d2);
+        {
+          const int zchunk = o.d0 >= 32 ? 8 : (o.d0 >= 8 ? 4 : o.d0);
+          hipLaunchKernelGGL(k_prob, dim3(cdiv(o.d1 * (o.d2 / 4), 256), cdiv(o.d0, zchunk)), dim3(256), 0, stream_, o.p0, o.p1, o.p2,
+                             o.d0, o.d1, o.d2, zchunk);
+        }
           break;
         case Op::COSTVOL: {
           const CostVolArgs &a = cv_[o.stage - 1];
-          const int C = 32 >> (o.stage - 1), pxb = 256 / (C / 4);
+          const int C = 32 >> (o.stage - 1), pxb = 256 / (C >= 16 ? C / 8 : C / 4);
           dim3 grid(cdiv(a.w, pxb), a.h, cdiv(a.planes.D, a.dchunk));
           if (C == 32) hipLaunchKernelGGL(k_costvol<32>, grid, dim3(256), 0, stream_, a);
           else if (C == 16) hipLaunchKernelGGL(k_costvol<16>, grid, dim3(256), 0, stream_, a);

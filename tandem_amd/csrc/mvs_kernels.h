@@ -81,19 +81,30 @@ struct CostVolArgs {
 
 __device__ inline float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
+// One lane owns CPL = 8 channels (4 when C == 8... see LPV) of one pixel and walks the depth planes of its chunk.
+// Per (plane, view): 3 FMAs + one v_rcp (1 ulp; the reference divides, the coordinate differs by <1e-4 px) give the
+// source position; taps are fetched branch-free (clamped address, zeroed weight == grid_sample's zero padding).
 template <int C>
 __global__ __launch_bounds__(256) void k_costvol(const CostVolArgs a) {
-  constexpr int LPV = C / 4;        // lanes per pixel (each owns 4 channels)
-  constexpr int PXB = 256 / LPV;    // pixels per block
+  constexpr int CPL = C >= 16 ? 8 : 4;  // channels per lane
+  constexpr int NV = CPL / 4;           // float4 per lane
+  constexpr int LPV = C / CPL;          // lanes per pixel
+  constexpr int PXB = 256 / LPV;        // pixels per block
   const int tid = threadIdx.x, q = tid % LPV;
   const int x = blockIdx.x * PXB + tid / LPV, y = blockIdx.y;
   const int d0 = blockIdx.z * a.dchunk, d1 = min(a.planes.D, d0 + a.dchunk);
   const bool live = x < a.w;
   const int xc = live ? x : a.w - 1;  // keep dead lanes running for the cross-lane gate sum
   const int h = a.h, w = a.w, nsrc = a.V - 1;
-  const size_t plane = (size_t)h * w * C;
+  const unsigned plane = (unsigned)h * w * C;  // floats per view (< 2^31 bytes for every supported size)
+  const float wm1 = (float)(w - 1), hm1 = (float)(h - 1);
 
-  const float4 ref = ld4(a.feat + ((size_t)y * w + xc) * C + q * 4);
+  float4 ref[NV], gw[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    ref[i] = ld4(a.feat + ((size_t)y * w + xc) * C + q * CPL + 4 * i);
+    gw[i] = make_float4(a.gw[q * CPL + 4 * i], a.gw[q * CPL + 4 * i + 1], a.gw[q * CPL + 4 * i + 2], a.gw[q * CPL + 4 * i + 3]);
+  }
   const PixelPlanes pp = make_planes(a.planes, y, xc);
   float rx[kMaxSrc], ry[kMaxSrc], rz[kMaxSrc];
 #pragma unroll
@@ -105,56 +116,75 @@ __global__ __launch_bounds__(256) void k_costvol(const CostVolArgs a) {
       rz[v] = m[8] * (float)xc + m[9] * (float)y + m[10];
     }
   }
-  const float4 gw = make_float4(a.gw[q * 4], a.gw[q * 4 + 1], a.gw[q * 4 + 2], a.gw[q * 4 + 3]);
+  const float inv_n = a.view_aggregation ? a.nsrc_f : a.nsrc_f + 1.f;
 
   for (int d = d0; d < d1; ++d) {
     const float depth = pp.at(a.planes, d);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 s1 = ref, s2 = make_float4(ref.x * ref.x, ref.y * ref.y, ref.z * ref.z, ref.w * ref.w);
+    float4 acc[NV], s1[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      acc[i] = a.view_aggregation ? make_float4(0.f, 0.f, 0.f, 0.f)
+                                  : make_float4(ref[i].x * ref[i].x, ref[i].y * ref[i].y, ref[i].z * ref[i].z, ref[i].w * ref[i].w);
+      s1[i] = ref[i];
+    }
 #pragma unroll
     for (int v = 0; v < kMaxSrc; ++v) {
       if (v >= nsrc) break;
       const float *m = a.M[v];
       const float px = rx[v] * depth + m[3], py = ry[v] * depth + m[7], pz = rz[v] * depth + m[11];
-      float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pz >= 0.001f) {  // module.py:861,887: negative / tiny depth -> 0
-        const float u = px / pz, vv = py / pz;
-        if (u > -1.f && u < (float)w && vv > -1.f && vv < (float)h) {  // else all four taps are padding zeros
-          const float fx0 = floorf(u), fy0 = floorf(vv);
-          const int x0 = (int)fx0, y0 = (int)fy0;
-          const float ax = u - fx0, ay = vv - fy0;
-          const float *f = a.feat + (size_t)(v + 1) * plane + q * 4;
-          const bool xl = x0 >= 0, xr = x0 + 1 < w, yt = y0 >= 0, yb = y0 + 1 < h;
-          const float w00 = (1.f - ax) * (1.f - ay), w01 = ax * (1.f - ay), w10 = (1.f - ax) * ay, w11 = ax * ay;
-          if (xl && yt) { const float4 t = ld4(f + ((size_t)y0 * w + x0) * C); wv.x += t.x * w00; wv.y += t.y * w00; wv.z += t.z * w00; wv.w += t.w * w00; }
-          if (xr && yt) { const float4 t = ld4(f + ((size_t)y0 * w + x0 + 1) * C); wv.x += t.x * w01; wv.y += t.y * w01; wv.z += t.z * w01; wv.w += t.w * w01; }
-          if (xl && yb) { const float4 t = ld4(f + ((size_t)(y0 + 1) * w + x0) * C); wv.x += t.x * w10; wv.y += t.y * w10; wv.z += t.z * w10; wv.w += t.w * w10; }
-          if (xr && yb) { const float4 t = ld4(f + ((size_t)(y0 + 1) * w + x0 + 1) * C); wv.x += t.x * w11; wv.y += t.y * w11; wv.z += t.z * w11; wv.w += t.w * w11; }
+      const float rcp = __builtin_amdgcn_rcpf(pz);
+      const float u = px * rcp, vv = py * rcp;
+      // module.py:861,887 (z < 1e-3 -> 0) and grid_sample zero padding; NaN coordinates fail `inside` too
+      const bool inside = pz >= 0.001f && u > -1.f && u < (float)w && vv > -1.f && vv < (float)h;
+      const float uc = inside ? u : 0.f, vc = inside ? vv : 0.f;
+      const float fx0 = floorf(uc), fy0 = floorf(vc);
+      const float ax = uc - fx0, ay = vc - fy0;
+      const bool xl = fx0 >= 0.f, xr = fx0 < wm1, yt = fy0 >= 0.f, yb = fy0 < hm1;
+      const float bx = 1.f - ax, by = 1.f - ay;
+      const float w00 = (inside && xl && yt) ? bx * by : 0.f, w01 = (inside && xr && yt) ? ax * by : 0.f;
+      const float w10 = (inside && xl && yb) ? bx * ay : 0.f, w11 = (inside && xr && yb) ? ax * ay : 0.f;
+      const int x0 = max((int)fx0, 0), y0 = max((int)fy0, 0);
+      const int x1 = min((int)fx0 + 1, w - 1), y1 = min((int)fy0 + 1, h - 1);
+      const float *f = a.feat + (size_t)(v + 1) * plane + q * CPL;
+      const unsigned o00 = ((unsigned)y0 * w + x0) * C, o01 = ((unsigned)y0 * w + x1) * C;
+      const unsigned o10 = ((unsigned)y1 * w + x0) * C, o11 = ((unsigned)y1 * w + x1) * C;
+      float s = 0.f;
+      float4 d2[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const float4 t00 = ld4(f + o00 + 4 * i), t01 = ld4(f + o01 + 4 * i), t10 = ld4(f + o10 + 4 * i), t11 = ld4(f + o11 + 4 * i);
+        float4 wv;
+        wv.x = t00.x * w00 + t01.x * w01 + t10.x * w10 + t11.x * w11;
+        wv.y = t00.y * w00 + t01.y * w01 + t10.y * w10 + t11.y * w11;
+        wv.z = t00.z * w00 + t01.z * w01 + t10.z * w10 + t11.z * w11;
+        wv.w = t00.w * w00 + t01.w * w01 + t10.w * w10 + t11.w * w11;
+        if (a.view_aggregation) {
+          const float4 df = make_float4(wv.x - ref[i].x, wv.y - ref[i].y, wv.z - ref[i].z, wv.w - ref[i].w);
+          d2[i] = make_float4(df.x * df.x, df.y * df.y, df.z * df.z, df.w * df.w);
+          s += gw[i].x * d2[i].x + gw[i].y * d2[i].y + gw[i].z * d2[i].z + gw[i].w * d2[i].w;
+        } else {  // plain variance incl. the reference view (module.py:1074-1075,1094-1096,1110)
+          s1[i].x += wv.x; s1[i].y += wv.y; s1[i].z += wv.z; s1[i].w += wv.w;
+          acc[i].x += wv.x * wv.x; acc[i].y += wv.y * wv.y; acc[i].z += wv.z * wv.z; acc[i].w += wv.w * wv.w;
         }
       }
       if (a.view_aggregation) {
-        const float4 df = make_float4(wv.x - ref.x, wv.y - ref.y, wv.z - ref.z, wv.w - ref.w);
-        const float4 d2 = make_float4(df.x * df.x, df.y * df.y, df.z * df.z, df.w * df.w);
-        float s = gw.x * d2.x + gw.y * d2.y + gw.z * d2.z + gw.w * d2.w;
 #pragma unroll
         for (int msk = 1; msk < LPV; msk <<= 1) s += __shfl_xor(s, msk);
         const float g1 = fmaxf(a.gA1 * s + a.gB1, 0.f);
         const float g = fmaxf(a.gA2 * g1 + a.gB2, 0.f) + 1.f;
-        acc.x += g * d2.x; acc.y += g * d2.y; acc.z += g * d2.z; acc.w += g * d2.w;
-      } else {  // plain variance incl. the reference view (module.py:1074-1075,1094-1096,1110)
-        s1.x += wv.x; s1.y += wv.y; s1.z += wv.z; s1.w += wv.w;
-        s2.x += wv.x * wv.x; s2.y += wv.y * wv.y; s2.z += wv.z * wv.z; s2.w += wv.w * wv.w;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { acc[i].x += g * d2[i].x; acc[i].y += g * d2[i].y; acc[i].z += g * d2[i].z; acc[i].w += g * d2[i].w; }
       }
     }
-    float4 o;
-    if (a.view_aggregation) {
-      o = make_float4(acc.x / a.nsrc_f, acc.y / a.nsrc_f, acc.z / a.nsrc_f, acc.w / a.nsrc_f);
-    } else {
-      const float V = a.nsrc_f + 1.f;
-      const float4 mu = make_float4(s1.x / V, s1.y / V, s1.z / V, s1.w / V);
-      o = make_float4(s2.x / V - mu.x * mu.x, s2.y / V - mu.y * mu.y, s2.z / V - mu.z * mu.z, s2.w / V - mu.w * mu.w);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      float4 o = make_float4(acc[i].x / inv_n, acc[i].y / inv_n, acc[i].z / inv_n, acc[i].w / inv_n);
+      if (!a.view_aggregation) {
+        const float4 mu = make_float4(s1[i].x / inv_n, s1[i].y / inv_n, s1[i].z / inv_n, s1[i].w / inv_n);
+        o = make_float4(o.x - mu.x * mu.x, o.y - mu.y * mu.y, o.z - mu.z * mu.z, o.w - mu.w * mu.w);
+      }
+      if (live) *reinterpret_cast<float4 *>(a.vol + ((size_t)d * h * w + (size_t)y * w + x) * C + q * CPL + 4 * i) = o;
     }
-    if (live) *reinterpret_cast<float4 *>(a.vol + (size_t)d * plane + ((size_t)y * w + x) * C + q * 4) = o;
   }
 }
 
@@ -162,40 +192,48 @@ __global__ __launch_bounds__(256) void k_costvol(const CostVolArgs a) {
 // CostRegNet.prob = Conv3d(8, 1, 3, padding=1, bias=False) (module.py:575): 216 MACs per voxel and a single output
 // channel -- no matrix shape to speak of, so it runs on the vector pipe: one lane = 4 consecutive x outputs,
 // weights are wave-uniform (scalar loads), inputs are float4 channels-last reads served by L1.
+// Each lane owns the column (y, x0..x0+3) of a z-chunk and MARCHES along z: one input plane (3 rows x 6 positions
+// x 8 channels) is loaded once and feeds the three output planes it touches, so L1 traffic is a third of a
+// plane-at-a-time stencil.
 __global__ __launch_bounds__(256) void k_prob(const float *__restrict__ x, const float *__restrict__ wt /*[27][8]*/,
-                                              float *__restrict__ out, int D, int h, int w) {
+                                              float *__restrict__ out, int D, int h, int w, int zchunk) {
   const int wq = w >> 2;
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= D * h * wq) return;
-  const int xq = n % wq, t = n / wq;
-  const int y = t % h, d = t / h, x0 = xq * 4;
-  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-  for (int kd = 0; kd < 3; ++kd) {
-    const int zz = d + kd - 1;
-    if (zz < 0 || zz >= D) continue;
-    for (int kh = 0; kh < 3; ++kh) {
-      const int yy = y + kh - 1;
-      if (yy < 0 || yy >= h) continue;
-      const float *row = x + ((size_t)zz * h + yy) * w * 8;
-      float4 lo[6], hi[6];
+  if (n >= h * wq) return;
+  const int xq = n % wq, y = n / wq, x0 = xq * 4;
+  const int z0 = blockIdx.y * zchunk, z1 = min(D, z0 + zchunk);
+  // acc[j][o]: output plane (zz - 1 + j) while input plane zz is being consumed
+  float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int zz = z0 - 1; zz <= z1; ++zz) {
+    if (zz >= 0 && zz < D) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const int xx = x0 - 1 + i;
-        if (xx >= 0 && xx < w) { lo[i] = ld4(row + (size_t)xx * 8); hi[i] = ld4(row + (size_t)xx * 8 + 4); }
-        else { lo[i] = make_float4(0.f, 0.f, 0.f, 0.f); hi[i] = lo[i]; }
-      }
-      const float *wk = wt + (kd * 3 + kh) * 3 * 8;
+      for (int kh = 0; kh < 3; ++kh) {
+        const int yy = y + kh - 1;
+        if (yy < 0 || yy >= h) continue;
+        const float *row = x + ((size_t)zz * h + yy) * w * 8;
+        float4 lo[6], hi[6];
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const float w0 = wk[kw * 8], w1 = wk[kw * 8 + 1], w2 = wk[kw * 8 + 2], w3 = wk[kw * 8 + 3];
-        const float w4 = wk[kw * 8 + 4], w5 = wk[kw * 8 + 5], w6 = wk[kw * 8 + 6], w7 = wk[kw * 8 + 7];
-#define DR_DOT8(A, I) A += lo[I].x * w0 + lo[I].y * w1 + lo[I].z * w2 + lo[I].w * w3 + hi[I].x * w4 + hi[I].y * w5 + hi[I].z * w6 + hi[I].w * w7
-        DR_DOT8(acc0, kw); DR_DOT8(acc1, kw + 1); DR_DOT8(acc2, kw + 2); DR_DOT8(acc3, kw + 3);
+        for (int i = 0; i < 6; ++i) {
+          const int xx = x0 - 1 + i;
+          if (xx >= 0 && xx < w) { lo[i] = ld4(row + (size_t)xx * 8); hi[i] = ld4(row + (size_t)xx * 8 + 4); }
+          else { lo[i] = make_float4(0.f, 0.f, 0.f, 0.f); hi[i] = lo[i]; }
+        }
+#define DR_DOT8(A, I, WK) A += lo[I].x * WK[0] + lo[I].y * WK[1] + lo[I].z * WK[2] + lo[I].w * WK[3] + hi[I].x * WK[4] + hi[I].y * WK[5] + hi[I].z * WK[6] + hi[I].w * WK[7]
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          // input plane zz is tap kd = 2 of output zz-1, kd = 1 of output zz, kd = 0 of output zz+1
+          const float *w2 = wt + ((2 * 3 + kh) * 3 + kw) * 8, *w1 = wt + ((1 * 3 + kh) * 3 + kw) * 8, *w0 = wt + ((0 * 3 + kh) * 3 + kw) * 8;
+#pragma unroll
+          for (int o = 0; o < 4; ++o) { DR_DOT8(a0[o], kw + o, w2); DR_DOT8(a1[o], kw + o, w1); DR_DOT8(a2[o], kw + o, w0); }
+        }
 #undef DR_DOT8
       }
     }
+    const int zo = zz - 1;  // complete once input plane zz has been consumed
+    if (zo >= z0 && zo < z1) *reinterpret_cast<float4 *>(out + ((size_t)zo * h + y) * w + x0) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) { a0[o] = a1[o]; a1[o] = a2[o]; a2[o] = 0.f; }
   }
-  *reinterpret_cast<float4 *>(out + ((size_t)d * h + y) * w + x0) = make_float4(acc0, acc1, acc2, acc3);
 }
 
 // ------------------------------------------------------------------ regression
