@@ -53,6 +53,7 @@ struct ConvArgs {
   int TZ, TY, TXT, TZI, TYI, TXI;
   int npass, ctTot, rows_valid, relu, add_mode, addH, addW;
   unsigned magicX, magicY;  // ceil(2^32 / TXI), ceil(2^32 / TYI): exact division of tile positions (< 2^16)
+  int nuMax;                // max K chunks per pass over the classes (sizes the LDS weight area)
   int tilesD, tilesH, tilesW;
 };
 
@@ -95,14 +96,16 @@ __global__ __launch_bounds__(kConvThreads) void k_conv(const ConvArgs a) {
 
   const int NP = a.TZI * a.TYI * a.TXI, NU = cls.NU;
   // tap table of this class -> LDS (pre-multiplied by the position stride) so the K loop has no dependent global load
-  int *tapl = reinterpret_cast<int *>(lds + (size_t)NP * CIS);
+  float4 *wl = lds4 + ((size_t)NP * CIS) / 4;                           // [NU][CT][64] packed weights of the current pass
+  int *tapl = reinterpret_cast<int *>(wl + (size_t)a.nuMax * CT * 64);  // [NU*TPC] tap offsets (floats)
   for (int i = tid; i < NU * TPC; i += kConvThreads) tapl[i] = a.tapoff[cls.tap_base + i] * CIS;
+  const unsigned n_w = (unsigned)NU * CT * 64;
   const int *tp = tapl + sub;
   const unsigned total = (unsigned)NP * C4;
   for (int p = 0; p < a.npass; ++p) {
     // ---- stage CI channels of the input halo tile into LDS (zero outside the tensor).  Loads are issued in
     // batches of kStageBatch per lane BEFORE the first LDS write so their HBM/L2 latencies overlap. ----
-    constexpr int kStageBatch = 4;
+    constexpr int kStageBatch = CT >= 4 ? 6 : 12;  // normally the whole stage: one exposed HBM/L2 latency per pass
     for (unsigned e0 = 0; e0 < total; e0 += kConvThreads * kStageBatch) {
       float4 v[kStageBatch];
       int dst[kStageBatch];
@@ -122,9 +125,28 @@ __global__ __launch_bounds__(kConvThreads) void k_conv(const ConvArgs a) {
       for (int k = 0; k < kStageBatch; ++k)
         if (dst[k] >= 0) *reinterpret_cast<float4 *>(lds + dst[k]) = v[k];
     }
+    {  // this pass's packed weights -> LDS, so that the K loop below touches no global memory
+      const float4 *wsrc = a.wpk + cls.w_base + ((size_t)p * NU * a.ctTot + ct0) * 64;
+      constexpr int kWB = 8;
+      for (unsigned e0 = 0; e0 < n_w; e0 += kConvThreads * kWB) {
+        float4 v[kWB];
+#pragma unroll
+        for (int k = 0; k < kWB; ++k) {
+          const unsigned e = e0 + k * kConvThreads + tid;  // = (u*CT + ct)*64 + l
+          const unsigned u = e / (CT * 64), r = e - u * (CT * 64);
+          v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (e < n_w) v[k] = wsrc[(size_t)u * a.ctTot * 64 + r];
+        }
+#pragma unroll
+        for (int k = 0; k < kWB; ++k) {
+          const unsigned e = e0 + k * kConvThreads + tid;
+          if (e < n_w) wl[e] = v[k];
+        }
+      }
+    }
     __syncthreads();
     // ---- K loop over the chunks of this channel pass, operands of chunk u+1 fetched under the MFMAs of u ----
-    const float4 *wp = a.wpk + cls.w_base + ((size_t)p * NU * a.ctTot + ct0) * 64 + lane;
+    const float4 *wp = wl + lane;
     float4 av[CT], bv[PT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) av[ct] = wp[ct * 64];
@@ -137,7 +159,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv(const ConvArgs a) {
       const int un = min(u + 1, NU - 1);
       float4 an[CT], bn[PT];
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) an[ct] = wp[((size_t)un * a.ctTot + ct) * 64];
+      for (int ct = 0; ct < CT; ++ct) an[ct] = wp[(un * CT + ct) * 64];
       const int toff = tp[un * TPC];
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) bn[pt] = *reinterpret_cast<const float4 *>(lds + base[pt] + toff);
@@ -338,19 +360,21 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
       for (int k = 0; k < ncand; ++k) {
         const int *c = cand[k];
         const int tzi = (c[0] - 1) * SZ + exz, tyi = (c[1] - 1) * SY + exy, txi = (c[2] * 16 - 1) * SX + exx;
-        const size_t bytes = (size_t)tzi * tyi * txi * (ci + 4) * 4 + 1024;  // + tap table
-        if (bytes > kConvMaxLds) continue;
+        int nu_max = 0;
+        for (auto &cc : classes) nu_max = std::max(nu_max, cdiv(cc.ntaps, tpc));
         const double tiles = (double)cdiv(nPD, c[0]) * cdiv(nPH, c[1]) * cdiv(nPW, c[2] * 16);
         for (int ct : {4, 2, 1}) {
           if (CTtot % ct || !conv_instance_exists(ci, ct)) continue;
+          const size_t bytes = (size_t)tzi * tyi * txi * (ci + 4) * 4 + (size_t)nu_max * ct * 1024 + (size_t)nu_max * tpc * 4 + 64;
+          if (bytes > kConvMaxLds) continue;
           const int split = CTtot / ct;
           // cost model (cycles): MFMA issue, staging, and a latency floor per chunk; see DESIGN.md
           const double wg_per_cu = std::max(1.0, std::min({(double)(kConvMaxLds / bytes), 8.0, (ct == 4 && pt == 4) ? 5.0 : 8.0}));
-          const double stage = npass * ((double)tzi * tyi * txi * (ci / 4) / 256.0 * 60.0 + 900.0);
+          const double stage = npass * (((double)tzi * tyi * txi * (ci / 4) + (chunks / ncls) * ct * 64.0) / 256.0 * 60.0 + 900.0);
           const double chunk_mfma = 4.0 * ct * pt * 32.0;
           const double n_wg = tiles * split;  // per class
           const double mfma_total = n_wg * npass * chunks * chunk_mfma, stage_total = n_wg * ncls * stage;
-          const double lat_wg = npass * (chunks / ncls) * std::max(chunk_mfma, 400.0) + stage;
+          const double lat_wg = npass * (chunks / ncls) * std::max(chunk_mfma, 160.0) + stage;
           const double waves = std::ceil(n_wg * ncls / (256.0 * wg_per_cu));
           const double thr = (mfma_total + stage_total) / 256.0 / (wg_per_cu >= 2 ? 0.8 : 0.5);
           const double cost = std::max(thr, waves * lat_wg);
@@ -436,7 +460,8 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   cl.grid = dim3(a.tilesD * a.tilesH * a.tilesW, ncls, CTtot / CT);
   int nu_max = 0;
   for (auto &c : cls) nu_max = std::max(nu_max, c.NU);
-  cl.lds_bytes = (size_t)TZI * TYI * TXI * CIS * 4 + (size_t)nu_max * TPC * 4;
+  a.nuMax = nu_max;
+  cl.lds_bytes = (size_t)TZI * TYI * TXI * CIS * 4 + (size_t)nu_max * CT * 1024 + (size_t)nu_max * TPC * 4 + 64;
   cl.flops = flops;
   R.launches.push_back(cl);
   return R;

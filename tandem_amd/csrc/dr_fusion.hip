@@ -20,6 +20,7 @@
 
 namespace dr {
 
+constexpr int kBS = 8;        // voxel block edge (DrFusionOptions::block_size must be 8, as TANDEM sets it)
 constexpr int kMaxDDA = 4096;  // cap on DDA steps per ray (the reference loops unboundedly)
 constexpr unsigned long long kEmptyKey = ~0ull;
 
@@ -40,6 +41,7 @@ struct FusionDev {  // everything the kernels need, passed by value
   int *n_alloc;              // allocated pool blocks
   int *err;                  // [0] pool exhausted, [1] coordinate out of packing range
   unsigned long long *cnt;   // [0] voxels updated by the current scan, [1] total, [2] round-trip mismatches
+  float *sd;                 // [H*W] per-pixel surface distance |GetPoint3d(i, depth)| of the current scan
 };
 
 // ---- CUDA float->int conversion semantics (cvt.rzi: saturate, NaN -> 0), see oracle header (4) ----
@@ -152,7 +154,7 @@ __device__ inline int floor_div(int v, int bs) { return v < 0 ? (v - bs + 1) / b
 __device__ inline int pos_mod(int v, int bs) { const int r = v % bs; return r < 0 ? r + bs : r; }
 __device__ inline void world_to_block_local(const drf_options_t &o, F3 p, I3 &blk, int &local) {
   const I3 v = world_to_global_voxel(o, p);
-  const int bs = o.block_size;
+  constexpr int bs = kBS;
   blk.x = floor_div(v.x, bs); blk.y = floor_div(v.y, bs); blk.z = floor_div(v.z, bs);
   local = pos_mod(v.x, bs) * bs * bs + pos_mod(v.y, bs) * bs + pos_mod(v.z, bs);  // voxel_block.h:37-41
 }
@@ -166,6 +168,9 @@ __global__ __launch_bounds__(256) void k_allocate(const FusionDev d, const float
   F3 start; start.x = T.m[3]; start.y = T.m[7]; start.z = T.m[11];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < size; i += gridDim.x * blockDim.x) {
     const float dep = depth[i];
+    // IntegrateScanKernel recomputes distance(0, GetPoint3d(idx, depth[idx])) for every voxel that projects to
+    // pixel idx (tsdf_volume.cu:485-486); it depends on the pixel only, so it is evaluated once here.
+    d.sd[i] = norm3(point3d(o, i, dep));
     if (dep < o.min_sensor_depth || dep > o.max_sensor_depth) continue;
     const F3 point = xform(T, point3d(o, i, dep));
     if (point.x == 0 && point.y == 0 && point.z == 0) continue;
@@ -207,27 +212,41 @@ __global__ __launch_bounds__(256) void k_allocate(const FusionDev d, const float
 }
 
 // ------------------------------------------------------------------ integration
-__device__ inline void combine(Voxel &a, const Voxel &b, unsigned char max_weight) {  // voxel.h:21-50
+// Voxel::Combine (voxel.h:21-50).  The colour channels are  uchar((c*w + vc*vw) / (w + vw))  with integer-valued
+// operands (c, vc <= 255, w <= 255, vw = 1): the quotient is either an exact integer or at least 1/(w+vw) away from
+// one, so the truncated IEEE quotient equals floor(num/den) and can be taken from a 1-ulp reciprocal with a bias of
+// half that gap -- bit-identical to the reference's division, a quarter of the instructions.
+// (IntegrateScanKernel always passes vw = 1; the general case keeps the division.)
+__device__ inline void combine(Voxel &a, const Voxel &b, unsigned char max_weight) {
   const float w = (float)a.weight, vw = (float)b.weight;
+  const float den = w + vw;
+  if (b.weight == 1) {
+    const float r = __builtin_amdgcn_rcpf(den), bias = 0.5f * r;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) a.c[k] = f2u8(((float)a.c[k] * w + (float)b.c[k] * vw) / (w + vw));
-  a.sdf = (a.sdf * w + b.sdf * vw) / (w + vw);
+    for (int k = 0; k < 3; ++k) a.c[k] = (unsigned char)(int)(((float)a.c[k] * w + (float)b.c[k]) * r + bias);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a.c[k] = f2u8(((float)a.c[k] * w + (float)b.c[k] * vw) / den);
+  }
+  a.sdf = (a.sdf * w + b.sdf * vw) / den;
   unsigned char nw = (unsigned char)(a.weight + b.weight);
   if (nw > max_weight) nw = max_weight;
   a.weight = nw;
 }
 
-// One workgroup (bs^3 = 512 lanes) walks allocated pool blocks [0, n_blocks); lane = voxel index x*64+y*8+z.
-__global__ __launch_bounds__(512) void k_integrate(const FusionDev d, const unsigned char *__restrict__ bgr,
+// One WAVE per allocated pool block (4 waves per workgroup, grid-strided): per-block work (pose transform of the
+// block origin, frustum test) is done once per wave, then 8 iterations of 64 voxels (lane = y*8+z of slab x), each
+// a coalesced 512-byte read-modify-write of the block.
+__global__ __launch_bounds__(256) void k_integrate(const FusionDev d, const unsigned char *__restrict__ bgr,
                                                    const float *__restrict__ depth, const Mat T, const Mat Ti) {
   const drf_options_t &o = d.o;
-  const int bs = o.block_size;
-  const float vs = o.voxel_size, trunc = o.truncation_distance;
-  const int li = threadIdx.x;
-  const int bx = li / (bs * bs), by = (li / bs) % bs, bz = li % bs;
+  constexpr int bs = kBS;
+  const float vs = o.voxel_size, trunc = o.truncation_distance, inv_vs = 1.0f / o.voxel_size;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int by = lane >> 3, bz = lane & 7;
   unsigned upd = 0;
   const int n_blocks = min(*d.n_alloc, o.num_blocks);  // written by k_allocate earlier on this stream
-  for (int e = blockIdx.x; e < n_blocks; e += gridDim.x) {
+  for (int e = blockIdx.x * 4 + wave; e < n_blocks; e += gridDim.x * 4) {
     const I3 P = unpack_key(d.blk_key[e]);
     F3 position; position.x = P.x * vs * bs; position.y = P.y * vs * bs; position.z = P.z * vs * bs;
     const F3 pc = xform(Ti, position);
@@ -236,53 +255,59 @@ __global__ __launch_bounds__(512) void k_integrate(const FusionDev d, const unsi
     center.x = (float)((double)pc.x + 0.5 * (double)vs * (double)bs);
     center.y = (float)((double)pc.y + 0.5 * (double)vs * (double)bs);
     center.z = (float)((double)pc.z + 0.5 * (double)vs * (double)bs);
-    int ix, iy;
-    project(o, center, ix, iy);
-    if (!(ix >= 0 && iy >= 0 && ix < o.width && iy < o.height)) continue;
-    F3 vp; vp.x = position.x + bx * vs; vp.y = position.y + by * vs; vp.z = position.z + bz * vs;
-    vp = xform(Ti, vp);
-    project(o, vp, ix, iy);
-    if (!(ix >= 0 && iy >= 0 && ix < o.width && iy < o.height)) continue;
-    const int idx = iy * o.width + ix;
-    const float dep = depth[idx];
-    if (dep <= 0) continue;
-    if (dep < o.min_sensor_depth) continue;
-    if (dep > o.max_sensor_depth) continue;
-    const float sd = norm3(point3d(o, idx, dep));
-    const float vd = norm3(vp);
-    Voxel v;
-    bool hit = false;
-    if (vd > sd - trunc && vd < sd + trunc && dep < o.max_sensor_depth) { v.sdf = sd - vd; hit = true; }
-    else if (vd < sd - trunc) { v.sdf = trunc; hit = true; }
-    if (!hit) continue;
-    v.c[0] = bgr[3 * idx]; v.c[1] = bgr[3 * idx + 1]; v.c[2] = bgr[3 * idx + 2];
-    v.weight = 1;
-    // UpdateVoxel re-derives block and voxel from the world position (tsdf_volume.cu:303-315); the
-    // round trip normally lands on this very lane's voxel -- verified, with the slow path kept literal.
-    I3 blk; int local;
-    world_to_block_local(o, xform(T, vp), blk, local);
-    int target = e;
-    if (blk.x != P.x || blk.y != P.y || blk.z != P.z || local != li) {
-      atomicAdd(&d.cnt[2], 1ull);
-      target = find_block(d, blk);
-      if (target < 0) continue;
+    int cx, cy;
+    project(o, center, cx, cy);
+    if (!(cx >= 0 && cy >= 0 && cx < o.width && cy < o.height)) continue;
+    Voxel *blk_vox = d.vox + (size_t)e * (bs * bs * bs);
+#pragma unroll 2
+    for (int bx = 0; bx < bs; ++bx) {
+      const int li = bx * (bs * bs) + lane;
+      F3 vp; vp.x = position.x + bx * vs; vp.y = position.y + by * vs; vp.z = position.z + bz * vs;
+      vp = xform(Ti, vp);
+      int ix, iy;
+      project(o, vp, ix, iy);
+      if (!(ix >= 0 && iy >= 0 && ix < o.width && iy < o.height)) continue;
+      const int idx = iy * o.width + ix;
+      const float dep = depth[idx];
+      if (dep <= 0) continue;
+      if (dep < o.min_sensor_depth) continue;
+      if (dep > o.max_sensor_depth) continue;
+      const float sd = d.sd[idx];
+      const float vd = norm3(vp);
+      Voxel v;
+      bool hit = false;
+      if (vd > sd - trunc && vd < sd + trunc && dep < o.max_sensor_depth) { v.sdf = sd - vd; hit = true; }
+      else if (vd < sd - trunc) { v.sdf = trunc; hit = true; }
+      if (!hit) continue;
+      v.c[0] = bgr[3 * idx]; v.c[1] = bgr[3 * idx + 1]; v.c[2] = bgr[3 * idx + 2];
+      v.weight = 1;
+      // UpdateVoxel re-derives block and voxel from the world position (tsdf_volume.cu:303-315):
+      //   g = trunc(wp/vs + sign(wp)*0.5) per axis, block = floor(g/8), local = g mod 8.
+      // Sufficient test without the three divisions: if |wp * (1/vs) - n| < 0.25 for this lane's own global voxel
+      // index n on every axis, then |wp/vs - n| < 0.3 and the truncation above yields exactly n (for n = 0 as well),
+      // i.e. the round trip lands on this lane's voxel.  Otherwise the literal path decides.
+      const F3 wp = xform(T, vp);
+      Voxel *dst = blk_vox + li;
+      const bool same = fabsf(wp.x * inv_vs - (float)(P.x * bs + bx)) < 0.25f && fabsf(wp.y * inv_vs - (float)(P.y * bs + by)) < 0.25f &&
+                        fabsf(wp.z * inv_vs - (float)(P.z * bs + bz)) < 0.25f;
+      if (!same) {
+        I3 blk; int local;
+        world_to_block_local(o, wp, blk, local);
+        if (blk.x != P.x || blk.y != P.y || blk.z != P.z || local != li) {
+          atomicAdd(&d.cnt[2], 1ull);
+          const int target = find_block(d, blk);
+          if (target < 0) continue;
+          dst = d.vox + (size_t)target * (bs * bs * bs) + local;
+        }
+      }
+      Voxel cur = *dst;
+      combine(cur, v, (unsigned char)o.max_sdf_weight);
+      *dst = cur;
+      ++upd;
     }
-    Voxel *dst = d.vox + (size_t)target * (bs * bs * bs) + local;
-    Voxel cur = *dst;
-    combine(cur, v, (unsigned char)o.max_sdf_weight);
-    *dst = cur;
-    ++upd;
   }
-  // workgroup reduction of the update count -> one atomic per workgroup
-  __shared__ unsigned red[8];
   for (int off = 32; off > 0; off >>= 1) upd += __shfl_down(upd, off);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = upd;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned s = 0;
-    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
-    if (s) atomicAdd(&d.cnt[0], (unsigned long long)s);
-  }
+  if (lane == 0 && upd) atomicAdd(&d.cnt[0], (unsigned long long)upd);
 }
 
 // ------------------------------------------------------------------ raycast
@@ -292,8 +317,7 @@ __device__ inline Voxel get_voxel(const FusionDev &d, F3 p) {  // tsdf_volume.cu
   world_to_block_local(d.o, p, blk, local);
   const int b = find_block(d, blk);
   if (b < 0) return z;
-  const int bs = d.o.block_size;
-  return d.vox[(size_t)b * (bs * bs * bs) + local];
+  return d.vox[(size_t)b * (kBS * kBS * kBS) + local];
 }
 
 __device__ inline Voxel get_interpolated_voxel(const FusionDev &d, F3 pos) {  // tsdf_volume.cu:161-289
@@ -406,6 +430,7 @@ class FusionEngine {
     d_.n_alloc = dalloc<int>(4);
     d_.err = d_.n_alloc + 1;
     d_.cnt = dalloc<unsigned long long>(4);
+    d_.sd = dalloc<float>(npix_);
     hipLaunchKernelGGL(k_fill_keys, dim3(1024), dim3(256), 0, int_stream_, d_.keys, cap);
     DR_HIP(hipMemsetAsync(d_.vox, 0, (size_t)o.num_blocks * 512 * sizeof(Voxel), int_stream_));  // hash_table.cu:28-32
     DR_HIP(hipMemsetAsync(d_.n_alloc, 0, 16, int_stream_));
@@ -414,7 +439,7 @@ class FusionEngine {
     d_depth_in_ = dalloc<float>(npix_);
     DR_HIP(hipHostMalloc((void **)&h_bgr_in_, npix_ * 3, hipHostMallocDefault));
     DR_HIP(hipHostMalloc((void **)&h_depth_in_, npix_ * 4, hipHostMallocDefault));
-    integrate_grid_ = std::min(o.num_blocks, 8192);
+    integrate_grid_ = std::min(cdiv(o.num_blocks, 4), 8192);
     DR_HIP(hipEventCreateWithFlags(&int_done_, hipEventDisableTiming));
     for (int i = 0; i < o.num_render_streams; ++i) {
       Render r;
@@ -434,7 +459,7 @@ class FusionEngine {
     (void)hipSetDevice(device_);
     (void)hipDeviceSynchronize();
     (void)hipFree(d_.keys); (void)hipFree(d_.vals); (void)hipFree(d_.blk_key); (void)hipFree(d_.vox);
-    (void)hipFree(d_.n_alloc); (void)hipFree(d_.cnt); (void)hipFree(d_bgr_in_); (void)hipFree(d_depth_in_);
+    (void)hipFree(d_.n_alloc); (void)hipFree(d_.cnt); (void)hipFree(d_.sd); (void)hipFree(d_bgr_in_); (void)hipFree(d_depth_in_);
     (void)hipHostFree(h_bgr_in_); (void)hipHostFree(h_depth_in_);
     for (auto &r : renders_) {
       (void)hipFree(r.d_bgr); (void)hipFree(r.d_depth);
@@ -560,7 +585,7 @@ class FusionEngine {
     inverse4_host(T.m, Ti.m);
     hipLaunchKernelGGL(k_allocate, dim3(cdiv((int)npix_, 256)), dim3(256), 0, int_stream_, d_, d_depth, T);
     if (kernel_events_[0]) DR_HIP(hipEventRecord(kernel_events_[0], int_stream_));
-    hipLaunchKernelGGL(k_integrate, dim3(integrate_grid_), dim3(512), 0, int_stream_, d_, d_bgr, d_depth, T, Ti);
+    hipLaunchKernelGGL(k_integrate, dim3(integrate_grid_), dim3(256), 0, int_stream_, d_, d_bgr, d_depth, T, Ti);
     if (kernel_events_[1]) DR_HIP(hipEventRecord(kernel_events_[1], int_stream_));
     hipLaunchKernelGGL(k_fold_counter, dim3(1), dim3(1), 0, int_stream_, d_.cnt);
     DR_HIP(hipGetLastError());
