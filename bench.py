@@ -24,6 +24,20 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r*_pmc_traffic.json, written by
+    tools/gpu_pmc_traffic.sh + tools/pmc_to_json.py on the same workload; counters cannot be read from inside this
+    process).  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950; returns None if no profile exists."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    e = json.load(open(files[-1])).get(kernel)
+    if not e or "fetch_bytes_corrected" not in e or "write_bytes" not in e:
+        return None
+    return e["fetch_bytes_corrected"] + e["write_bytes"]
+
+
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA (== fp32 vector) peak
 PEAK_HBM_GBPS = 8000.0          # HBM3E spec peak (6.3 TB/s measured achievable)
 H, W, V = 480, 640, 7
@@ -62,7 +76,7 @@ def mvsnet_leg(args, rank, dev, world):
         res["roofline"] = dict(bound="mfma", kernel=name, launches_per_step=dom["n"],
                                avg_launch_ms=dom["ms"] / dom["n"], flops_per_launch=dom["flops"] / dom["n"],
                                achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_FP32_MFMA_TFLOPS,
-                               traffic=None)
+                               traffic=pmc_traffic(name))
         step_s = res["ms_per_step"] * 1e-3
         res["pipeline"] = dict(gflop_per_depth_map=flops / 1e9, gb_per_depth_map=nbytes / 1e9,
                                tflops=flops / step_s / 1e12, frac_mfma=flops / step_s / 1e12 / PEAK_FP32_MFMA_TFLOPS,
@@ -128,7 +142,7 @@ def tsdf_leg(args, rank, dev, world):
         n = len(bgrs)
         ach = 16.0 * vox / (kms * 1e-3) / 1e9
         res["roofline"] = dict(bound="hbm", kernel="k_integrate", avg_launch_ms=kms / n, bytes_per_launch=16.0 * vox / n,
-                               achieved=ach, peak=PEAK_HBM_GBPS, unit="GB/s", frac=ach / PEAK_HBM_GBPS, traffic=None)
+                               achieved=ach, peak=PEAK_HBM_GBPS, unit="GB/s", frac=ach / PEAK_HBM_GBPS, traffic=pmc_traffic("k_integrate"))
         # raycast (DrFusion::RenderAsync) of the fused map, one 640x480 view
         f.IntegrateScanAsync(*sc["scans"][0])
         t0 = time.perf_counter(); f.RenderAsync([poses[0]]); f.GetRenderResult(); t1 = time.perf_counter()

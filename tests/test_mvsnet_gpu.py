@@ -142,3 +142,54 @@ def test_edge_filter_is_exact_given_the_same_depth(trained_blob):
         assert np.array_equal(out.depth, filt.numpy())
         assert np.array_equal(out.depth == 0, mask.numpy() | (out.depth_dense == 0))
     m.close()
+
+
+def test_plain_variance_model_without_view_aggregation(tmp_path):
+    """abl01/abl02 models: no gate, variance over all views incl. the reference (module.py:1074-1075,1094-1096,1110)."""
+    from oracle import mvsnet_oracle as O, scene
+    from tandem_amd import weights as Wt
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    tens = Wt.random_state((48, 32, 8), seed=11)
+    blob = str(tmp_path / "nova.tdmw")
+    Wt.write_blob(blob, tens, depth_num=(48, 32, 8), view_aggregation=False)
+    meta, back = Wt.read_blob(blob)
+    assert meta["view_aggregation"] is False
+    win = scene.make_window(64, 96, 4, seed=8)
+    ref = O.forward(O.Weights(meta, back), win["bgrs"], win["K"], win["c2ws"], win["ref_index"], 0.5, 5.0, 5.0)
+    m = DrMvsnet(blob)
+    m.CallAsync(64, 96, 4, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), 0.5, 5.0, 5.0)
+    compare(m.GetResult(), ref, "no-VA")
+    m.close()
+
+
+def test_resolution_and_view_count_can_change_between_calls(trained_blob):
+    """The engine re-plans when TANDEM changes the window shape (dr_mvsnet.cpp builds tensors per call)."""
+    from oracle import mvsnet_oracle as O, scene
+    from tandem_amd import weights as Wt
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    meta, tens = Wt.read_blob(trained_blob)
+    w = O.Weights(meta, tens)
+    m = DrMvsnet(trained_blob)
+    for (H, W, V) in ((64, 96, 3), (96, 64, 5), (64, 96, 3), (128, 128, 2)):
+        win = scene.make_window(H, W, V, seed=H + V)
+        m.CallAsync(H, W, V, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), 0.5, 5.0, 2.5)
+        out = m.GetResult()
+        ref = O.forward(w, win["bgrs"], win["K"], win["c2ws"], win["ref_index"], 0.5, 5.0, 2.5)
+        compare(out, ref, f"{H}x{W}x{V}")
+    m.close()
+
+
+def test_ref_index_and_view_order(trained_blob):
+    """Model order is [ref, others in window order] (dr_mvsnet.cpp:190-197): permuting the window consistently with
+    ref_index must not change the result when the source order is preserved."""
+    from oracle import scene
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    win = scene.make_window(64, 96, 4, seed=6)  # ref_index = 2
+    m = DrMvsnet(trained_blob)
+    m.CallAsync(64, 96, 4, 2, win["bgrs"], win["K"], list(win["c2ws"]), 0.5, 5.0, 2.5)
+    a = m.GetResult()
+    order = [2, 0, 1, 3]  # same model order, reference now first
+    m.CallAsync(64, 96, 4, 0, [win["bgrs"][i] for i in order], win["K"], [win["c2ws"][i] for i in order], 0.5, 5.0, 2.5)
+    b = m.GetResult()
+    assert np.array_equal(a.depth_dense, b.depth_dense) and np.array_equal(a.depth, b.depth)
+    m.close()
