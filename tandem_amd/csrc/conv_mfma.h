@@ -52,6 +52,7 @@ struct ConvArgs {
   int omz, omy, omx;
   int TZ, TY, TXT, TZI, TYI, TXI;
   int npass, ctTot, rows_valid, relu, add_mode, addH, addW;
+  int par_rows, par_map;    // transposed layers: rows per output parity (= Cout) and 3 bits (z,y,x) per parity; 0 otherwise
   unsigned magicX, magicY;  // ceil(2^32 / TXI), ceil(2^32 / TYI): exact division of tile positions (< 2^16)
   int nuMax;                // max K chunks per pass over the classes (sizes the LDS weight area)
   int tilesD, tilesH, tilesW;
@@ -203,14 +204,19 @@ __global__ __launch_bounds__(kConvThreads) void k_conv(const ConvArgs a) {
     const int xt = tau % a.TXT, yt = (tau / a.TXT) % a.TY, zt = tau / (a.TXT * a.TY);
     const int qz = pz0 + zt, qy = py0 + yt, qx = px0 + xt * 16 + j;
     if (qz >= a.nPD || qy >= a.nPH || qx >= a.nPW) continue;
-    const int oz = qz * a.omz + cls.ooz, oy = qy * a.omy + cls.ooy, ox = qx * a.omx + cls.oox;
-    const size_t obase = (((size_t)oz * a.outH + oy) * a.outW + ox) * a.outC;
-    size_t abase = obase;
-    if (a.add_mode == 2) abase = (((size_t)oz * a.addH + (oy >> 1)) * a.addW + (ox >> 1)) * a.outC;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       const int c0 = (ct0 + ct) * 16 + 4 * g;
       if (c0 >= a.rows_valid) continue;
+      int oz = qz * a.omz + cls.ooz, oy = qy * a.omy + cls.ooy, ox = qx * a.omx + cls.oox, ch = c0;
+      if (a.par_rows) {  // transposed layer: this lane's 4 rows are 4 channels of output parity q
+        const int q = c0 / a.par_rows, bits = (a.par_map >> (3 * q)) & 7;
+        ch = c0 - q * a.par_rows;
+        oz += (bits >> 2) & 1; oy += (bits >> 1) & 1; ox += bits & 1;
+      }
+      const size_t obase = (((size_t)oz * a.outH + oy) * a.outW + ox) * a.outC + ch;
+      size_t abase = obase;
+      if (a.add_mode == 2) abase = (((size_t)oz * a.addH + (oy >> 1)) * a.addW + (ox >> 1)) * a.outC + ch;
       const float4 sc = *reinterpret_cast<const float4 *>(a.scale + c0);
       const float4 bi = *reinterpret_cast<const float4 *>(a.bias + c0);
       float4 v;
@@ -222,10 +228,10 @@ __global__ __launch_bounds__(kConvThreads) void k_conv(const ConvArgs a) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       }
       if (a.add_mode) {
-        const float4 r = *reinterpret_cast<const float4 *>(a.add + abase + c0);
+        const float4 r = *reinterpret_cast<const float4 *>(a.add + abase);
         v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
       }
-      *reinterpret_cast<float4 *>(a.out + obase + c0) = v;
+      *reinterpret_cast<float4 *>(a.out + obase) = v;
     }
   }
 }
@@ -258,8 +264,15 @@ struct DimTaps {               // per-axis decomposition of one parity class
   int s = 1, p = 0, om = 1, oo = 0, npos = 0;
 };
 
-// Per-axis tap lists.  Normal conv: in = pos*s - pad + t.  Transposed stride 2 (parity class c):
-// out[2m] = x[m] w[1];  out[2m+1] = x[m] w[2] + x[m+1] w[0].  Transposed stride 1: out[o] = sum_t x[o+1-t] w[t].
+// Per-axis tap lists.  Normal conv: in = pos*s - pad + t.  Transposed stride 1: out[o] = sum_t x[o+1-t] w[t].
+// Transposed stride 2 (k=3, pad=1, output_padding=1):  out[2m] = x[m] w[1];  out[2m+1] = x[m] w[2] + x[m+1] w[0].
+// All 2^d output parities of a position m read the same 2^d input neighbourhood, so the layer runs as ONE stride-1
+// convolution with a 2-wide kernel per strided axis and npar*Cout output rows (row = parity*Cout + channel, zero
+// weight where a parity does not use an offset); the epilogue scatters row groups to out[2m + parity].
+inline int parity_kernel_index(int parity, int off) {  // -1: this (parity, offset) pair carries no weight
+  if (parity == 0) return off == 0 ? 1 : -1;
+  return off == 0 ? 2 : 0;
+}
 inline std::vector<DimTaps> axis_classes(int k, int s, bool transposed, int in_size) {
   std::vector<DimTaps> r;
   if (!transposed) {
@@ -275,8 +288,9 @@ inline std::vector<DimTaps> axis_classes(int k, int s, bool transposed, int in_s
     d.p = 1; d.npos = in_size;
     r.push_back(d);
   } else {
-    DimTaps e; e.t = {1}; e.off = {0}; e.om = 2; e.oo = 0; e.npos = in_size; r.push_back(e);
-    DimTaps o; o.t = {2, 0}; o.off = {0, 1}; o.om = 2; o.oo = 1; o.npos = in_size; r.push_back(o);
+    // dense parity form: input offsets {0,1}; which kernel index a (parity, offset) pair selects is resolved when the
+    // weights are packed (parity_kernel_index), the two parities of this axis become separate output ROWS
+    DimTaps d; d.t = {0, 1}; d.off = {0, 1}; d.om = 2; d.oo = 0; d.npos = in_size; r.push_back(d);
   }
   return r;
 }
@@ -322,6 +336,19 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   } else {
     rows = cdiv(L.Cout, 16) * 16; rows_valid = L.Cout; outCv = L.Cout;
     if (L.Cout % 4) fail(DR_ERR_ARG, "plan_conv: Cout=%d must be a multiple of 4", L.Cout);
+  }
+  // transposed: parity bits of the strided axes, enumerated (z, y, x) -> par_map holds 3 bits (z<<2|y<<1|x) per parity
+  int npar = 1, par_map = 0;
+  const bool strided[3] = {L.transposed && L.sd == 2, L.transposed && L.sh == 2, L.transposed && L.sw == 2};
+  if (L.transposed) {
+    if (mode != CONV_NORMAL) fail(DR_ERR_ARG, "plan_conv: transposed layers use CONV_NORMAL");
+    for (int d = 0; d < 3; ++d) if (strided[d]) npar *= 2;
+    for (int q = 0; q < npar; ++q) {
+      int bits = 0, rem = q;
+      for (int d = 2; d >= 0; --d) if (strided[d]) { bits |= (rem & 1) << (2 - d); rem >>= 1; }
+      par_map |= bits << (3 * q);
+    }
+    rows_valid = npar * L.Cout; rows = cdiv(rows_valid, 16) * 16;
   }
   const int CTtot = rows / 16;
   const int shifts = mode == CONV_XPAIR ? 2 : (mode == CONV_X8 ? 8 : 1);
@@ -389,7 +416,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   // per-row epilogue affine
   std::vector<float> sc(rows, 1.f), bi(rows, 0.f);
   for (int r = 0; r < rows_valid; ++r) {
-    const int c = mode == CONV_NORMAL ? r : (mode == CONV_XPAIR ? (r & 7) : 0);
+    const int c = L.transposed ? r % L.Cout : (mode == CONV_NORMAL ? r : (mode == CONV_XPAIR ? (r & 7) : 0));
     if (!L.scale.empty()) sc[r] = L.scale[c];
     if (!L.bias.empty()) bi[r] = L.bias[c];
   }
@@ -427,7 +454,18 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
         const int tap = u * TPC + k16 / CI, cin = p * CI + k16 % CI, row = ct * 16 + i;
         float v = 0.f;
         if (tap < ntaps && row < rows_valid) {
-          if (mode == CONV_NORMAL) v = weight_at(row, cin, tz[tap], ty[tap], tx[tap]);
+          if (L.transposed) {
+            const int q = row / L.Cout, co = row % L.Cout, bits = (par_map >> (3 * q)) & 7;
+            const int offs[3] = {tz[tap], ty[tap], tx[tap]};  // for transposed layers DimTaps::t carries the input offset
+            int kk[3];
+            bool ok = true;
+            for (int d = 0; d < 3; ++d) {
+              if (strided[d]) kk[d] = parity_kernel_index((bits >> (2 - d)) & 1, offs[d]);
+              else kk[d] = offs[d];  // stride-1 axis: DimTaps::t is the kernel index already (k == 1 or the 3-tap flip)
+              ok = ok && kk[d] >= 0;
+            }
+            if (ok) v = weight_at(co, cin, kk[0], kk[1], kk[2]);
+          } else if (mode == CONV_NORMAL) v = weight_at(row, cin, tz[tap], ty[tap], tx[tap]);
           else {
             const int shift = mode == CONV_XPAIR ? (row >> 3) : row, co = mode == CONV_XPAIR ? (row & 7) : 0;
             const int kx = tx[tap] - shift;
@@ -436,7 +474,8 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
         }
         pk[w0 + ((((size_t)p * NU + u) * CTtot + ct) * 64 + l) * 4 + s] = v;
       }
-    flops += 2.0 * nPD * nPH * nPW * (mode == CONV_NORMAL ? 1 : shifts) * (double)ntz * nty * (mode == CONV_NORMAL ? ntx : L.kw) * L.Cin * L.Cout;
+    if (L.transposed) flops += 2.0 * nPD * nPH * nPW * (double)L.kd * L.kh * L.kw * L.Cin * L.Cout;
+    else flops += 2.0 * nPD * nPH * nPW * (mode == CONV_NORMAL ? 1 : shifts) * (double)ntz * nty * (mode == CONV_NORMAL ? ntx : L.kw) * L.Cin * L.Cout;
   }
 
   ConvLaunch cl{};
@@ -449,6 +488,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   a.nPD = nPD; a.nPH = nPH; a.nPW = nPW;
   a.sz = SZ; a.sy = SY; a.sx = SX; a.pz = PZ; a.py = PY; a.px = PX;
   a.omz = cz[0].om; a.omy = cy[0].om; a.omx = cx[0].om;
+  a.par_rows = L.transposed ? L.Cout : 0; a.par_map = par_map;
   a.TZ = TZ; a.TY = TY; a.TXT = TXT; a.TZI = TZI; a.TYI = TYI; a.TXI = TXI;
   a.magicX = (unsigned)((0x100000000ull + TXI - 1) / TXI); a.magicY = (unsigned)((0x100000000ull + TYI - 1) / TYI);
   if ((size_t)TZI * TYI * TXI >= 65536) fail(DR_ERR_ARG, "plan_conv: halo tile too large");
