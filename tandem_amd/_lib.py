@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdr_mi355x.so")
+# DR_MI355X_LIB: load another build of the same C ABI (used for within-box A/B timing of kernel variants)
+LIB_PATH = os.environ.get("DR_MI355X_LIB") or os.path.join(_HERE, "libdr_mi355x.so")
 
 DR_OK = 0
 ERR_NAMES = {1: "DR_ERR_ARG", 2: "DR_ERR_PROTOCOL", 3: "DR_ERR_DEVICE", 4: "DR_ERR_IO", 5: "DR_ERR_CAPACITY",
