@@ -11,12 +11,12 @@ all: $(LIB) oracle/libtsdf_oracle.so
 
 $(CSRC)/dr_mvsnet.o: $(CSRC)/dr_mvsnet.hip $(CSRC)/conv_mfma.h $(CSRC)/mvs_kernels.h $(CSRC)/dr_common.h include/dr_mi355x.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-$(CSRC)/dr_fusion.o: $(CSRC)/dr_fusion.hip $(CSRC)/dr_common.h include/dr_mi355x.h
+$(CSRC)/dr_fusion.o: $(CSRC)/dr_fusion.hip $(CSRC)/mesh_kernels.h $(CSRC)/mc_tables.h $(CSRC)/dr_common.h include/dr_mi355x.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@ -lpthread
 
-oracle/libtsdf_oracle.so: oracle/tsdf_oracle.c
+oracle/libtsdf_oracle.so: oracle/tsdf_oracle.c tandem_amd/csrc/mc_tables.h
 	gcc -O2 -std=c99 -fPIC -shared -ffp-contract=off -fno-fast-math $< -o $@ -lm
 
 clean:

@@ -123,10 +123,20 @@ int drf_render_async(drf_t *h, const float *const *poses16, int n);
 /* DrFusion::GetRenderResult(bgr, depth)                          dr_fusion.h:54, tsdf_volume.cu:702-737
  * Fills n library-owned pinned pointers, valid until the next drf_get_render_result. */
 int drf_get_render_result(drf_t *h, uint8_t **bgr, float **depth, int n);
-/* DrFusion::ExtractMeshAsync / GetMeshSync / SaveMeshToFile / GetMesh   dr_fusion.h:56-62
- * Marching cubes is a SURVEY 8(f) "next" row: round 1 returns DR_ERR_UNSUPPORTED. */
+/* DrFusion::ExtractMeshAsync(lower, upper)                        dr_fusion.h:60, tsdf_volume.cu:759-779,
+ * marching_cubes/mesh_extractor.cu:136-281.  Marching cubes over the lattice lower + g * voxel_size; legal where
+ * IntegrateScanAsync is (after GetRenderResult); at most one extraction may be pending. */
 int drf_extract_mesh_async(drf_t *h, const float lower[3], const float upper[3]);
+/* DrFusion::GetMeshSync()                                         dr_fusion.h:61, tsdf_volume.cu:781-838
+ * Waits for the pending extraction and copies it out: vert / cols hold num_max vertices (3 floats each);
+ * *num = 3 * triangles; vert[9t + 3k + 0..2] = position of vertex k of triangle t, cols[...] = its colour as RGB in
+ * [0, 1].  DR_ERR_CAPACITY if 3 * triangles > num_max (the mesh stays pending) or above 20 M triangles. */
 int drf_get_mesh_sync(drf_t *h, size_t num_max, size_t *num, float *vert, float *cols);
+/* Size of the pending mesh (waits for it, does not consume it) -- lets a binding allocate exactly; no reference
+ * counterpart (the reference preallocates 2 x 720 MB, dr_fusion.cpp:36-37). */
+int drf_mesh_num_triangles(drf_t *h, size_t *ntri);
+/* DrFusion::SaveMeshToFile(filename, lower, upper)                dr_fusion.h:56, dr_fusion.cpp:74-93, mesh.cu:24-66
+ * Synchronous extraction written as Wavefront OBJ: "v x y z r g b" per vertex, "f i i+1 i+2" per triangle. */
 int drf_save_mesh(drf_t *h, const char *filename, const float lower[3], const float upper[3]);
 /* DrFusion::Synchronize()                                        dr_fusion.h:64 */
 int drf_synchronize(drf_t *h);

@@ -11,6 +11,7 @@
  *   AllocateFromDepthKernel         tsdfvh/tsdf_volume.cu:317-434
  *   IntegrateScanKernel             tsdfvh/tsdf_volume.cu:436-513
  *   GenerateRgbDepthKernel          tsdfvh/tsdf_volume.cu:600-632
+ *   ExtractMeshKernel & helpers     marching_cubes/mesh_extractor.cu:24-265, GetMeshSync tsdf_volume.cu:781-838
  *   GetPoint3d / Project / norm ... utils/utils.h:44-108
  *   float4x4 * float3, getInverse   utils/matrix_utils.h:914-922, :958-1083
  *
@@ -25,7 +26,9 @@
  *       aliases every free one onto block (0,0,0), tsdf_volume.cu:451-455 -- a defect we do not inherit);
  *   (4) float->int conversions follow CUDA's cvt.rzi (saturating, NaN -> 0), since the reference
  *       runs on CUDA and uses out-of-range conversions in Project();
- *   (5) DDA walks are capped at ORACLE_MAX_DDA steps (the reference loops forever on overshoot).
+ *   (5) DDA walks are capped at ORACLE_MAX_DDA steps (the reference loops forever on overshoot);
+ *   (6) a mesh is a SET of triangles: the reference appends with atomicAdd (mesh.cu:19-22), so its order is
+ *       arbitrary; this restatement emits in lattice order and tests compare sorted triangle lists.
  * All arithmetic is fp32 in the reference's expression order; build with -ffp-contract=off.
  */
 #include <float.h>
@@ -34,6 +37,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+
+#include "../tandem_amd/csrc/mc_tables.h" /* Paul Bourke's public-domain triangle table, shared constants */
 
 #define ORACLE_MAX_DDA 4096
 
@@ -397,4 +402,92 @@ int tsdf_export_blocks(const tsdf_t *t, int max_blocks, int *coords, unsigned ch
   for (int i = 0; i < n; ++i) { coords[3 * i] = t->coord[i].x; coords[3 * i + 1] = t->coord[i].y; coords[3 * i + 2] = t->coord[i].z; }
   memcpy(voxels, t->vox, (size_t)n * nvox(t) * sizeof(voxel_t));
   return n;
+}
+
+/* ---------------------------------------------------------------- marching cubes
+ * TrilinearInterpolation, mesh_extractor.cu:24-103: distance only (the interpolated colour is computed by the
+ * reference but never used by ExtractMeshAtPosition); false as soon as one of the 8 voxels is unobserved. */
+static int mc_trilinear(const tsdf_t *t, f3 position, float *distance) {
+  float vs = t->o.voxel_size;
+  f3 half = {vs / 2.0f, vs / 2.0f, vs / 2.0f};
+  f3 pd = sub3(position, half);
+  f3 vp = {position.x / vs, position.y / vs, position.z / vs};
+  f3 w = {vp.x - floorf(vp.x), vp.y - floorf(vp.y), vp.z - floorf(vp.z)};
+  static const int corner[8][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 0}, {0, 1, 1}, {1, 0, 1}, {1, 1, 1}};
+  float d = 0.0f;
+  for (int k = 0; k < 8; ++k) {
+    f3 off = {corner[k][0] ? vs : 0.0f, corner[k][1] ? vs : 0.0f, corner[k][2] ? vs : 0.0f};
+    voxel_t v = get_voxel(t, add3(pd, off));
+    if (v.weight == 0) return 0;
+    float a = corner[k][0] ? w.x : (1.0f - w.x);
+    float b = corner[k][1] ? w.y : (1.0f - w.y);
+    float c = corner[k][2] ? w.z : (1.0f - w.z);
+    d += a * b * c * v.sdf;
+  }
+  *distance = d;
+  return 1;
+}
+
+/* VertexInterpolation, mesh_extractor.cu:105-134, with c1 == c2 == colour of the cell's centre voxel (as the caller
+ * passes it) and isolevel 0: out[0..2] = position, out[3..5] = colour / 255 in the voxel's (BGR) channel order. */
+static void mc_vertex(f3 p1, f3 p2, float d1, float d2, const unsigned char *c, float *out) {
+  const float iso = 0.0f;
+  f3 p;
+  if (fabsf(iso - d1) < 0.00001f) p = p1;
+  else if (fabsf(iso - d2) < 0.00001f) p = p2;
+  else if (fabsf(d1 - d2) < 0.00001f) p = p1;
+  else {
+    float mu = (iso - d1) / (d2 - d1);
+    p.x = p1.x + mu * (p2.x - p1.x);
+    p.y = p1.y + mu * (p2.y - p1.y);
+    p.z = p1.z + mu * (p2.z - p1.z);
+  }
+  out[0] = p.x; out[1] = p.y; out[2] = p.z;
+  out[3] = (float)c[0] / 255.f; out[4] = (float)c[1] / 255.f; out[5] = (float)c[2] / 255.f;
+}
+
+/* ExtractMeshKernel + ExtractMeshAtPosition (mesh_extractor.cu:136-265) over the dense lattice, then the
+ * GetMeshSync layout (tsdf_volume.cu:800-832): vert[9*t + 3*k + 0..2] = position of vertex k of triangle t,
+ * cols[9*t + 3*k + 0..2] = (colour.z, colour.y, colour.x) -- i.e. RGB from the BGR voxel.  Returns the number of
+ * triangles found; at most max_tri are written. */
+long tsdf_extract_mesh(const tsdf_t *t, const float *lower, const float *upper, long max_tri, float *vert, float *cols) {
+  float vs = t->o.voxel_size;
+  f3 size = {fabsf(lower[0] - upper[0]), fabsf(lower[1] - upper[1]), fabsf(lower[2] - upper[2])};
+  int nx = f2i(size.x / vs), ny = f2i(size.y / vs), nz = f2i(size.z / vs);
+  const float P = vs / 2.0f, M = -P;
+  /* cube corners in Bourke order v0..v7 = p010 p110 p100 p000 p011 p111 p101 p001 (mesh_extractor.cu:192-199) */
+  static const int cs[8][3] = {{0, 1, 0}, {1, 1, 0}, {1, 0, 0}, {0, 0, 0}, {0, 1, 1}, {1, 1, 1}, {1, 0, 1}, {0, 0, 1}};
+  long ntri = 0;
+  for (int gz = 0; gz < nz; ++gz) for (int gy = 0; gy < ny; ++gy) for (int gx = 0; gx < nx; ++gx) {
+    f3 pos = {(float)gx * vs + lower[0], (float)gy * vs + lower[1], (float)gz * vs + lower[2]};
+    f3 p[8];
+    float d[8];
+    int ok = 1;
+    for (int k = 0; k < 8 && ok; ++k) {
+      f3 off = {cs[k][0] ? P : M, cs[k][1] ? P : M, cs[k][2] ? P : M};
+      p[k] = add3(pos, off);
+      ok = mc_trilinear(t, p[k], &d[k]);
+    }
+    if (!ok) continue;
+    unsigned cube = 0;
+    for (int k = 0; k < 8; ++k) if (d[k] < 0.0f) cube |= 1u << k;
+    if (cube == 0 || cube == 255) continue; /* edgeTable[cube] == 0 */
+    voxel_t v = get_voxel(t, pos);
+    unsigned long long row = kMcTri[cube];
+    for (int i = 0; i < 15 && ((row >> (4 * i)) & 15) != 15; i += 3) {
+      if (ntri < max_tri) {
+        for (int k = 0; k < 3; ++k) {
+          int e = (int)((row >> (4 * (i + k))) & 15);
+          int a = kMcEdgeCorner[e][0], b = kMcEdgeCorner[e][1];
+          float o6[6];
+          mc_vertex(p[a], p[b], d[a], d[b], v.c, o6);
+          float *vv = vert + 9 * ntri + 3 * k, *cc = cols + 9 * ntri + 3 * k;
+          vv[0] = o6[0]; vv[1] = o6[1]; vv[2] = o6[2];
+          cc[0] = o6[5]; cc[1] = o6[4]; cc[2] = o6[3];
+        }
+      }
+      ++ntri;
+    }
+  }
+  return ntri;
 }

@@ -21,7 +21,8 @@ class Options(C.Structure):
 
 def build():
     src = os.path.join(_HERE, "tsdf_oracle.c")
-    if not os.path.isfile(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    tab = os.path.join(_HERE, "..", "tandem_amd", "csrc", "mc_tables.h")
+    if not os.path.isfile(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(src), os.path.getmtime(tab)):
         subprocess.check_call(["gcc", "-O2", "-std=c99", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
                                src, "-o", _SO, "-lm"])
     return _SO
@@ -43,6 +44,8 @@ def lib():
         L.tsdf_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
         L.tsdf_export_blocks.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.tsdf_inverse4.argtypes = [C.c_void_p, C.c_void_p]
+        L.tsdf_extract_mesh.restype = C.c_long
+        L.tsdf_extract_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -81,3 +84,13 @@ class TsdfOracle:
         vox = np.empty((max(n, 1), 4096), np.uint8)
         got = lib().tsdf_export_blocks(self._h, n, coords.ctypes.data, vox.ctypes.data)
         return {tuple(int(v) for v in coords[i]): vox[i] for i in range(got)}
+
+    def extract_mesh(self, lower, upper, max_tri=2_000_000):
+        """(vert, cols): float32 arrays of shape (3 * ntri, 3) in the GetMeshSync layout (cols are RGB in [0, 1])."""
+        lo = np.ascontiguousarray(lower, np.float32)
+        up = np.ascontiguousarray(upper, np.float32)
+        vert, cols = np.empty((max_tri * 3, 3), np.float32), np.empty((max_tri * 3, 3), np.float32)
+        n = lib().tsdf_extract_mesh(self._h, lo.ctypes.data, up.ctypes.data, max_tri, vert.ctypes.data, cols.ctypes.data)
+        if n > max_tri:
+            raise RuntimeError("oracle mesh has %d triangles > max_tri=%d" % (n, max_tri))
+        return vert[:3 * n].copy(), cols[:3 * n].copy()

@@ -61,6 +61,7 @@ SIGNATURES = {
     "drf_get_render_result": (C.c_int, [vp, C.POINTER(u8p), C.POINTER(f32p), C.c_int]),
     "drf_extract_mesh_async": (C.c_int, [vp, f32p, f32p]),
     "drf_get_mesh_sync": (C.c_int, [vp, C.c_size_t, C.POINTER(C.c_size_t), f32p, f32p]),
+    "drf_mesh_num_triangles": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
     "drf_save_mesh": (C.c_int, [vp, C.c_char_p, f32p, f32p]),
     "drf_synchronize": (C.c_int, [vp]),
     "drf_stats": (C.c_int, [vp, C.POINTER(C.c_uint64)]),

@@ -8,15 +8,23 @@
 //                                                           ALLOCATED block, one voxel per lane, coalesced 4 KB)
 //   GenerateRgbDepthKernel  tsdfvh/tsdf_volume.cu:600-632 -> k_raycast    (one lane per pixel, sphere tracing)
 //   TsdfVolume::{IntegrateScanAsync,RenderAsync,GetRenderResult}  tsdf_volume.cu:515-737 -> FusionEngine
+//   MeshExtractor / ExtractMeshAsync / GetMeshSync  marching_cubes/mesh_extractor.cu, tsdf_volume.cu:739-838
+//                                                         -> mesh_kernels.h (per allocated block, LDS neighbourhood)
 //
 // Semantics follow the canonical form fixed by the CPU oracle (oracle/tsdf_oracle.c header): the voxel
 // state keyed by block coordinate is bit-identical; hash slots and pool indices are implementation detail.
 // fp32 arithmetic is written in the reference's expression order and compiled with -ffp-contract=off;
 // divisions and square roots are IEEE-correct (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
 #include <cfloat>
+#include <cstdio>
+#include <cstring>
 #include <memory>
 
+#include <rocprim/rocprim.hpp>  // device radix sort (block keys) and exclusive scan (triangle offsets) of the mesh path
+
 #include "dr_common.h"
+#define DR_MC_CONST __device__ static const
+#include "mc_tables.h"
 
 namespace dr {
 
@@ -379,6 +387,10 @@ __global__ void k_fill_keys(unsigned long long *keys, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) keys[i] = kEmptyKey;
 }
 
+}  // namespace dr
+#include "mesh_kernels.h"
+namespace dr {
+
 // cofactor inverse on the host in the reference's term order (matrix_utils.h:958-1083), fp32, no contraction
 static void inverse4_host(const float *e, float *out) {
   float inv[16];
@@ -468,6 +480,9 @@ class FusionEngine {
     }
     (void)hipEventDestroy(int_done_);
     (void)hipStreamDestroy(int_stream_);
+    (void)hipFree(mesh_axis_); (void)hipFree(mesh_keys_); (void)hipFree(mesh_total_); (void)hipFree(mesh_counts_);
+    (void)hipFree(mesh_offsets_); (void)hipFree(mesh_tmp_); (void)hipFree(mesh_vert_); (void)hipFree(mesh_cols_);
+    if (mesh_done_) (void)hipEventDestroy(mesh_done_);
   }
 
   // tsdf_volume.cu:515-598
@@ -545,6 +560,48 @@ class FusionEngine {
     DR_HIP(hipMemcpy(voxels, d_.vox, (size_t)na * 4096, hipMemcpyDeviceToHost));
     if (n) *n = na;
   }
+  // ---- marching cubes: TsdfVolume::ExtractMeshAsync / GetMeshSync (tsdf_volume.cu:759-838) ----
+  void extract_mesh_async(const float *lower, const float *upper) {
+    if (!lower || !upper) fail(DR_ERR_ARG, "ExtractMeshAsync: null argument");
+    expect(kIntegrate, "Please call this functions after GetRenderResult.");
+    if (mesh_pending_) fail(DR_ERR_PROTOCOL, "mesh_extractor should be NULL (fetch the previous mesh with GetMeshSync first)");
+    launch_mesh(lower, upper);
+    mesh_pending_ = true;
+  }
+  size_t mesh_num_triangles() {  // blocks until the pending extraction is done; does not consume it
+    if (!mesh_pending_) fail(DR_ERR_PROTOCOL, "mesh_extractor should not be NULL (did you call ExtractMeshAsync before)?");
+    return finish_mesh();
+  }
+  // vert / cols hold num_max vertices (3 floats each).  The reference compares num_max with the TRIANGLE count
+  // (tsdf_volume.cu:796) and would overrun for meshes above num_max / 3 triangles; here the vertex count is checked.
+  void get_mesh_sync(size_t num_max, size_t *num, float *vert, float *cols) {
+    expect(kIntegrate, "Please call this functions after GetRenderResult.");
+    if (!num || !vert || !cols) fail(DR_ERR_ARG, "GetMeshSync: null argument");
+    const size_t ntri = mesh_num_triangles();
+    if (num_max < 3 * ntri) fail(DR_ERR_CAPACITY, "Did not provide enough storage for mesh (%zu vertices > %zu).", 3 * ntri, num_max);
+    DR_HIP(hipMemcpy(vert, mesh_vert_, ntri * 36, hipMemcpyDeviceToHost));
+    DR_HIP(hipMemcpy(cols, mesh_cols_, ntri * 36, hipMemcpyDeviceToHost));
+    *num = 3 * ntri;  // 1 triangle = 3 vert (tsdf_volume.cu:800)
+    mesh_pending_ = false;
+  }
+  // DrFusion::SaveMeshToFile (dr_fusion.cpp:74-93): synchronous extraction, then Mesh::SaveToFile(filename, bgr=true)
+  // (mesh.cu:24-66): one "v x y z r g b" line per vertex, one "f i i+1 i+2" line per triangle.
+  void save_mesh(const char *filename, const float *lower, const float *upper) {
+    if (!filename || !lower || !upper) fail(DR_ERR_ARG, "SaveMeshToFile: null argument");
+    if (mesh_pending_) fail(DR_ERR_PROTOCOL, "SaveMeshToFile: an ExtractMeshAsync is pending, call GetMeshSync first");
+    launch_mesh(lower, upper);
+    const size_t ntri = finish_mesh();
+    std::vector<float> v(ntri * 9), c(ntri * 9);
+    DR_HIP(hipMemcpy(v.data(), mesh_vert_, ntri * 36, hipMemcpyDeviceToHost));
+    DR_HIP(hipMemcpy(c.data(), mesh_cols_, ntri * 36, hipMemcpyDeviceToHost));
+    FILE *f = fopen(filename, "w");
+    if (!f) fail(DR_ERR_IO, "SaveMeshToFile: cannot open %s", filename);
+    for (size_t i = 0; i < ntri * 3; ++i)
+      fprintf(f, "v %g %g %g %g %g %g\n", v[3 * i], v[3 * i + 1], v[3 * i + 2], c[3 * i], c[3 * i + 1], c[3 * i + 2]);
+    for (size_t i = 1; i <= ntri * 3; i += 3) fprintf(f, "f %zu %zu %zu\n", i, i + 1, i + 2);
+    if (fclose(f) != 0) fail(DR_ERR_IO, "SaveMeshToFile: write to %s failed", filename);
+  }
+
   // bench path: inputs already resident in HBM
   void integrate_device(const void *d_bgr, const void *d_depth, const float *pose16) {
     DR_HIP(hipSetDevice(device_));
@@ -590,6 +647,82 @@ class FusionEngine {
     hipLaunchKernelGGL(k_fold_counter, dim3(1), dim3(1), 0, int_stream_, d_.cnt);
     DR_HIP(hipGetLastError());
   }
+  static int f2i_host(float f) {  // make_int3(float...) on CUDA: cvt.rzi (saturating, NaN -> 0)
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return -2147483647 - 1;
+    return (int)f;
+  }
+  // Enqueue the whole extraction on int_stream_ (after the last integration, before the next one).
+  void launch_mesh(const float *lower, const float *upper) {
+    DR_HIP(hipSetDevice(device_));
+    DR_HIP(hipStreamSynchronize(int_stream_));  // the block count lives on the device
+    int na = 0;
+    DR_HIP(hipMemcpy(&na, d_.n_alloc, 4, hipMemcpyDeviceToHost));
+    const int nblk = std::min(na, o_.num_blocks);
+    const float vs = o_.voxel_size;
+    int n[3];
+    size_t ntab = 0;
+    for (int a = 0; a < 3; ++a) {  // ExtractMeshKernel, mesh_extractor.cu:241-245
+      n[a] = f2i_host(fabsf(lower[a] - upper[a]) / vs);
+      if (n[a] > (1 << 22)) fail(DR_ERR_ARG, "ExtractMesh: %d lattice cells along axis %d (box too large for voxel_size %g)", n[a], a, vs);
+      ntab += (size_t)std::max(n[a], 0);
+    }
+    if (!mesh_total_) mesh_total_ = dalloc<unsigned long long>(1);
+    if (nblk <= 0 || n[0] <= 0 || n[1] <= 0 || n[2] <= 0) {
+      DR_HIP(hipMemsetAsync(mesh_total_, 0, 8, int_stream_));
+      DR_HIP(hipEventRecord(mesh_done_ev(), int_stream_));
+      return;
+    }
+    if (ntab > mesh_axis_cap_) {
+      if (mesh_axis_) DR_HIP(hipFree(mesh_axis_));
+      mesh_axis_ = dalloc<McAxis>(ntab);
+      mesh_axis_cap_ = ntab;
+    }
+    if (!mesh_keys_) {
+      mesh_keys_ = dalloc<unsigned long long>(o_.num_blocks);
+      mesh_counts_ = dalloc<unsigned>(o_.num_blocks);
+      mesh_offsets_ = dalloc<unsigned>(o_.num_blocks);
+      size_t t1 = 0, t2 = 0;
+      DR_HIP(rocprim::radix_sort_keys(nullptr, t1, d_.blk_key, mesh_keys_, (size_t)o_.num_blocks, 0, 63, int_stream_));
+      DR_HIP(rocprim::exclusive_scan(nullptr, t2, mesh_counts_, mesh_offsets_, 0u, (size_t)o_.num_blocks, rocprim::plus<unsigned>(), int_stream_));
+      mesh_tmp_bytes_ = std::max(t1, t2);
+      mesh_tmp_ = dalloc<unsigned char>(mesh_tmp_bytes_);
+      // the reference's MeshExtractor::Init(20000000, ...) (tsdf_volume.cu:776): 72 B per triangle, 1.44 GB of HBM
+      mesh_vert_ = dalloc<float>((size_t)kMeshMaxTriangles * 9);
+      mesh_cols_ = dalloc<float>((size_t)kMeshMaxTriangles * 9);
+    }
+    McArgs a{};
+    McAxis *p = mesh_axis_;
+    for (int k = 0; k < 3; ++k) {
+      hipLaunchKernelGGL(k_mc_axes, dim3(cdiv(n[k], 256)), dim3(256), 0, int_stream_, p, n[k], lower[k], vs);
+      a.ax[k] = p; a.n[k] = n[k];
+      p += n[k];
+    }
+    size_t tb = mesh_tmp_bytes_;
+    DR_HIP(rocprim::radix_sort_keys(mesh_tmp_, tb, d_.blk_key, mesh_keys_, (size_t)nblk, 0, 63, int_stream_));
+    a.sorted_keys = mesh_keys_; a.nblk = nblk; a.counts = mesh_counts_; a.offsets = mesh_offsets_;
+    a.vert = mesh_vert_; a.cols = mesh_cols_; a.cap_tri = kMeshMaxTriangles;
+    hipLaunchKernelGGL((k_mc_cells<false>), dim3(nblk), dim3(256), 0, int_stream_, d_, a);
+    tb = mesh_tmp_bytes_;
+    DR_HIP(rocprim::exclusive_scan(mesh_tmp_, tb, mesh_counts_, mesh_offsets_, 0u, (size_t)nblk, rocprim::plus<unsigned>(), int_stream_));
+    hipLaunchKernelGGL((k_mc_cells<true>), dim3(nblk), dim3(256), 0, int_stream_, d_, a);
+    hipLaunchKernelGGL(k_mc_total, dim3(1), dim3(1), 0, int_stream_, mesh_counts_, mesh_offsets_, nblk, mesh_total_);
+    DR_HIP(hipGetLastError());
+    DR_HIP(hipEventRecord(mesh_done_ev(), int_stream_));
+  }
+  hipEvent_t mesh_done_ev() {
+    if (!mesh_done_) DR_HIP(hipEventCreateWithFlags(&mesh_done_, hipEventDisableTiming));
+    return mesh_done_;
+  }
+  size_t finish_mesh() {
+    DR_HIP(hipSetDevice(device_));
+    DR_HIP(hipEventSynchronize(mesh_done_ev()));
+    unsigned long long t = 0;
+    DR_HIP(hipMemcpy(&t, mesh_total_, 8, hipMemcpyDeviceToHost));
+    if (t > kMeshMaxTriangles) fail(DR_ERR_CAPACITY, "Triangles limit reached! (%llu > %u)", t, kMeshMaxTriangles);
+    return (size_t)t;
+  }
   void check_device_flags() {
     int f[4];
     DR_HIP(hipMemcpy(f, d_.n_alloc, 16, hipMemcpyDeviceToHost));
@@ -615,6 +748,16 @@ class FusionEngine {
   std::vector<Render> renders_;
   int free_slot_ = 0;
   Next next_ = kIntegrate;
+  // mesh extraction state (allocated with the first ExtractMeshAsync)
+  static constexpr unsigned kMeshMaxTriangles = 20000000;
+  bool mesh_pending_ = false;
+  hipEvent_t mesh_done_ = nullptr;
+  McAxis *mesh_axis_ = nullptr;
+  size_t mesh_axis_cap_ = 0, mesh_tmp_bytes_ = 0;
+  unsigned long long *mesh_keys_ = nullptr, *mesh_total_ = nullptr;
+  unsigned *mesh_counts_ = nullptr, *mesh_offsets_ = nullptr;
+  unsigned char *mesh_tmp_ = nullptr;
+  float *mesh_vert_ = nullptr, *mesh_cols_ = nullptr;
 };
 
 }  // namespace dr
@@ -641,14 +784,17 @@ int drf_integrate_scan_async(drf_t *h, const uint8_t *bgr, const float *depth, c
 }
 int drf_render_async(drf_t *h, const float *const *poses16, int n) { return guarded([&] { h->e->render_async(poses16, n); }); }
 int drf_get_render_result(drf_t *h, uint8_t **bgr, float **depth, int n) { return guarded([&] { h->e->get_render_result(bgr, depth, n); }); }
-int drf_extract_mesh_async(drf_t *, const float *, const float *) {
-  return guarded([&] { dr::fail(DR_ERR_UNSUPPORTED, "ExtractMeshAsync: marching cubes is a SURVEY 8(f) 'next' row, not built in round 1"); });
+int drf_extract_mesh_async(drf_t *h, const float *lower, const float *upper) {
+  return guarded([&] { h->e->extract_mesh_async(lower, upper); });
 }
-int drf_get_mesh_sync(drf_t *, size_t, size_t *, float *, float *) {
-  return guarded([&] { dr::fail(DR_ERR_UNSUPPORTED, "GetMeshSync: marching cubes is a SURVEY 8(f) 'next' row, not built in round 1"); });
+int drf_get_mesh_sync(drf_t *h, size_t num_max, size_t *num, float *vert, float *cols) {
+  return guarded([&] { h->e->get_mesh_sync(num_max, num, vert, cols); });
 }
-int drf_save_mesh(drf_t *, const char *, const float *, const float *) {
-  return guarded([&] { dr::fail(DR_ERR_UNSUPPORTED, "SaveMeshToFile: marching cubes is a SURVEY 8(f) 'next' row, not built in round 1"); });
+int drf_mesh_num_triangles(drf_t *h, size_t *ntri) {
+  return guarded([&] { if (!ntri) dr::fail(DR_ERR_ARG, "drf_mesh_num_triangles: null argument"); *ntri = h->e->mesh_num_triangles(); });
+}
+int drf_save_mesh(drf_t *h, const char *filename, const float *lower, const float *upper) {
+  return guarded([&] { h->e->save_mesh(filename, lower, upper); });
 }
 int drf_synchronize(drf_t *h) { return guarded([&] { h->e->synchronize(); }); }
 int drf_stats(drf_t *h, uint64_t out[4]) { return guarded([&] { h->e->stats(out); }); }

@@ -57,12 +57,26 @@ class DrFusion:
         return bgrs, depths
 
     def ExtractMeshAsync(self, lower_corner, upper_corner):
+        """dr_fusion.h:60: marching cubes over the lattice lower + g * voxel_size, legal after GetRenderResult."""
         lo, up = (np.ascontiguousarray(a, np.float32) for a in (lower_corner, upper_corner))
         check(_lib.lib().drf_extract_mesh_async(self._h, fptr(lo), fptr(up)))
 
     def GetMeshSync(self):
+        """dr_fusion.h:61: fills the public members dr_mesh_num (vertices = 3 * triangles), dr_mesh_vert, dr_mesh_cols
+        ((num, 3) float32: positions, RGB colours in [0, 1]) and returns (vert, cols)."""
+        ntri = C.c_size_t()
+        check(_lib.lib().drf_mesh_num_triangles(self._h, C.byref(ntri)))
+        nv = 3 * ntri.value
+        vert, cols = np.empty((max(nv, 1), 3), np.float32), np.empty((max(nv, 1), 3), np.float32)
         num = C.c_size_t()
-        check(_lib.lib().drf_get_mesh_sync(self._h, 0, C.byref(num), None, None))
+        check(_lib.lib().drf_get_mesh_sync(self._h, max(nv, 1), C.byref(num), fptr(vert), fptr(cols)))
+        self.dr_mesh_num, self.dr_mesh_vert, self.dr_mesh_cols = int(num.value), vert[:nv], cols[:nv]
+        return self.dr_mesh_vert, self.dr_mesh_cols
+
+    def GetMesh(self, lower_corner, upper_corner):
+        """dr_fusion.h:58 (DrMesh): synchronous extraction."""
+        self.ExtractMeshAsync(lower_corner, upper_corner)
+        return self.GetMeshSync()
 
     def SaveMeshToFile(self, filename, lower_corner, upper_corner):
         lo, up = (np.ascontiguousarray(a, np.float32) for a in (lower_corner, upper_corner))

@@ -62,10 +62,14 @@ public:
     for (int i = 0; i < n_render_; i++) { bgr.push_back(b[i]); depth.push_back(d[i]); }
   }
   void SaveMeshToFile(std::string const &filename, float lower_corner[3], float upper_corner[3]) { check(drf_save_mesh(impl, filename.c_str(), lower_corner, upper_corner)); }
-  struct DrMesh GetMesh(float lower_corner[3], float upper_corner[3]) {
-    ExtractMeshAsync(lower_corner, upper_corner);
-    GetMeshSync();
-    DrMesh m; m.num = dr_mesh_num; m.vert = dr_mesh_vert; m.cols = dr_mesh_cols;
+  struct DrMesh GetMesh(float lower_corner[3], float upper_corner[3]) {  // caller owns vert / cols (dr_fusion.cpp:95-148)
+    check(drf_extract_mesh_async(impl, lower_corner, upper_corner));
+    size_t ntri = 0;
+    check(drf_mesh_num_triangles(impl, &ntri));
+    DrMesh m;
+    m.vert = (float *) malloc(sizeof(float) * (ntri ? ntri : 1) * 9);
+    m.cols = (float *) malloc(sizeof(float) * (ntri ? ntri : 1) * 9);
+    check(drf_get_mesh_sync(impl, 3 * ntri, &m.num, m.vert, m.cols));
     return m;
   }
   void ExtractMeshAsync(float lower_corner[3], float upper_corner[3]) { check(drf_extract_mesh_async(impl, lower_corner, upper_corner)); }

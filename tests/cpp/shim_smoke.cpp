@@ -41,6 +41,14 @@ int main(int argc, char **argv) {
   size_t hit = 0;
   for (int i = 0; i < H * W; i++) hit += rd[0][i] > 0;
   printf("fusion: rendered %zu / %d pixels\n", hit, H * W);
+  // mesh, the way TandemBackend asks for it (tandem_backend.cpp:194-200)
+  float lower[3] = {-5, -5, -5}, upper[3] = {5, 5, 5};
+  fusion.ExtractMeshAsync(lower, upper);
+  fusion.GetMeshSync();
+  printf("fusion: mesh with %zu vertices, first (%g %g %g)\n", fusion.dr_mesh_num, fusion.dr_mesh_vert[0], fusion.dr_mesh_vert[1], fusion.dr_mesh_vert[2]);
+  DrMesh m = fusion.GetMesh(lower, upper);
+  const bool mesh_ok = fusion.dr_mesh_num > 300 && fusion.dr_mesh_num % 3 == 0 && m.num == fusion.dr_mesh_num;
+  free(m.vert); free(m.cols);
   delete out;
-  return hit > (size_t) (H * W) / 4 ? 0 : 1;
+  return hit > (size_t) (H * W) / 4 && mesh_ok ? 0 : 1;
 }
