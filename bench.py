@@ -147,6 +147,14 @@ def tsdf_leg(args, rank, dev, world):
         f.IntegrateScanAsync(*sc["scans"][0])
         t0 = time.perf_counter(); f.RenderAsync([poses[0]]); f.GetRenderResult(); t1 = time.perf_counter()
         res["raycast_ms_incl_d2h"] = 1e3 * (t1 - t0)
+        # marching cubes (DrFusion::ExtractMeshAsync + GetMeshSync) of the fused map over TANDEM's (-5..5 m)^3 box
+        # (tandem_backend.cpp:80-81): device time = until the triangle count is known, total adds the D2H copy
+        lo, hi = (-5.0, -5.0, -5.0), (5.0, 5.0, 5.0)
+        f.ExtractMeshAsync(lo, hi); f.GetMeshSync()  # first call allocates the 1.44 GB triangle buffers
+        t0 = time.perf_counter(); f.ExtractMeshAsync(lo, hi); ntri = f.mesh_num_triangles(); t1 = time.perf_counter()
+        f.GetMeshSync(); t2 = time.perf_counter()
+        res["mesh"] = dict(triangles=ntri, blocks=after["blocks"], extract_ms=1e3 * (t1 - t0), get_ms_incl_d2h=1e3 * (t2 - t1),
+                           lattice="2000^3 cells at 5 mm, visited per allocated block")
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = tsdf_cpu_baseline(sc, opt)
     f.close()

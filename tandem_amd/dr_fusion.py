@@ -73,6 +73,12 @@ class DrFusion:
         self.dr_mesh_num, self.dr_mesh_vert, self.dr_mesh_cols = int(num.value), vert[:nv], cols[:nv]
         return self.dr_mesh_vert, self.dr_mesh_cols
 
+    def mesh_num_triangles(self):
+        """Size of the pending mesh (waits for the extraction, does not consume it)."""
+        ntri = C.c_size_t()
+        check(_lib.lib().drf_mesh_num_triangles(self._h, C.byref(ntri)))
+        return int(ntri.value)
+
     def GetMesh(self, lower_corner, upper_corner):
         """dr_fusion.h:58 (DrMesh): synchronous extraction."""
         self.ExtractMeshAsync(lower_corner, upper_corner)
