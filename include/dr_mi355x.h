@@ -70,6 +70,19 @@ int drm_upload(drm_t *h, int height, int width, int view_num, int ref_index, con
 /* Enqueue `iters` complete forwards (pre-process .. edge filter) of the resident window on the
  * engine stream; returns after a stream synchronise.  ms_total (may be NULL) = hipEvent time. */
 int drm_forward(drm_t *h, int iters, float *ms_total);
+/* --- view sharding (BASELINE configs[2]): one source view (or a few) per GPU, the host sum-reduces the
+ * partial cost volumes over the ranks (RCCL).  No reference counterpart: the reference has no inference-time
+ * collective.  Protocol per rank: drm_set_view_shard(total source views of the window) -> drm_upload(sub-window =
+ * [reference view, this rank's source views], view_num may be 1) -> for p in 0..2 { drm_forward_phase(p);
+ * all-reduce(sum) the tensor "volume<p+1>" in place } -> drm_forward_phase(3) -> drm_download.  With the shard set,
+ * each rank's cost volume is sum_over_local_views((gate + 1) * (warp - ref)^2) / total, so the reduced volume is the
+ * unsharded one up to fp32 summation order.  View-aggregation models only (module.py:1097-1108). */
+int drm_set_view_shard(drm_t *h, int nsrc_total); /* 0 = off (default) */
+/* Enqueue phase 0..3 of the resident window and wait for it: 0 = pre-process, FeatureNet, cost volume 1;
+ * p = 1,2: regularise + regress stage p, cost volume p+1; 3 = regularise + regress stage 3, edge filter. */
+int drm_forward_phase(drm_t *h, int phase);
+/* Device pointer and element count of a named internal tensor ("volume1".."volume3", "feat1", "depth2", ...). */
+int drm_device_tensor(drm_t *h, const char *name, void **dptr, size_t *nfloats);
 /* Copy the last forward's stage-3 outputs to host (same four arrays as drm_get_result). */
 int drm_download(drm_t *h, float *depth, float *confidence, float *depth_dense, float *confidence_dense);
 /* Unfiltered depth / confidence of stage 1..3 (h_s*w_s floats each). */
@@ -155,6 +168,7 @@ int dr_device_alloc(int device, size_t bytes, void **dptr);
 int dr_device_free(void *dptr);
 int dr_memcpy_h2d(void *dptr, const void *src, size_t bytes);
 int dr_memcpy_d2h(void *dst, const void *dptr, size_t bytes);
+int dr_memcpy_d2d(void *dst, const void *src, size_t bytes);
 /* Time `iters` back-to-back integrations of `nscans` resident scans with hipEvents on the
  * integration stream.  ms / kernel_ms (integrate kernel only) may be NULL. */
 int drf_bench_integrate(drf_t *h, const void *d_bgr, const void *d_depth, const float *poses16, int nscans,

@@ -54,6 +54,9 @@ SIGNATURES = {
     "drm_debug_conv": (C.c_int, [C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_int, f32p, C.c_int,
                                  f32p, C.POINTER(C.c_int)]),
+    "drm_set_view_shard": (C.c_int, [vp, C.c_int]),
+    "drm_forward_phase": (C.c_int, [vp, C.c_int]),
+    "drm_device_tensor": (C.c_int, [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]),
     "drf_create": (C.c_int, [C.POINTER(FusionOptions), C.c_int, C.POINTER(vp)]),
     "drf_destroy": (None, [vp]),
     "drf_integrate_scan_async": (C.c_int, [vp, u8p, f32p, f32p]),
@@ -69,6 +72,7 @@ SIGNATURES = {
     "drf_integrate_device": (C.c_int, [vp, vp, vp, f32p]),
     "dr_device_alloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(vp)]),
     "dr_device_free": (C.c_int, [vp]),
+    "dr_memcpy_d2d": (C.c_int, [vp, vp, C.c_size_t]),
     "dr_memcpy_h2d": (C.c_int, [vp, vp, C.c_size_t]),
     "dr_memcpy_d2h": (C.c_int, [vp, vp, C.c_size_t]),
     "drf_bench_integrate": (C.c_int, [vp, vp, vp, f32p, C.c_int, f32p, f32p]),

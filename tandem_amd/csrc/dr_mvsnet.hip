@@ -192,6 +192,32 @@ class MvsEngine {
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (ms) *ms = t;
   }
+  // ---- view sharding hooks (SURVEY 8e / BASELINE configs[2]; no reference counterpart) ----
+  // Phase p = 0..3 of the uploaded window: [.. cost volume 1] [regularise 1 .. cost volume 2] [.. cost volume 3]
+  // [regularise 3 .. edge filter].  Between phases the host sum-reduces "volume<p+1>" over the ranks.
+  void set_view_shard(int nsrc_total) {
+    std::unique_lock<std::mutex> lk(mu_);
+    if (nsrc_total < 0 || nsrc_total > kMaxSrc) fail(DR_ERR_ARG, "set_view_shard: %d source views unsupported (0..%d)", nsrc_total, kMaxSrc);
+    shard_nsrc_ = nsrc_total;
+  }
+  void forward_phase(int phase) {
+    std::unique_lock<std::mutex> lk(mu_);
+    require_config();
+    if (phase < 0 || phase > 3) fail(DR_ERR_ARG, "forward_phase: phase must be 0..3");
+    DR_HIP(hipSetDevice(device_));
+    std::vector<size_t> cut{0};
+    for (size_t i = 0; i < ops_.size(); ++i) if (ops_[i].kind == Op::COSTVOL) cut.push_back(i + 1);
+    cut.push_back(ops_.size());
+    forward(nullptr, cut[phase], cut[phase + 1]);
+    DR_HIP(hipStreamSynchronize(stream_));
+  }
+  void device_tensor(const char *name, void **dptr, size_t *n) {
+    std::unique_lock<std::mutex> lk(mu_);
+    require_config();
+    const DevTensor &t = T(name);
+    if (dptr) *dptr = t.d;
+    if (n) *n = t.n();
+  }
   void download(float *depth, float *conf, float *depth_dense, float *conf_dense) {
     std::unique_lock<std::mutex> lk(mu_);
     require_config();
@@ -257,7 +283,8 @@ class MvsEngine {
   // ---------------------------------------------------------------- plumbing
   void check_args(int H, int W, int V, int ref, const uint8_t *const *bgrs, const float *K9, const float *const *c2ws) {
     if (!bgrs || !K9 || !c2ws) fail(DR_ERR_ARG, "CallAsync: null pointer argument");
-    if (V < 2 || V > kMaxSrc + 1) fail(DR_ERR_ARG, "CallAsync: view_num=%d unsupported (2..%d)", V, kMaxSrc + 1);
+    const int vmin = shard_nsrc_ ? 1 : 2;  // a view-shard rank may hold the reference view only
+    if (V < vmin || V > kMaxSrc + 1) fail(DR_ERR_ARG, "CallAsync: view_num=%d unsupported (%d..%d)", V, vmin, kMaxSrc + 1);
     if (ref < 0 || ref >= V) fail(DR_ERR_ARG, "CallAsync: ref_index=%d out of range", ref);
     if (H <= 0 || W <= 0 || H % 32 || W % 32) fail(DR_ERR_ARG, "CallAsync: height/width must be positive multiples of 32 (got %dx%d)", H, W);
     for (int i = 0; i < V - 1; ++i) for (int j = i + 1; j < V; ++j)
@@ -482,7 +509,9 @@ class MvsEngine {
       a.V = V; a.h = h; a.w = w;
       a.dchunk = s == 1 ? 4 : (D >= 16 ? 8 : D);  // enough workgroups to fill 256 CUs at every stage
       a.view_aggregation = blob_.view_aggregation;
-      a.nsrc_f = (float)(V - 1);
+      // view sharding: this rank's window holds a subset of the source views, the divisor stays the whole window's
+      if (shard_nsrc_ && !blob_.view_aggregation) fail(DR_ERR_UNSUPPORTED, "view sharding needs a view-aggregation model (the variance volume is not a sum over views)");
+      a.nsrc_f = shard_nsrc_ ? (float)shard_nsrc_ : (float)(V - 1);
       PlaneArgs &p = a.planes;
       p.D = D; p.dmin = dmin; p.interval = base_interval;
       if (s > 1) {
@@ -531,12 +560,14 @@ class MvsEngine {
     filter_rank_ = (unsigned)ci;
   }
 
-  // Enqueue one complete forward on stream_.  ev (optional): ops_.size()+1 events for per-op timing.
-  void forward(std::vector<hipEvent_t> *ev) {
+  // Enqueue one complete forward on stream_ (or the ops [first, last) of it).  ev (optional): ops_.size()+1 events
+  // for per-op timing.
+  void forward(std::vector<hipEvent_t> *ev, size_t first = 0, size_t last = ~(size_t)0) {
     size_t i = 0;
     for (const Op &o : ops_) {
       if (ev) DR_HIP(hipEventRecord((*ev)[i], stream_));
       ++i;
+      if (i - 1 < first || i - 1 >= last) continue;
       switch (o.kind) {
         case Op::PREPROCESS: {
           const size_t npix = (size_t)V_ * H_ * W_;
@@ -602,6 +633,7 @@ class MvsEngine {
   unsigned *d_state_ = nullptr, *d_hist_ = nullptr;
   unsigned filter_rank_ = 0;
   int H_ = 0, W_ = 0, V_ = 0;
+  int shard_nsrc_ = 0;  // > 0: view-shard rank, cost-volume divisor = source views of the whole window
 
   std::thread worker_;
   std::mutex mu_;
@@ -648,6 +680,11 @@ int drm_upload(drm_t *h, int height, int width, int view_num, int ref_index, con
   return guarded([&] { h->e->upload(height, width, view_num, ref_index, bgrs, K9, c2ws, depth_min, depth_max, discard_percentage); });
 }
 int drm_forward(drm_t *h, int iters, float *ms_total) { return guarded([&] { h->e->forward_n(iters, ms_total); }); }
+int drm_set_view_shard(drm_t *h, int nsrc_total) { return guarded([&] { h->e->set_view_shard(nsrc_total); }); }
+int drm_forward_phase(drm_t *h, int phase) { return guarded([&] { h->e->forward_phase(phase); }); }
+int drm_device_tensor(drm_t *h, const char *name, void **dptr, size_t *nfloats) {
+  return guarded([&] { if (!name) dr::fail(DR_ERR_ARG, "drm_device_tensor: null name"); h->e->device_tensor(name, dptr, nfloats); });
+}
 int drm_download(drm_t *h, float *depth, float *confidence, float *depth_dense, float *confidence_dense) {
   return guarded([&] { h->e->download(depth, confidence, depth_dense, confidence_dense); });
 }

@@ -81,6 +81,19 @@ class DrMvsnet:
         check(_lib.lib().drm_forward(self._h, iters, C.byref(ms)))
         return ms.value
 
+    # ---- view sharding hooks (include/dr_mi355x.h "view sharding"; host protocol in tandem_amd/view_shard.py) ----
+    def set_view_shard(self, nsrc_total):
+        check(_lib.lib().drm_set_view_shard(self._h, int(nsrc_total)))
+
+    def forward_phase(self, phase):
+        check(_lib.lib().drm_forward_phase(self._h, int(phase)))
+
+    def device_tensor(self, name):
+        """(device pointer, float count) of a named internal tensor, e.g. "volume2"."""
+        ptr, n = C.c_void_p(), C.c_size_t()
+        check(_lib.lib().drm_device_tensor(self._h, name.encode(), C.byref(ptr), C.byref(n)))
+        return ptr.value, int(n.value)
+
     def download(self):
         out = DrMvsnetOutput(*self._hw)
         check(_lib.lib().drm_download(self._h, fptr(out.depth), fptr(out.confidence), fptr(out.depth_dense),

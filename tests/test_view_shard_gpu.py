@@ -1,0 +1,106 @@
+"""-m gpu: view sharding (BASELINE configs[2]) on the real engine.  One GPU box, so the ranks are emulated: `world`
+DrMvsnet engines in one process, each uploaded with its rank's sub-window (tandem_amd/view_shard.upload), and an
+all-reduce that sums the engines' partial volumes on the device's behalf (D2H, fp32 sum in rank order, H2D to every
+engine) exactly where RCCL's all_reduce sits in the multi-process path.  The sharded result must equal the
+unsharded engine's to fp32 summation order, every rank must end with the same depth map, and a rank without source
+views must contribute nothing."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+DEPTH_TOL = 2e-4   # metres, max |depth_dense difference| sharded vs unsharded (summation order of <= 6 views)
+
+
+def host_allreduce(models):
+    from tandem_amd import _lib
+
+    def reduce_all(name):
+        parts = []
+        for m in models:
+            ptr, n = m.device_tensor(name)
+            a = np.empty(n, np.float32)
+            _lib.check(_lib.lib().dr_memcpy_d2h(a.ctypes.data_as(C.c_void_p), ptr, n * 4))
+            parts.append(a)
+        total = parts[0].copy()
+        for a in parts[1:]:
+            total += a
+        for m in models:
+            ptr, n = m.device_tensor(name)
+            _lib.check(_lib.lib().dr_memcpy_h2d(ptr, total.ctypes.data_as(C.c_void_p), n * 4))
+        return parts, total
+    return reduce_all
+
+
+def run_sharded(blob, window, world):
+    from tandem_amd import view_shard
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    models = [DrMvsnet(blob) for _ in range(world)]
+    subs = [view_shard.upload(m, window, r, world) for r, m in enumerate(models)]
+    reduce_all = host_allreduce(models)
+    parts_log = {}
+    for p in range(3):
+        for m in models:
+            m.forward_phase(p)
+        parts_log[p + 1] = reduce_all("volume%d" % (p + 1))
+    for m in models:
+        m.forward_phase(3)
+    outs = [m.download() for m in models]
+    for m in models:
+        m.close()
+    return outs, subs, parts_log
+
+
+@pytest.mark.parametrize("H,W,V,world", [(64, 96, 7, 2), (64, 96, 7, 3), (96, 128, 4, 8), (64, 96, 7, 1)])
+def test_sharded_equals_unsharded(H, W, V, world):
+    import os
+    from oracle import scene
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    blob = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "weights", "tandem_va.tdmw")
+    win = scene.make_window(H, W, V, seed=V + world)
+    window = dict(bgrs=win["bgrs"], K=win["K"], c2ws=list(win["c2ws"]), ref_index=win["ref_index"],
+                  depth_min=0.5, depth_max=5.0, discard=2.5)
+    full = DrMvsnet(blob)
+    full.CallAsync(H, W, V, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), 0.5, 5.0, 2.5)
+    ref = full.GetResult()
+    full.close()
+    outs, subs, parts = run_sharded(blob, window, world)
+    # partition: every source view on exactly one rank, the reference on all
+    assert all(s[0] == win["ref_index"] for s in subs)
+    assert sorted(i for s in subs for i in s[1:]) == [i for i in range(V) if i != win["ref_index"]]
+    for r, s in enumerate(subs):
+        if len(s) == 1:  # a rank with no source views adds a zero volume
+            assert all(not parts[k][0][r].any() for k in parts)
+    for o in outs:
+        assert np.abs(o.depth_dense - ref.depth_dense).max() < DEPTH_TOL
+        assert np.abs(o.confidence_dense - ref.confidence_dense).mean() < 1e-4
+        assert ((o.depth == 0) != (ref.depth == 0)).mean() < 2e-3
+    for o in outs[1:]:  # all ranks regularise the same reduced volume: identical results, no broadcast needed
+        assert np.array_equal(o.depth_dense.view(np.uint32), outs[0].depth_dense.view(np.uint32))
+        assert np.array_equal(o.depth.view(np.uint32), outs[0].depth.view(np.uint32))
+
+
+def test_shard_requires_view_aggregation_and_resets():
+    import os
+    from oracle import scene
+    from tandem_amd import _lib
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    win = scene.make_window(64, 96, 3, seed=1)
+    m = DrMvsnet(os.path.join(root, "weights", "tandem_va.tdmw"))
+    with pytest.raises(_lib.DrError):  # a one-view window is only legal on a shard rank
+        m.upload(64, 96, 1, 0, win["bgrs"][:1], win["K"], list(win["c2ws"])[:1], 0.5, 5.0, 2.5)
+    m.set_view_shard(2)
+    m.upload(64, 96, 1, 0, win["bgrs"][:1], win["K"], list(win["c2ws"])[:1], 0.5, 5.0, 2.5)
+    m.forward_phase(0)
+    ptr, n = m.device_tensor("volume1")
+    a = np.empty(n, np.float32)
+    _lib.check(_lib.lib().dr_memcpy_d2h(a.ctypes.data_as(C.c_void_p), ptr, n * 4))
+    assert n == 48 * 16 * 24 * 32 and not a.any()
+    with pytest.raises(_lib.DrError):
+        m.forward_phase(4)
+    m.set_view_shard(0)  # back to the plain path
+    m.CallAsync(64, 96, 3, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), 0.5, 5.0, 2.5)
+    assert np.isfinite(m.GetResult().depth_dense).all()
+    m.close()
