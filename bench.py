@@ -161,6 +161,44 @@ def tsdf_leg(args, rank, dev, world):
     return res
 
 
+def view_shard_leg(args, rank, dev, world):
+    """BASELINE configs[2]: ONE 7-view window, its source views sharded over the ranks, one RCCL sum all-reduce of the
+    fp32 cost volume per cascade stage (tandem_amd/view_shard.py).  Reported next to the replicas headline, never as it:
+    by SURVEY 8e the reduce alone exceeds the single-GPU pipeline, so this configuration loses throughput by design."""
+    import torch
+    from oracle import scene
+    from tandem_amd import replicas, view_shard
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    steps, warmup = min(args.steps, 20), 2
+    win = scene.make_window(H, W, V, seed=0)  # the SAME window on every rank
+    window = dict(bgrs=win["bgrs"], K=win["K"], c2ws=list(win["c2ws"]), ref_index=win["ref_index"],
+                  depth_min=win["depth_min"], depth_max=win["depth_max"], discard=DISCARD)
+    m = DrMvsnet(os.path.join(ROOT, "weights", "tandem_va.tdmw"), device=dev)
+    mine = view_shard.upload(m, window, rank, world)
+    nmax = max(m.device_tensor("volume%d" % s)[1] for s in (1, 2, 3))
+    ar = view_shard.TorchAllReduce(dev, nmax)
+    for _ in range(warmup):
+        view_shard.forward(m, ar)
+    ar.bytes = 0
+    replicas.barrier(dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        view_shard.forward(m, ar)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    replicas.barrier(dev)
+    tmax, nsrc = replicas.reduce_max_sum(t1 - t0, len(mine) - 1, dev)
+    out = m.download()
+    chk = replicas.reduce_max_sum(float(out.depth_dense.astype("float64").sum()), 0, dev)[0]
+    same = abs(chk - float(out.depth_dense.astype("float64").sum())) == 0.0  # every rank holds the same depth map
+    m.close()
+    return dict(depth_maps_per_s=steps / tmax, ms_per_depth_map=1e3 * tmax / steps, steps=steps, n_gpus=world,
+                source_views_total=int(nsrc), source_views_this_rank=len(mine) - 1,
+                allreduce_mb_per_depth_map=ar.bytes / steps / 1e6, ranks_agree=bool(same),
+                note="one window sharded over the ranks; 3 fp32 volume all-reduces (RCCL) per depth map; phases host-synchronised")
+
+
 def tsdf_cpu_baseline(sc, opt):
     from oracle.tsdf_oracle import TsdfOracle
     o = TsdfOracle(**dict(opt, num_blocks=400000))
@@ -184,6 +222,7 @@ def main():
     ap.add_argument("--tsdf-cycles", type=int, default=20, help="times the scan set is re-integrated (default 50 x 20 = 1000 integrations)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
     ap.add_argument("--no-tsdf", action="store_true")
+    ap.add_argument("--no-view-shard", action="store_true", help="N > 1 only: skip the view-sharded (configs[2]) leg")
     args = ap.parse_args()
 
     import torch
@@ -194,11 +233,19 @@ def main():
               % (args.gpus, world, world, "" if world == 1 else "s"), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    # test scaffolding for 1-GPU boxes: DR_BENCH_ONE_DEVICE=1 runs every rank on cuda:0 over gloo (RCCL refuses two ranks
+    # on one device) so that the N > 1 code path can be exercised end to end; never set by the driver
+    one_dev = os.environ.get("DR_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    replicas.init("nccl", local_rank)
+    replicas.init("gloo" if one_dev else "nccl", local_rank)
 
     mv = mvsnet_leg(args, rank, local_rank, world)
     ts = None if args.no_tsdf else tsdf_leg(args, rank, local_rank, world)
+    vs = None
+    if world > 1 and not args.no_view_shard:
+        vs = view_shard_leg(args, rank, local_rank, world)
     if rank == 0:
         out = {
             "metric": "depth-maps/sec @ 640x480x7-view x3-stage; TSDF voxels integrated/sec",
@@ -218,6 +265,8 @@ def main():
                 out[k] = mv[k]
         if ts is not None:
             out["tsdf"] = ts
+        if vs is not None:
+            out["view_sharded"] = vs
         print(json.dumps(out))
     import torch.distributed as dist
     if dist.is_initialized():

@@ -168,7 +168,7 @@ int dr_device_alloc(int device, size_t bytes, void **dptr);
 int dr_device_free(void *dptr);
 int dr_memcpy_h2d(void *dptr, const void *src, size_t bytes);
 int dr_memcpy_d2h(void *dst, const void *dptr, size_t bytes);
-int dr_memcpy_d2d(void *dst, const void *src, size_t bytes);
+int dr_memcpy_d2d(void *dst, const void *src, size_t bytes); /* returns after the copy has completed */
 /* Time `iters` back-to-back integrations of `nscans` resident scans with hipEvents on the
  * integration stream.  ms / kernel_ms (integrate kernel only) may be NULL. */
 int drf_bench_integrate(drf_t *h, const void *d_bgr, const void *d_depth, const float *poses16, int nscans,

@@ -809,7 +809,11 @@ int dr_device_alloc(int device, size_t bytes, void **dptr) {
 }
 int dr_device_free(void *dptr) { return guarded([&] { DR_HIP(hipFree(dptr)); }); }
 int dr_memcpy_h2d(void *dptr, const void *src, size_t bytes) { return guarded([&] { DR_HIP(hipMemcpy(dptr, src, bytes, hipMemcpyHostToDevice)); }); }
-int dr_memcpy_d2d(void *dst, const void *src, size_t bytes) { return guarded([&] { DR_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice)); }); }
+int dr_memcpy_d2d(void *dst, const void *src, size_t bytes) {
+  // a device-to-device hipMemcpy may return before the copy has run, and the engines' streams are non-blocking:
+  // synchronise so that whatever the caller enqueues next (on any stream) sees the data
+  return guarded([&] { DR_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice)); DR_HIP(hipDeviceSynchronize()); });
+}
 int dr_memcpy_d2h(void *dst, const void *dptr, size_t bytes) { return guarded([&] { DR_HIP(hipMemcpy(dst, dptr, bytes, hipMemcpyDeviceToHost)); }); }
 int drf_bench_integrate(drf_t *h, const void *d_bgr, const void *d_depth, const float *poses16, int nscans, float *ms, float *kernel_ms) {
   return guarded([&] { h->e->bench_integrate(d_bgr, d_depth, poses16, nscans, ms, kernel_ms); });

@@ -104,3 +104,28 @@ def test_shard_requires_view_aggregation_and_resets():
     m.CallAsync(64, 96, 3, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), 0.5, 5.0, 2.5)
     assert np.isfinite(m.GetResult().depth_dense).all()
     m.close()
+
+
+def test_two_process_bench_path_on_one_gpu(tmp_path):
+    """bench.py's N > 1 code path end to end -- torch.distributed.run, barrier, max-over-ranks clock, replicas leg,
+    view-sharded leg with the torch all-reduce between phases -- as two processes sharing cuda:0 over gloo
+    (DR_BENCH_ONE_DEVICE=1: RCCL refuses two ranks on one device; the driver's 8-GPU run uses nccl)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-tsdf"]
+    p = subprocess.run(cmd, env=dict(os.environ, DR_BENCH_ONE_DEVICE="1"), capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    vs = d["view_sharded"]
+    assert vs["n_gpus"] == 2 and vs["source_views_total"] == 6 and vs["source_views_this_rank"] == 3
+    assert vs["ranks_agree"] is True
+    assert abs(vs["allreduce_mb_per_depth_map"] - 4e-6 * (48 * 120 * 160 * 32 + 32 * 240 * 320 * 16 + 8 * 480 * 640 * 8)) < 1e-3
