@@ -5,13 +5,15 @@ CSRC  := tandem_amd/csrc
 LIB   := tandem_amd/libdr_mi355x.so
 # -ffp-contract=off: the TSDF path is compared bit-for-bit with the C oracle (no FMA contraction on either side)
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-pass-failed
-OBJS := $(CSRC)/dr_mvsnet.o $(CSRC)/dr_fusion.o
+OBJS := $(CSRC)/dr_mvsnet.o $(CSRC)/dr_fusion.o $(CSRC)/dr_tracker.o
 
-all: $(LIB) oracle/libtsdf_oracle.so
+all: $(LIB) oracle/libtsdf_oracle.so oracle/libtracker_oracle.so
 
 $(CSRC)/dr_mvsnet.o: $(CSRC)/dr_mvsnet.hip $(CSRC)/conv_mfma.h $(CSRC)/mvs_kernels.h $(CSRC)/dr_common.h include/dr_mi355x.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(CSRC)/dr_fusion.o: $(CSRC)/dr_fusion.hip $(CSRC)/mesh_kernels.h $(CSRC)/mc_tables.h $(CSRC)/dr_common.h include/dr_mi355x.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(CSRC)/dr_tracker.o: $(CSRC)/dr_tracker.hip $(CSRC)/dr_common.h include/dr_mi355x.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@ -lpthread
@@ -19,6 +21,9 @@ $(LIB): $(OBJS)
 oracle/libtsdf_oracle.so: oracle/tsdf_oracle.c tandem_amd/csrc/mc_tables.h
 	gcc -O2 -std=c99 -fPIC -shared -ffp-contract=off -fno-fast-math $< -o $@ -lm
 
+oracle/libtracker_oracle.so: oracle/tracker_oracle.c
+	gcc -O2 -std=c99 -fPIC -shared -ffp-contract=off -fno-fast-math $< -o $@ -lm
+
 clean:
-	rm -f $(OBJS) $(LIB) oracle/libtsdf_oracle.so
+	rm -f $(OBJS) $(LIB) oracle/libtsdf_oracle.so oracle/libtracker_oracle.so
 .PHONY: all clean

@@ -174,6 +174,51 @@ int dr_memcpy_d2d(void *dst, const void *src, size_t bytes); /* returns after th
 int drf_bench_integrate(drf_t *h, const void *d_bgr, const void *d_depth, const float *poses16, int nscans,
                         float *ms, float *kernel_ms);
 
+/* ======================================================================================================
+ * DrCoarseTracker -- the dense coarse tracker operator.  Replaces
+ *   tandem/libdr/cuda_coarse_tracker/include/public/cuda_coarse_tracker.h   (class CudaCoarseTracker)
+ * member for member (Eigen arguments become plain arrays: matrices row-major, double where the reference is), plus
+ * the dense-depth hand-off of CoarseTracker::setCoarseTrackingRef (src/FullSystem/CoarseTracker.cpp:655-725).
+ * ====================================================================================================== */
+typedef struct drt_s drt_t;
+/* CudaCoarseTracker(w, h, setting_huberTH, setting_coarseCutoffTH)            cuda_coarse_tracker.h:11, .cpp:63-69 */
+int drt_create(int w, int h, float setting_huberTH, float setting_coarseCutoffTH, int device, drt_t **out);
+void drt_destroy(drt_t *t);                                                   /* ~CudaCoarseTracker / free(), .cpp:142-199 */
+/* setK(w, h, fx, fy, cx, cy): w, h must equal the constructor's               cuda_coarse_tracker.h:13, .cpp:358-372 */
+int drt_set_k(drt_t *t, int w, int h, float fx, float fy, float cx, float cy);
+/* init(n_max = 0 -> w*h); a second call is DR_ERR_PROTOCOL                      cuda_coarse_tracker.h:17, .cpp:101-140 */
+int drt_init(drt_t *t, int n_max);
+/* setReference(n, pc_u, pc_v, pc_idepth, pc_color, ref_exposure, ref_aff_g2l)  cuda_coarse_tracker.h:21, .cpp:71-89 */
+int drt_set_reference(drt_t *t, int n, const float *pc_u, const float *pc_v, const float *pc_idepth, const float *pc_color,
+                      float ref_exposure, const double ref_aff_g2l[2]);
+/* setNew(dInew): 3*w*h floats, (I, dx, dy) interleaved per pixel                cuda_coarse_tracker.h:23, .cpp:91-94 */
+int drt_set_new(drt_t *t, const float *dInew);
+/* Vec6 calcRes(refToNew 4x4, new_exposure, aff_g2l, cutoffTH)                   cuda_coarse_tracker.h:25, .cpp:217-288
+ * refToNew row-major.  out6 = the reference's Vec6 (E, numTermsInE, shiftT/num, 0, shiftRT/num, saturated/numTermsInE);
+ * sums7 (may be NULL) = the 7 raw sums in the order of cuda_coarse_tracker_private.h:8-15. */
+int drt_calc_res(drt_t *t, const double refToNew[16], float new_exposure, const double aff_g2l[2], float cutoffTH, double out6[6],
+                 double sums7[7]);
+/* calcG(H_out 8x8, b_out 8, new_exposure, aff_g2l)                              cuda_coarse_tracker.h:27, .cpp:290-356
+ * Uses the warped buffers of the last calcRes.  H row-major, scaled as the reference; raw45 (may be NULL) = the 45
+ * unscaled upper-triangular sums. */
+int drt_calc_g(drt_t *t, double H_out[64], double b_out[8], float new_exposure, const double aff_g2l[2], double raw45[45]);
+/* The dense-depth branch of CoarseTracker::setCoarseTrackingRef (CoarseTracker.cpp:655-725), on the device: forward-warp
+ * `depth` (w*h, metres, <= 0 invalid; sampled every `step` pixels) with p' = KRKi * (x*d, y*d, d) + Kt into the tracker's
+ * reference frame (z-buffer minimum), then append every pixel of rows/cols [2, size-2) that received a depth -- and has
+ * idepth0 <= 0 unless dense_only -- as (x, y, 1/depth, dIp0[3*i]) after the current points, row-major.  KRKi (row-major)
+ * and Kt are the caller's float products K*R*Ki and K*t (:672-673).  on_device != 0: depth / idepth0 / dIp0 are device
+ * pointers (e.g. a DrFusion render left in HBM).  *n_out = new point count.  DR_ERR_CAPACITY above n_max. */
+int drt_append_dense_reference(drt_t *t, const float *depth, const float KRKi[9], const float Kt[3], int step, int dense_only,
+                               const float *idepth0, const float *dIp0, int on_device, int *n_out);
+/* synchronize / startTiming / endTimingMilliseconds                              cuda_coarse_tracker.h:30-34 */
+int drt_synchronize(drt_t *t);
+int drt_start_timing(drt_t *t);
+int drt_end_timing_ms(drt_t *t, float *ms);
+/* --- introspection hooks (no reference counterpart) --- */
+int drt_get_points(drt_t *t, float *pc_u, float *pc_v, float *pc_idepth, float *pc_color, int cap, int *n); /* arrays may be NULL */
+int drt_get_warped(drt_t *t, int which, float *out, int cap); /* which: 0 u, 1 v, 2 dx, 3 dy, 4 idepth, 5 residual, 6 weight */
+int drt_get_zbuffer(drt_t *t, float *out);                    /* w*h projected depths of the last append, -1 = empty */
+
 #ifdef __cplusplus
 }
 #endif

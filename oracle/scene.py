@@ -105,3 +105,39 @@ def make_scans(n, height=480, width=640, seed=0, drop_fraction=0.025, texture_te
         scans.append((np.ascontiguousarray(bgr), np.ascontiguousarray(depth), T.astype(np.float32)))
     return dict(fx=float(f), fy=float(f), cx=float(K[0, 2]), cy=float(K[1, 2]), height=height, width=width,
                 scans=scans)
+
+
+def _dI(rgb):
+    """DSO-style image triple (I, dx, dy) per pixel, I in [0, 255] (FrameHessian::makeImages): central differences."""
+    I = (255.0 * rgb.mean(axis=2)).astype(np.float32)
+    dx, dy = np.zeros_like(I), np.zeros_like(I)
+    dx[:, 1:-1] = 0.5 * (I[:, 2:] - I[:, :-2])
+    dy[1:-1, :] = 0.5 * (I[2:, :] - I[:-2, :])
+    return np.ascontiguousarray(np.stack([I, dx, dy], axis=2))
+
+
+def make_tracking_pair(height=480, width=640, seed=0, sparse_fraction=0.03, motion=1.0):
+    """A reference frame and a new frame of the analytic scene for the dense coarse tracker:
+    dict(K (fx,fy,cx,cy), dI_ref / dI_new (H,W,3 f32), depth_ref / depth_new (H,W f32), c2w_ref / c2w_new (4x4 f64),
+    refToNew (4x4 f64), sparse points pc_u/pc_v/pc_idepth/pc_color of the reference, idepth0 (H,W; > 0 at sparse points))."""
+    f = 0.78125 * width
+    K = np.array([[f, 0, (width - 1) / 2.0], [0, f, (height - 1) / 2.0], [0, 0, 1]], np.float64)
+    Tr = _pose(0.01, -0.02, 0.005, [0.02, 0.01, 0.0])
+    Tn = _pose(0.01 + 0.012 * motion, -0.02 + 0.02 * motion, 0.005 - 0.008 * motion,
+               [0.02 + 0.04 * motion, 0.01 - 0.025 * motion, 0.03 * motion])
+    rgb_r, z_r = _render(K, Tr, height, width, seed, 12)
+    rgb_n, z_n = _render(K, Tn, height, width, seed, 12)
+    dIr, dIn = _dI(rgb_r), _dI(rgb_n)
+    rng = np.random.RandomState(seed + 7)
+    pick = (rng.rand(height, width) < sparse_fraction)
+    pick[:3, :] = pick[-3:, :] = False
+    pick[:, :3] = pick[:, -3:] = False
+    ys, xs = np.nonzero(pick)
+    idepth = (1.0 / z_r).astype(np.float32)
+    idepth0 = np.zeros((height, width), np.float32)
+    idepth0[ys, xs] = idepth[ys, xs]
+    return dict(fx=float(f), fy=float(f), cx=float(K[0, 2]), cy=float(K[1, 2]), height=height, width=width,
+                dI_ref=dIr, dI_new=dIn, depth_ref=z_r.astype(np.float32), depth_new=z_n.astype(np.float32),
+                c2w_ref=Tr, c2w_new=Tn, refToNew=np.linalg.inv(Tn) @ Tr,
+                pc_u=xs.astype(np.float32), pc_v=ys.astype(np.float32), pc_idepth=idepth[ys, xs].copy(),
+                pc_color=dIr[ys, xs, 0].copy(), idepth0=idepth0)

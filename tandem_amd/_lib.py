@@ -32,6 +32,7 @@ class FusionOptions(C.Structure):
 
 _lib = None
 u8p, f32p, vp = C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.c_void_p
+f64p = C.POINTER(C.c_double)
 
 SIGNATURES = {
     "dr_last_error": (C.c_char_p, []),
@@ -70,6 +71,21 @@ SIGNATURES = {
     "drf_stats": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "drf_export_blocks": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int32), u8p, C.POINTER(C.c_int)]),
     "drf_integrate_device": (C.c_int, [vp, vp, vp, f32p]),
+    "drt_create": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.POINTER(vp)]),
+    "drt_destroy": (None, [vp]),
+    "drt_set_k": (C.c_int, [vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "drt_init": (C.c_int, [vp, C.c_int]),
+    "drt_set_reference": (C.c_int, [vp, C.c_int, f32p, f32p, f32p, f32p, C.c_float, f64p]),
+    "drt_set_new": (C.c_int, [vp, f32p]),
+    "drt_calc_res": (C.c_int, [vp, f64p, C.c_float, f64p, C.c_float, f64p, f64p]),
+    "drt_calc_g": (C.c_int, [vp, f64p, f64p, C.c_float, f64p, f64p]),
+    "drt_append_dense_reference": (C.c_int, [vp, vp, f32p, f32p, C.c_int, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int)]),
+    "drt_synchronize": (C.c_int, [vp]),
+    "drt_start_timing": (C.c_int, [vp]),
+    "drt_end_timing_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
+    "drt_get_points": (C.c_int, [vp, f32p, f32p, f32p, f32p, C.c_int, C.POINTER(C.c_int)]),
+    "drt_get_warped": (C.c_int, [vp, C.c_int, f32p, C.c_int]),
+    "drt_get_zbuffer": (C.c_int, [vp, f32p]),
     "dr_device_alloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(vp)]),
     "dr_device_free": (C.c_int, [vp]),
     "dr_memcpy_d2d": (C.c_int, [vp, vp, C.c_size_t]),

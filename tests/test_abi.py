@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def header_functions():
     src = open(os.path.join(ROOT, "include", "dr_mi355x.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"\b(dr[mf]?_[a-z0-9_]+)\s*\(", src)
+    names = re.findall(r"\b(dr[mft]?_[a-z0-9_]+)\s*\(", src)
     return sorted(set(names))
 
 

@@ -40,3 +40,27 @@ def test_shim_end_to_end(tmp_path, trained_blob):
     r = subprocess.run([exe, trained_blob, sample], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "All looks good!" in r.stdout and "fusion: rendered" in r.stdout
+
+
+def build_tracker(tmp_path):
+    import __graft_entry__ as g
+    if not os.path.isfile(os.path.join(ROOT, "tandem_amd", "libdr_mi355x.so")):
+        g.build()
+    exe = str(tmp_path / "tracker_smoke")
+    subprocess.check_call(["g++", "-std=c++14", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "tandem_amd", "libdr"), os.path.join(ROOT, "tests/cpp/tracker_smoke.cpp"),
+                           "-o", exe, "-L" + os.path.join(ROOT, "tandem_amd"), "-ldr_mi355x",
+                           "-Wl,-rpath," + os.path.join(ROOT, "tandem_amd")])
+    return exe
+
+
+def test_tracker_shim_compiles_and_links_with_gcc(tmp_path):
+    assert os.path.isfile(build_tracker(tmp_path))
+
+
+@pytest.mark.gpu
+def test_tracker_shim_end_to_end(tmp_path):
+    """class CudaCoarseTracker (cuda_coarse_tracker.h:9-35) through the shim: closed-form residual on a ramp image."""
+    r = subprocess.run([build_tracker(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "tracker: E=" in r.stdout
