@@ -161,6 +161,59 @@ def tsdf_leg(args, rank, dev, world):
     return res
 
 
+def tracker_leg(args, dev):
+    """SURVEY 8(f) rows 3-4 (not a headline metric): the dense coarse tracker at its largest size -- every pixel of a
+    640x480 keyframe as a reference point -- one calcRes + calcG (one Gauss-Newton iteration of
+    CoarseTracker::trackNewestCoarse on level 0) and the dense-depth hand-off, hipEvent-timed on the tracker stream;
+    the single-threaded C restatement beside it."""
+    import numpy as np
+    from oracle import scene
+    from tandem_amd.dr_tracker import DrCoarseTracker
+    p = scene.make_tracking_pair(H, W, seed=1, sparse_fraction=1.0)
+    g = DrCoarseTracker(W, H, 9.0, 20.0, device=dev)
+    g.setK(W, H, p["fx"], p["fy"], p["cx"], p["cy"])
+    g.init()
+    g.setReference(p["pc_u"], p["pc_v"], p["pc_idepth"], p["pc_color"], 1.0, [0.0, 0.0])
+    g.setNew(p["dI_new"])
+    for _ in range(3):
+        g.calcRes(p["refToNew"], 1.0, [0.0, 0.0], 20.0); g.calcG(1.0, [0.0, 0.0])
+    reps = 50
+    g.startTiming()
+    for _ in range(reps):
+        g.calcRes(p["refToNew"], 1.0, [0.0, 0.0], 20.0)
+    t_res = g.endTimingMilliseconds() / reps
+    g.startTiming()
+    for _ in range(reps):
+        g.calcG(1.0, [0.0, 0.0])
+    t_g = g.endTimingMilliseconds() / reps
+    K = np.array([[p["fx"], 0, p["cx"]], [0, p["fy"], p["cy"]], [0, 0, 1]], np.float32)
+    T = np.linalg.inv(p["c2w_ref"]) @ p["c2w_new"]
+    KRKi = (K @ T[:3, :3].astype(np.float32)) @ np.linalg.inv(K.astype(np.float64)).astype(np.float32)
+    Kt = K @ T[:3, 3].astype(np.float32)
+    g.setReference([], [], [], [], 1.0, [0.0, 0.0])
+    g.appendDenseReference(p["depth_new"], KRKi, Kt, 1, True, None, p["dI_ref"])
+    g.setReference([], [], [], [], 1.0, [0.0, 0.0])
+    t0 = time.perf_counter(); n_dense = g.appendDenseReference(p["depth_new"], KRKi, Kt, 1, True, None, p["dI_ref"]); t1 = time.perf_counter()
+    g.close()
+    n = len(p["pc_u"])
+    res = dict(points=n, calc_res_ms=t_res, calc_g_ms=t_g, gauss_newton_iterations_per_s=1e3 / (t_res + t_g),
+               hbm_gbps=dict(calc_res=n * 4.0 * (4 + 7) / (t_res * 1e-3) / 1e9, calc_g=n * 4.0 * 8 / (t_g * 1e-3) / 1e9),
+               dense_handoff_ms_incl_uploads=1e3 * (t1 - t0), dense_points=n_dense,
+               note="each call ends with a stream synchronise + 7/45-double D2H, as the reference's does; launch/sync latency bound")
+    if not args.no_cpu:
+        from oracle.tracker_oracle import TrackerOracle
+        o = TrackerOracle(W, H, 9.0, 20.0)
+        o.setK(p["fx"], p["fy"], p["cx"], p["cy"])
+        o.setReference(p["pc_u"], p["pc_v"], p["pc_idepth"], p["pc_color"], 1.0, [0.0, 0.0])
+        o.setNew(p["dI_new"])
+        t0 = time.perf_counter()
+        for _ in range(5):
+            o.calcRes(p["refToNew"], 1.0, [0.0, 0.0], 20.0); o.calcG(1.0, [0.0, 0.0])
+        res["cpu_baseline"] = dict(value=5.0 / (time.perf_counter() - t0), unit="gauss-newton iterations/s", cores=1, kind="port",
+                                   sample="5 x (calcRes + calcG) over the same 307200 points, single-threaded C restatement (oracle/tracker_oracle.c)")
+    return res
+
+
 def view_shard_leg(args, rank, dev, world):
     """BASELINE configs[2]: ONE 7-view window, its source views sharded over the ranks, one RCCL sum all-reduce of the
     fp32 cost volume per cascade stage (tandem_amd/view_shard.py).  Reported next to the replicas headline, never as it:
@@ -243,6 +296,7 @@ def main():
 
     mv = mvsnet_leg(args, rank, local_rank, world)
     ts = None if args.no_tsdf else tsdf_leg(args, rank, local_rank, world)
+    tr = tracker_leg(args, local_rank) if (rank == 0 and not args.no_tsdf) else None
     vs = None
     if world > 1 and not args.no_view_shard:
         vs = view_shard_leg(args, rank, local_rank, world)
@@ -265,6 +319,8 @@ def main():
                 out[k] = mv[k]
         if ts is not None:
             out["tsdf"] = ts
+        if tr is not None:
+            out["tracker"] = tr
         if vs is not None:
             out["view_sharded"] = vs
         print(json.dumps(out))
