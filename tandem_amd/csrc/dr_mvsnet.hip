@@ -120,6 +120,9 @@ class MvsEngine {
     if (hipGetDeviceCount(&n) != hipSuccess || n <= device) fail(DR_ERR_DEVICE, "DrMvsnet: no HIP device %d (found %d) -- the MI355X path has no CPU fallback", device, n);
     DR_HIP(hipSetDevice(device_));
     DR_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    DR_HIP(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
+    for (auto *e : {&ev_fork_, &ev_feat2_, &ev_feat3_}) DR_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    side_enabled_ = !getenv("DR_MVS_NO_SIDE_STREAM");
     std::vector<float> lut(256);
     for (int i = 0; i < 256; ++i) lut[i] = (float)((double)(float)i / 255.0);
     lut_ = consts_.upload(lut);
@@ -138,6 +141,9 @@ class MvsEngine {
     release();
     if (h_out_) (void)hipHostFree(h_out_);
     if (h_in_) (void)hipHostFree(h_in_);
+    (void)hipStreamSynchronize(side_);
+    for (auto e : {ev_fork_, ev_feat2_, ev_feat3_}) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(side_);
     (void)hipStreamDestroy(stream_);
   }
 
@@ -423,10 +429,13 @@ class MvsEngine {
     DevTensor &c1b = cbr2("fn.conv2.1", fn + "conv2.1", c1a, 3, 1, CONV_NORMAL);
     DevTensor &c1 = cbr2("fn.conv2.2", fn + "conv2.2", c1b, 3, 1, CONV_NORMAL);
     add_conv("fn.out1", fn + "out.stage1", "", false, false, c1, "feat1", 1, 1, 1, 1, 1, 1, false, CONV_NORMAL, nullptr, 0);
+    fork_lo_ = ops_.size();
     DevTensor &i2 = add_conv("fn.skip2", fn + "skip.stage2", "", true, false, c2, "inter2", 1, 1, 1, 1, 1, 1, false, CONV_NORMAL, &c1, 2);
     add_conv("fn.out2", fn + "out.stage2", "", false, false, i2, "feat2", 1, 3, 3, 1, 1, 1, false, CONV_NORMAL, nullptr, 0);
+    feat2_op_ = ops_.size() - 1;
     DevTensor &i3 = add_conv("fn.skip3", fn + "skip.stage3", "", true, false, c3, "inter3", 1, 1, 1, 1, 1, 1, false, CONV_NORMAL, &i2, 2);
     add_conv("fn.out3", fn + "out.stage3", "", false, false, i3, "feat3", 1, 3, 3, 1, 1, 1, false, CONV_XPAIR, nullptr, 0);
+    fork_hi_ = ops_.size();
 
     for (int s = 1; s <= 3; ++s) {
       const int sc = 1 << (3 - s), h = H / sc, w = W / sc, D = blob_.depth_num[s - 1], C = 32 >> (s - 1);
@@ -562,12 +571,23 @@ class MvsEngine {
 
   // Enqueue one complete forward on stream_ (or the ops [first, last) of it).  ev (optional): ops_.size()+1 events
   // for per-op timing.
+  //
+  // A whole forward (no per-op events, no range) forks: the FeatureNet heads that only stages 2 and 3 need
+  // (fn.skip2, fn.out2, fn.skip3, fn.out3 -- 0.5 ms at 640x480) run on a side stream under stage 1's cost volume and
+  // regularisation, whose coarse UNet levels leave most CUs idle; stage 2 / 3's cost volume waits for feat2 / feat3.
+  // The next forward's main-stream work is ordered after those waits, so the side stream never runs ahead of a reader.
   void forward(std::vector<hipEvent_t> *ev, size_t first = 0, size_t last = ~(size_t)0) {
+    const bool fork = side_enabled_ && !ev && first == 0 && last >= ops_.size() && fork_lo_ < fork_hi_;
     size_t i = 0;
     for (const Op &o : ops_) {
       if (ev) DR_HIP(hipEventRecord((*ev)[i], stream_));
       ++i;
       if (i - 1 < first || i - 1 >= last) continue;
+      const bool on_side = fork && i - 1 >= fork_lo_ && i - 1 < fork_hi_;
+      if (fork && i - 1 == fork_lo_) { DR_HIP(hipEventRecord(ev_fork_, stream_)); DR_HIP(hipStreamWaitEvent(side_, ev_fork_, 0)); }
+      if (fork && o.kind == Op::COSTVOL && o.stage == 2) DR_HIP(hipStreamWaitEvent(stream_, ev_feat2_, 0));
+      if (fork && o.kind == Op::COSTVOL && o.stage == 3) DR_HIP(hipStreamWaitEvent(stream_, ev_feat3_, 0));
+      hipStream_t stream_ = on_side ? side_ : this->stream_;  // shadows the member for the launches below
       switch (o.kind) {
         case Op::PREPROCESS: {
           const size_t npix = (size_t)V_ * H_ * W_;
@@ -575,7 +595,11 @@ class MvsEngine {
                              reinterpret_cast<float4 *>(T("image").d), lut_, npix);
           break;
         }
-        case Op::CONV: launch_conv(o.conv, stream_); break;
+        case Op::CONV:
+          launch_conv(o.conv, stream_);
+          if (on_side && i - 1 == feat2_op_) DR_HIP(hipEventRecord(ev_feat2_, side_));
+          if (on_side && i - 1 == fork_hi_ - 1) DR_HIP(hipEventRecord(ev_feat3_, side_));
+          break;
         case Op::PROB:
         {
           const int zchunk = o.d0 >= 32 ? 8 : (o.d0 >= 8 ? 4 : o.d0);
@@ -616,6 +640,11 @@ class MvsEngine {
     if (ev) DR_HIP(hipEventRecord((*ev)[i], stream_));
     DR_HIP(hipGetLastError());
   }
+
+  hipStream_t side_ = nullptr;
+  hipEvent_t ev_fork_ = nullptr, ev_feat2_ = nullptr, ev_feat3_ = nullptr;
+  bool side_enabled_ = true;
+  size_t fork_lo_ = 0, fork_hi_ = 0, feat2_op_ = 0;  // ops [fork_lo_, fork_hi_) = fn.skip2 .. fn.out3
 
   int device_;
   Blob blob_;
