@@ -4,8 +4,8 @@
 //   HashTable / Heap        tsdfvh/hash_table.cu, heap.cu  -> lock-free open-addressing table keyed by the
 //                                                           packed block coordinate (64-bit CAS), bump pool
 //   AllocateFromDepthKernel tsdfvh/tsdf_volume.cu:317-434 -> k_allocate   (one lane per pixel, DDA)
-//   IntegrateScanKernel     tsdfvh/tsdf_volume.cu:436-513 -> k_integrate  (one 512-thread workgroup per
-//                                                           ALLOCATED block, one voxel per lane, coalesced 4 KB)
+//   IntegrateScanKernel     tsdfvh/tsdf_volume.cu:436-513 -> k_integrate  (one 64-lane wave per ALLOCATED block,
+//                                                           8 voxels per lane, coalesced 4 KB block read-modify-write)
 //   GenerateRgbDepthKernel  tsdfvh/tsdf_volume.cu:600-632 -> k_raycast    (one lane per pixel, sphere tracing)
 //   TsdfVolume::{IntegrateScanAsync,RenderAsync,GetRenderResult}  tsdf_volume.cu:515-737 -> FusionEngine
 //   MeshExtractor / ExtractMeshAsync / GetMeshSync  marching_cubes/mesh_extractor.cu, tsdf_volume.cu:739-838

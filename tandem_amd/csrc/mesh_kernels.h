@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void k_mc_cells(const FusionDev d, const McArg
   __shared__ int rng[3][2];
   __shared__ unsigned wsum[4];
   __shared__ unsigned run_base;
+  __shared__ float sdist[EMIT ? 8 : 1][EMIT ? 256 : 1];  // emit pass: corner values, indexed by a RUNTIME corner id (keeps them out of scratch)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bi = blockIdx.x;
   const I3 B = unpack_key(a.sorted_keys[bi]);
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void k_mc_cells(const FusionDev d, const McArg
     const int cell = base + tid;
     unsigned ntri = 0;
     unsigned long long row = ~0ull;
-    F3 p[8];
+    float qx[2] = {0.f, 0.f}, qy[2] = {0.f, 0.f}, qz[2] = {0.f, 0.f};  // corner positions per axis (c = 0: -half voxel, 1: +half)
     float dist[8];
     Voxel cv;
     if (cell < ncell) {
@@ -140,10 +141,10 @@ __global__ __launch_bounds__(256) void k_mc_cells(const FusionDev d, const McArg
       const McAxis X = a.ax[0][gx0 + cx], Y = a.ax[1][gy0 + cy], Z = a.ax[2][gz0 + cz];
       // cube corners in Bourke order v0..v7 = p010 p110 p100 p000 p011 p111 p101 p001 (mesh_extractor.cu:192-199)
       bool ok = true;
+      qx[0] = X.q[0]; qx[1] = X.q[1]; qy[0] = Y.q[0]; qy[1] = Y.q[1]; qz[0] = Z.q[0]; qz[1] = Z.q[1];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int sx = (k == 1 || k == 2 || k == 5 || k == 6), sy = (k == 0 || k == 1 || k == 4 || k == 5), sz = k >> 2;
-        p[k].x = X.q[sx]; p[k].y = Y.q[sy]; p[k].z = Z.q[sz];
         float acc = 0.0f;
         if (ok) {
           const float wx = X.w[sx], wy = Y.w[sy], wz = Z.w[sz];
@@ -171,6 +172,8 @@ __global__ __launch_bounds__(256) void k_mc_cells(const FusionDev d, const McArg
       }
     }
     if (!EMIT) { my_total += ntri; continue; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sdist[k][tid] = dist[k];  // own column only: no barrier needed
     // deterministic order inside the block: exclusive scan of ntri over the 256 cells of this round
     unsigned incl = ntri;
 #pragma unroll
@@ -188,7 +191,11 @@ __global__ __launch_bounds__(256) void k_mc_cells(const FusionDev d, const McArg
       for (int k = 0; k < 3; ++k) {
         const int e = (int)((row >> (4 * (i + k))) & 15);
         const int c1 = kMcEdgeCorner[e][0], c2 = kMcEdgeCorner[e][1];
-        const F3 r = mc_vertex_pos(p[c1], p[c2], dist[c1], dist[c2]);
+        // corner k sits at (+x for k in {1,2,5,6}, +y for k in {0,1,4,5}, +z for k >= 4): bit tables 0x66 / 0x33
+        F3 p1, p2;
+        p1.x = ((0x66 >> c1) & 1) ? qx[1] : qx[0]; p1.y = ((0x33 >> c1) & 1) ? qy[1] : qy[0]; p1.z = (c1 >> 2) ? qz[1] : qz[0];
+        p2.x = ((0x66 >> c2) & 1) ? qx[1] : qx[0]; p2.y = ((0x33 >> c2) & 1) ? qy[1] : qy[0]; p2.z = (c2 >> 2) ? qz[1] : qz[0];
+        const F3 r = mc_vertex_pos(p1, p2, sdist[c1][tid], sdist[c2][tid]);
         vv[3 * k] = r.x; vv[3 * k + 1] = r.y; vv[3 * k + 2] = r.z;
         cc[3 * k] = (float)cv.c[2] / 255.f;  // GetMeshSync swaps BGR -> RGB (tsdf_volume.cu:810-812)
         cc[3 * k + 1] = (float)cv.c[1] / 255.f;
