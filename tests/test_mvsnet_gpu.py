@@ -193,3 +193,64 @@ def test_ref_index_and_view_order(trained_blob):
     b = m.GetResult()
     assert np.array_equal(a.depth_dense, b.depth_dense) and np.array_equal(a.depth, b.depth)
     m.close()
+
+
+def test_maximum_views_large_frame_and_textureless_input(trained_blob):
+    """Edges of the supported range: view_num = 8 (kMaxSrc + 1), a 1280x960 frame (4x the headline size: every conv
+    plan, halo tile and cost-volume grid is re-derived), and a textureless window (all views one grey level: the cost
+    volume is exactly zero, every plane ties, depth = mean hypothesis) -- each against the oracle."""
+    from oracle import mvsnet_oracle as O, scene
+    from tandem_amd import weights as Wt
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    meta, tens = Wt.read_blob(trained_blob)
+    w = O.Weights(meta, tens)
+    m = DrMvsnet(trained_blob)
+    win = scene.make_window(64, 96, 8, seed=8)
+    m.CallAsync(64, 96, 8, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), 0.5, 5.0, 2.5)
+    compare(m.GetResult(), O.forward(w, win["bgrs"], win["K"], win["c2ws"], win["ref_index"], 0.5, 5.0, 2.5), "v8")
+    win = scene.make_window(960, 1280, 3, seed=9)
+    m.CallAsync(960, 1280, 3, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), win["depth_min"], win["depth_max"], 10.0)
+    compare(m.GetResult(), O.forward(w, win["bgrs"], win["K"], win["c2ws"], win["ref_index"], win["depth_min"], win["depth_max"], 10.0), "1280x960")
+    win = scene.make_window(64, 96, 3, seed=1)
+    grey = [np.full_like(b, 97) for b in win["bgrs"]]
+    m.CallAsync(64, 96, 3, win["ref_index"], grey, win["K"], list(win["c2ws"]), 0.5, 5.0, 2.5)
+    out = m.GetResult()
+    ref = O.forward(w, grey, win["K"], win["c2ws"], win["ref_index"], 0.5, 5.0, 2.5)
+    assert np.isfinite(out.depth_dense).all() and np.isfinite(out.confidence_dense).all()
+    assert np.abs(out.depth_dense - ref["depth_dense"]).max() < 2e-3
+    m.close()
+
+
+def test_concurrent_engines_give_the_sequential_answer(trained_blob):
+    """bench.py's throughput configuration: several DrMvsnet engines (own stream + worker each) running at once on
+    one GPU must each return exactly what they return alone."""
+    import threading
+    from oracle import scene
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    wins = [scene.make_window(96, 128, 5, seed=20 + i) for i in range(3)]
+    alone = []
+    for win in wins:
+        m = DrMvsnet(trained_blob)
+        m.CallAsync(96, 128, 5, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), 0.5, 5.0, 5.0)
+        alone.append(m.GetResult())
+        m.close()
+    engines = [DrMvsnet(trained_blob) for _ in wins]
+    outs = [None] * len(wins)
+
+    def work(i):
+        for _ in range(4):
+            win = wins[i]
+            engines[i].CallAsync(96, 128, 5, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), 0.5, 5.0, 5.0)
+            outs[i] = engines[i].GetResult()
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(wins))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for a, b in zip(alone, outs):
+        assert np.array_equal(a.depth_dense.view(np.uint32), b.depth_dense.view(np.uint32))
+        assert np.array_equal(a.depth.view(np.uint32), b.depth.view(np.uint32))
+        assert np.array_equal(a.confidence_dense.view(np.uint32), b.confidence_dense.view(np.uint32))
+    for e in engines:
+        e.close()
