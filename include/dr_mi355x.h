@@ -70,6 +70,10 @@ int drm_upload(drm_t *h, int height, int width, int view_num, int ref_index, con
 /* Enqueue `iters` complete forwards (pre-process .. edge filter) of the resident window on the
  * engine stream; returns after a stream synchronise.  ms_total (may be NULL) = hipEvent time. */
 int drm_forward(drm_t *h, int iters, float *ms_total);
+/* Autotune the convolution plan of the resident window: time the first max_candidates tile/pass configurations of each
+ * layer's cost-model ranking on the device and keep the fastest.  before_ms / after_ms (may be NULL) = summed layer time.
+ * Opt-in: a tuned engine's results differ from an untuned one's at the 1e-7 level (fp32 accumulation order). */
+int drm_autotune(drm_t *h, int max_candidates, float *before_ms, float *after_ms);
 /* --- view sharding (BASELINE configs[2]): one source view (or a few) per GPU, the host sum-reduces the
  * partial cost volumes over the ranks (RCCL).  No reference counterpart: the reference has no inference-time
  * collective.  Protocol per rank: drm_set_view_shard(total source views of the window) -> drm_upload(sub-window =

@@ -298,6 +298,7 @@ inline std::vector<DimTaps> axis_classes(int k, int s, bool transposed, int in_s
 struct ConvPlanOut {
   std::vector<ConvLaunch> launches;
   int outD, outH, outW;
+  int ncand = 0;  // feasible (CI, PT, CT, tile) candidates the planner ranked
 };
 
 struct DeviceArena {  // owns small device buffers created while planning (weights, tables)
@@ -317,7 +318,8 @@ inline bool conv_instance_exists(int ci, int ct) {
 }
 
 inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in, int inD, int inH, int inW, int inC,
-                             float *out, const float *add, int add_mode, DeviceArena &arena) {
+                             float *out, const float *add, int add_mode, DeviceArena &arena, int rank = 0) {
+  // rank: which candidate of the cost model's ranking to build (0 = its choice); used by the engine's autotuner
   if (L.Cin % 4 != 0 || inC < L.Cin) fail(DR_ERR_ARG, "plan_conv: Cin=%d must be a multiple of 4 (tensor C=%d)", L.Cin, inC);
   auto cz = axis_classes(L.kd, L.sd, L.transposed, inD);
   auto cy = axis_classes(L.kh, L.sh, L.transposed, inH);
@@ -374,8 +376,10 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   static const int cand16[][3] = {{1, 1, 16}, {1, 2, 8}, {1, 4, 4}, {1, 8, 2}, {1, 16, 1}, {2, 1, 8}, {2, 2, 4},
                                   {2, 4, 2}, {2, 8, 1}, {4, 1, 4}, {4, 2, 2}, {4, 4, 1}, {8, 1, 2}, {8, 2, 1}, {16, 1, 1}};
   static const int cand4[][3] = {{1, 1, 4}, {1, 2, 2}, {1, 4, 1}, {2, 1, 2}, {2, 2, 1}, {4, 1, 1}};
-  double best = 1e300;
+  [[maybe_unused]] double best = 1e300;
   int CI = 0, PT = 0, CT = 0, TZ = 0, TY = 0, TXT = 0, TZI = 0, TYI = 0, TXI = 0;
+  struct Cand { double cost; int ci, pt, ct, tz, ty, txt, tzi, tyi, txi; };
+  std::vector<Cand> cands;
   for (int ci : {16, 8, 4}) {
     if (L.Cin % ci || (ci == 4 && L.Cin != 4)) continue;
     const int npass = L.Cin / ci, tpc = 16 / ci;
@@ -405,10 +409,16 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
           const double waves = std::ceil(n_wg * ncls / (256.0 * wg_per_cu));
           const double thr = (mfma_total + stage_total) / 256.0 / (wg_per_cu >= 2 ? 0.8 : 0.5);
           const double cost = std::max(thr, waves * lat_wg);
-          if (cost < best) { best = cost; CI = ci; PT = pt; CT = ct; TZ = c[0]; TY = c[1]; TXT = c[2]; TZI = tzi; TYI = tyi; TXI = txi; }
+          cands.push_back({cost, ci, pt, ct, c[0], c[1], c[2], tzi, tyi, txi});
         }
       }
     }
+  }
+  if (!cands.empty()) {
+    std::stable_sort(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) { return a.cost < b.cost; });
+    const Cand &k = cands[std::min<size_t>(rank < 0 ? 0 : rank, cands.size() - 1)];
+    best = k.cost; CI = k.ci; PT = k.pt; CT = k.ct; TZ = k.tz; TY = k.ty; TXT = k.txt; TZI = k.tzi; TYI = k.tyi; TXI = k.txi;
+    R.ncand = (int)cands.size();
   }
   if (!CI) fail(DR_ERR_ARG, "plan_conv: no kernel instance / tile shape for Cin=%d Cout=%d", L.Cin, L.Cout);
   const int npass = L.Cin / CI, TPC = 16 / CI, CIS = CI + 4;

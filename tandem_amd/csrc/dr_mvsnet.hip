@@ -9,6 +9,7 @@
 // CallAsync blocks only while the previous input is still unprocessed.
 #include <cmath>
 #include <condition_variable>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -109,6 +110,8 @@ struct Op {
   int d0 = 0, d1 = 0, d2 = 0;
   std::string name;
   ConvLaunch conv;
+  std::function<ConvLaunch(int)> replan;  // CONV only: build candidate `rank` of the planner's ranking
+  int ncand = 0;
   int stage = 0, shift = 0, bits = 0;
   double flops = 0, bytes = 0;
 };
@@ -198,6 +201,49 @@ class MvsEngine {
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (ms) *ms = t;
   }
+  // Time the first `k` candidates of every convolution layer's plan ranking in place (hipEvents, layer alone on the
+  // stream) and keep the fastest.  Different candidates tile and order the fp32 accumulation differently, so results
+  // move at the 1e-7 level; a tuned engine is therefore only bit-reproducible against an equally tuned one.
+  // Returns the summed layer time before / after (ms).
+  void autotune(int k, float *before_ms, float *after_ms) {
+    std::unique_lock<std::mutex> lk(mu_);
+    require_config();
+    DR_HIP(hipSetDevice(device_));
+    hipEvent_t e0, e1;
+    DR_HIP(hipEventCreate(&e0)); DR_HIP(hipEventCreate(&e1));
+    auto time_launch = [&](const ConvLaunch &c) {
+      for (int i = 0; i < 2; ++i) launch_conv(c, stream_);
+      DR_HIP(hipEventRecord(e0, stream_));
+      for (int i = 0; i < 8; ++i) launch_conv(c, stream_);
+      DR_HIP(hipEventRecord(e1, stream_));
+      DR_HIP(hipEventSynchronize(e1));
+      float t = 0;
+      DR_HIP(hipEventElapsedTime(&t, e0, e1));
+      return t / 8;
+    };
+    double t_before = 0, t_after = 0;
+    const bool print = getenv("DR_CONV_PRINT") != nullptr;
+    for (Op &o : ops_) {
+      if (o.kind != Op::CONV || !o.replan) continue;
+      const float t0 = time_launch(o.conv);
+      float best = t0;
+      int best_rank = 0;
+      ConvLaunch best_c = o.conv;
+      for (int r = 1; r < std::min(k, o.ncand); ++r) {
+        const ConvLaunch c = o.replan(r);
+        const float t = time_launch(c);
+        if (t < best * 0.98f) { best = t; best_rank = r; best_c = c; }
+      }
+      if (print) fprintf(stderr, "autotune %-12s model %.4f ms <%d,%d,%d> -> rank %d %.4f ms <%d,%d,%d> tile %dx%dx%d\n", o.name.c_str(), t0, o.conv.ci, o.conv.ct,
+                         o.conv.pt, best_rank, best, best_c.ci, best_c.ct, best_c.pt, best_c.args.TZ, best_c.args.TY, best_c.args.TXT * 16);
+      o.conv = best_c;
+      t_before += t0; t_after += best;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (before_ms) *before_ms = (float)t_before;
+    if (after_ms) *after_ms = (float)t_after;
+  }
+
   // ---- view sharding hooks (SURVEY 8e / BASELINE configs[2]; no reference counterpart) ----
   // Phase p = 0..3 of the uploaded window: [.. cost volume 1] [regularise 1 .. cost volume 2] [.. cost volume 3]
   // [regularise 3 .. edge filter].  Between phases the host sum-reduces "volume<p+1>" over the ranks.
@@ -382,9 +428,20 @@ class MvsEngine {
     }
     DevTensor &out = alloc(outname, P0.outD, P0.outH, P0.outW, c_out);
     ConvPlanOut P = plan_conv(L, mode, in.d, in.D, in.H, in.W, in.C, out.d, add ? add->d : nullptr, add_mode, *plan_arena_);
+    // the autotuner re-plans this layer with another candidate of the cost model's ranking (weights are kept alive)
+    auto keep = std::make_shared<std::vector<float>>(L.weight, L.weight + (size_t)L.Cout * L.Cin * k3d * kh * kw);
+    ConvLayer Lc = L;
+    const float *in_d = in.d, *add_d = add ? add->d : nullptr;
+    float *out_d = out.d;
+    const int iD = in.D, iH = in.H, iW = in.W, iC = in.C, ncand = P.ncand;
+    auto replan = [this, keep, Lc, mode, in_d, iD, iH, iW, iC, out_d, add_d, add_mode](int rank) mutable {
+      Lc.weight = keep->data();
+      return plan_conv(Lc, mode, in_d, iD, iH, iW, iC, out_d, add_d, add_mode, *plan_arena_, rank).launches.at(0);
+    };
     int idx = 0;
     for (auto &cl : P.launches) {
       Op o; o.kind = Op::CONV; o.conv = cl; o.name = opname + (P.launches.size() > 1 ? "." + std::to_string(idx) : "");
+      if (P.launches.size() == 1) { o.replan = replan; o.ncand = ncand; }
       o.flops = cl.flops;
       if (idx == 0) o.bytes = 4.0 * (in.n() + out.n() + (add ? (add_mode == 2 ? add->n() : out.n()) : 0));
       ops_.push_back(o);
@@ -709,6 +766,9 @@ int drm_upload(drm_t *h, int height, int width, int view_num, int ref_index, con
   return guarded([&] { h->e->upload(height, width, view_num, ref_index, bgrs, K9, c2ws, depth_min, depth_max, discard_percentage); });
 }
 int drm_forward(drm_t *h, int iters, float *ms_total) { return guarded([&] { h->e->forward_n(iters, ms_total); }); }
+int drm_autotune(drm_t *h, int max_candidates, float *before_ms, float *after_ms) {
+  return guarded([&] { h->e->autotune(max_candidates, before_ms, after_ms); });
+}
 int drm_set_view_shard(drm_t *h, int nsrc_total) { return guarded([&] { h->e->set_view_shard(nsrc_total); }); }
 int drm_forward_phase(drm_t *h, int phase) { return guarded([&] { h->e->forward_phase(phase); }); }
 int drm_device_tensor(drm_t *h, const char *name, void **dptr, size_t *nfloats) {

@@ -81,6 +81,13 @@ class DrMvsnet:
         check(_lib.lib().drm_forward(self._h, iters, C.byref(ms)))
         return ms.value
 
+    def autotune(self, max_candidates=8):
+        """Time the planner's top candidates per convolution layer on the device and keep the fastest (opt-in; results
+        move at the 1e-7 level).  Returns (summed layer ms before, after)."""
+        a, b = C.c_float(), C.c_float()
+        check(_lib.lib().drm_autotune(self._h, max_candidates, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     # ---- view sharding hooks (include/dr_mi355x.h "view sharding"; host protocol in tandem_amd/view_shard.py) ----
     def set_view_shard(self, nsrc_total):
         check(_lib.lib().drm_set_view_shard(self._h, int(nsrc_total)))
