@@ -155,6 +155,9 @@ int drf_mesh_num_triangles(drf_t *h, size_t *ntri);
 /* DrFusion::SaveMeshToFile(filename, lower, upper)                dr_fusion.h:56, dr_fusion.cpp:74-93, mesh.cu:24-66
  * Synchronous extraction written as Wavefront OBJ: "v x y z r g b" per vertex, "f i i+1 i+2" per triangle. */
 int drf_save_mesh(drf_t *h, const char *filename, const float lower[3], const float upper[3]);
+/* Device pointers of render stream `stream`'s result (H*W*3 u8 BGR, H*W f32 depth), valid from drf_get_render_result
+ * until the next drf_render_async; no reference counterpart.  Feeds drt_append_dense_reference(on_device = 1). */
+int drf_get_render_device(drf_t *h, int stream, const uint8_t **d_bgr, const float **d_depth);
 /* DrFusion::Synchronize()                                        dr_fusion.h:64 */
 int drf_synchronize(drf_t *h);
 

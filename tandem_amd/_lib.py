@@ -68,6 +68,7 @@ SIGNATURES = {
     "drf_get_mesh_sync": (C.c_int, [vp, C.c_size_t, C.POINTER(C.c_size_t), f32p, f32p]),
     "drf_mesh_num_triangles": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
     "drf_save_mesh": (C.c_int, [vp, C.c_char_p, f32p, f32p]),
+    "drf_get_render_device": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp)]),
     "drf_synchronize": (C.c_int, [vp]),
     "drf_stats": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "drf_export_blocks": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int32), u8p, C.POINTER(C.c_int)]),

@@ -530,6 +530,15 @@ class FusionEngine {
     }
     check_device_flags();
   }
+  // Device-resident result of render stream i (the buffers GetRenderResult copies from): valid from GetRenderResult
+  // until the next RenderAsync.  Lets a consumer on the same GPU (the coarse tracker's dense-depth hand-off) skip the
+  // D2H + H2D round trip.
+  void get_render_device(int i, const uint8_t **d_bgr, const float **d_depth) {
+    if (i < 0 || i >= (int)renders_.size()) fail(DR_ERR_ARG, "get_render_device: stream %d of %zu", i, renders_.size());
+    if (next_ != kIntegrate) fail(DR_ERR_PROTOCOL, "get_render_device: call after GetRenderResult");
+    if (d_bgr) *d_bgr = renders_[i].d_bgr;
+    if (d_depth) *d_depth = renders_[i].d_depth;
+  }
   void synchronize() {
     DR_HIP(hipSetDevice(device_));
     DR_HIP(hipDeviceSynchronize());
@@ -795,6 +804,9 @@ int drf_mesh_num_triangles(drf_t *h, size_t *ntri) {
 }
 int drf_save_mesh(drf_t *h, const char *filename, const float *lower, const float *upper) {
   return guarded([&] { h->e->save_mesh(filename, lower, upper); });
+}
+int drf_get_render_device(drf_t *h, int stream, const uint8_t **d_bgr, const float **d_depth) {
+  return guarded([&] { h->e->get_render_device(stream, d_bgr, d_depth); });
 }
 int drf_synchronize(drf_t *h) { return guarded([&] { h->e->synchronize(); }); }
 int drf_stats(drf_t *h, uint64_t out[4]) { return guarded([&] { h->e->stats(out); }); }

@@ -88,6 +88,12 @@ class DrFusion:
         lo, up = (np.ascontiguousarray(a, np.float32) for a in (lower_corner, upper_corner))
         check(_lib.lib().drf_save_mesh(self._h, str(filename).encode(), fptr(lo), fptr(up)))
 
+    def render_device_pointers(self, stream=0):
+        """(d_bgr, d_depth) device pointers of a render stream's result, valid until the next RenderAsync."""
+        b, d = C.c_void_p(), C.c_void_p()
+        check(_lib.lib().drf_get_render_device(self._h, stream, C.byref(b), C.byref(d)))
+        return b.value, d.value
+
     def Synchronize(self):
         check(_lib.lib().drf_synchronize(self._h))
 

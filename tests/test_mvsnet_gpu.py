@@ -254,3 +254,20 @@ def test_concurrent_engines_give_the_sequential_answer(trained_blob):
         assert np.array_equal(a.confidence_dense.view(np.uint32), b.confidence_dense.view(np.uint32))
     for e in engines:
         e.close()
+
+
+def test_autotuned_plan_stays_within_tolerance(trained_blob):
+    """drm_autotune swaps convolution tilings by measured time; the result may move by accumulation order only."""
+    from oracle import mvsnet_oracle as O, scene
+    from tandem_amd import weights as Wt
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    meta, tens = Wt.read_blob(trained_blob)
+    win = scene.make_window(96, 128, 5, seed=31)
+    ref = O.forward(O.Weights(meta, tens), win["bgrs"], win["K"], win["c2ws"], win["ref_index"], 0.5, 5.0, 5.0)
+    m = DrMvsnet(trained_blob)
+    m.upload(96, 128, 5, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), 0.5, 5.0, 5.0)
+    before, after = m.autotune(12)
+    assert 0 < after <= before * 1.0001
+    m.forward(1)
+    compare(m.download(), ref, "autotuned")
+    m.close()

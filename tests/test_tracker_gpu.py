@@ -144,3 +144,50 @@ def test_device_pointers_protocol_and_capacity():
     with pytest.raises(_lib.DrError, match="Did not start before"):
         g.endTimingMilliseconds()
     g.close()
+
+
+def test_render_to_tracker_handoff_stays_on_the_device():
+    """SURVEY 8(f) row 3 end to end: DrFusion renders the fused map for the keyframe pose, the tracker appends the
+    dense reference points straight from the render's device buffer -- same list as through the host copy."""
+    from oracle import scene
+    from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
+    from tandem_amd.dr_tracker import DrCoarseTracker
+    H, W = 96, 128
+    sc = scene.make_scans(3, H, W, seed=4)
+    f = DrFusion(DrFusionOptions(voxel_size=0.02, num_buckets=40000, bucket_size=10, num_blocks=40000, block_size=8, max_sdf_weight=64,
+                                 truncation_distance=0.08, max_sensor_depth=10.0, min_sensor_depth=0.1, num_render_streams=1,
+                                 fx=sc["fx"], fy=sc["fy"], cx=sc["cx"], cy=sc["cy"], height=H, width=W))
+    for bgr, depth, pose in sc["scans"]:
+        f.IntegrateScanAsync(bgr, depth, pose)
+        f.RenderAsync([pose])
+        rb, rd = f.GetRenderResult()
+    _, d_depth = f.render_device_pointers(0)
+    dI = np.zeros((H, W, 3), np.float32)
+    dI[..., 0] = rb[0].mean(axis=2)
+    K = np.array([[sc["fx"], 0, sc["cx"]], [0, sc["fy"], sc["cy"]], [0, 0, 1]], np.float32)
+    T = np.linalg.inv(sc["scans"][1][2].astype(np.float64)) @ sc["scans"][2][2].astype(np.float64)  # render frame -> tracker frame
+    KRKi = (K @ T[:3, :3].astype(np.float32)) @ np.linalg.inv(K.astype(np.float64)).astype(np.float32)
+    Kt = K @ T[:3, 3].astype(np.float32)
+    lists = []
+    for use_device in (False, True):
+        g = DrCoarseTracker(W, H, 9.0, 20.0)
+        g.setK(W, H, sc["fx"], sc["fy"], sc["cx"], sc["cy"])
+        g.init()
+        g.setReference([], [], [], [], 1.0, [0, 0])
+        if use_device:
+            import ctypes as C
+            from tandem_amd import _lib
+            a = np.ascontiguousarray(dI)
+            d_dip = C.c_void_p()
+            _lib.check(_lib.lib().dr_device_alloc(0, a.nbytes, C.byref(d_dip)))
+            _lib.check(_lib.lib().dr_memcpy_h2d(d_dip, a.ctypes.data_as(C.c_void_p), a.nbytes))
+            n = g.appendDenseReference(d_depth, KRKi, Kt, 1, True, None, d_dip.value, device_pointers=True)
+            _lib.check(_lib.lib().dr_device_free(d_dip))
+        else:
+            n = g.appendDenseReference(rd[0], KRKi, Kt, 1, True, None, dI)
+        assert n > 2000
+        lists.append([a.copy() for a in g.points()])
+        g.close()
+    for a, b in zip(*lists):
+        assert np.array_equal(bits(a), bits(b))
+    f.close()
