@@ -114,8 +114,9 @@ __global__ __launch_bounds__(kConvThreads) void k_conv(const ConvArgs a) {
       for (int k = 0; k < kStageBatch; ++k) {
         const unsigned e = e0 + k * kConvThreads + tid;
         const unsigned pos = e / C4, c4 = e - pos * C4;
-        const unsigned t = __umulhi(pos, a.magicX), x = pos - t * a.TXI;   // exact for pos < 2^16
-        const unsigned z = __umulhi(t, a.magicY), y = t - z * a.TYI;
+        // exact for pos < 2^16; a divisor of 1 has no 32-bit magic (2^32), the host stores 0 for it
+        const unsigned t = a.magicX ? __umulhi(pos, a.magicX) : pos, x = pos - t * a.TXI;
+        const unsigned z = a.magicY ? __umulhi(t, a.magicY) : t, y = t - z * a.TYI;
         const int gz = iz0 + (int)z, gy = iy0 + (int)y, gx = ix0 + (int)x;
         v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         dst[k] = e < total ? (int)(pos * CIS + c4 * 4) : -1;
@@ -313,6 +314,13 @@ struct DeviceArena {  // owns small device buffers created while planning (weigh
   ~DeviceArena() { for (void *p : ptrs) (void)hipFree(p); }
 };
 
+// Measured-best plans for known layer shapes (tools/tune_conv.sh -> conv_tuned.h); anything else uses the cost model.
+struct ConvTuned {
+  int Cin, Cout, kd, kh, kw, sd, sh, sw, transposed, mode, inD, inH, inW;  // layer signature
+  int ci, ct, pt, tz, ty, txt;                                              // plan: channel pass, row tiles, position tiles per wave, tile shape (txt in 16s)
+};
+#include "conv_tuned.h"
+
 inline bool conv_instance_exists(int ci, int ct) {
   return (ci == 4 && ct == 1) || ((ci == 8 || ci == 16) && (ct == 1 || ct == 2 || ct == 4));
 }
@@ -416,6 +424,17 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   }
   if (!cands.empty()) {
     std::stable_sort(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) { return a.cost < b.cost; });
+    if (rank == 0 && !getenv("DR_CONV_NO_TUNED")) {  // a measured plan for exactly this layer moves to the front
+      for (const ConvTuned &t : kConvTuned) {
+        if (t.Cin != L.Cin || t.Cout != L.Cout || t.kd != L.kd || t.kh != L.kh || t.kw != L.kw || t.sd != L.sd || t.sh != L.sh || t.sw != L.sw ||
+            t.transposed != (L.transposed ? 1 : 0) || t.mode != (int)mode || t.inD != inD || t.inH != inH || t.inW != inW) continue;
+        for (size_t i = 0; i < cands.size(); ++i) {
+          const Cand &k = cands[i];
+          if (k.ci == t.ci && k.ct == t.ct && k.pt == t.pt && k.tz == t.tz && k.ty == t.ty && k.txt == t.txt) { std::swap(cands[0], cands[i]); break; }
+        }
+        break;
+      }
+    }
     const Cand &k = cands[std::min<size_t>(rank < 0 ? 0 : rank, cands.size() - 1)];
     best = k.cost; CI = k.ci; PT = k.pt; CT = k.ct; TZ = k.tz; TY = k.ty; TXT = k.txt; TZI = k.tzi; TYI = k.tyi; TXI = k.txi;
     R.ncand = (int)cands.size();
@@ -500,7 +519,8 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   a.omz = cz[0].om; a.omy = cy[0].om; a.omx = cx[0].om;
   a.par_rows = L.transposed ? L.Cout : 0; a.par_map = par_map;
   a.TZ = TZ; a.TY = TY; a.TXT = TXT; a.TZI = TZI; a.TYI = TYI; a.TXI = TXI;
-  a.magicX = (unsigned)((0x100000000ull + TXI - 1) / TXI); a.magicY = (unsigned)((0x100000000ull + TYI - 1) / TYI);
+  a.magicX = TXI == 1 ? 0u : (unsigned)((0x100000000ull + TXI - 1) / TXI);
+  a.magicY = TYI == 1 ? 0u : (unsigned)((0x100000000ull + TYI - 1) / TYI);
   if ((size_t)TZI * TYI * TXI >= 65536) fail(DR_ERR_ARG, "plan_conv: halo tile too large");
   a.npass = npass; a.ctTot = CTtot; a.rows_valid = rows_valid; a.relu = L.relu ? 1 : 0;
   a.add_mode = add ? add_mode : 0;

@@ -111,6 +111,7 @@ struct Op {
   std::string name;
   ConvLaunch conv;
   std::function<ConvLaunch(int)> replan;  // CONV only: build candidate `rank` of the planner's ranking
+  std::string sig;                        // CONV only: layer signature in conv_tuned.h's column order
   int ncand = 0;
   int stage = 0, shift = 0, bits = 0;
   double flops = 0, bytes = 0;
@@ -236,6 +237,9 @@ class MvsEngine {
       }
       if (print) fprintf(stderr, "autotune %-12s model %.4f ms <%d,%d,%d> -> rank %d %.4f ms <%d,%d,%d> tile %dx%dx%d\n", o.name.c_str(), t0, o.conv.ci, o.conv.ct,
                          o.conv.pt, best_rank, best, best_c.ci, best_c.ct, best_c.pt, best_c.args.TZ, best_c.args.TY, best_c.args.TXT * 16);
+      if (print && best_rank != 0)
+        fprintf(stderr, "TUNED    {%s,   %d, %d, %d, %d, %d, %d},  // %s %.4f -> %.4f ms\n", o.sig.c_str(), best_c.ci, best_c.ct, best_c.pt, best_c.args.TZ,
+                best_c.args.TY, best_c.args.TXT, o.name.c_str(), t0, best);
       o.conv = best_c;
       t_before += t0; t_after += best;
     }
@@ -441,7 +445,12 @@ class MvsEngine {
     int idx = 0;
     for (auto &cl : P.launches) {
       Op o; o.kind = Op::CONV; o.conv = cl; o.name = opname + (P.launches.size() > 1 ? "." + std::to_string(idx) : "");
-      if (P.launches.size() == 1) { o.replan = replan; o.ncand = ncand; }
+      if (P.launches.size() == 1) {
+        o.replan = replan; o.ncand = ncand;
+        char sig[160];
+        snprintf(sig, sizeof sig, "%d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d", L.Cin, L.Cout, k3d, kh, kw, sd, sh, sw, transposed ? 1 : 0, (int)mode, iD, iH, iW);
+        o.sig = sig;
+      }
       o.flops = cl.flops;
       if (idx == 0) o.bytes = 4.0 * (in.n() + out.n() + (add ? (add_mode == 2 ? add->n() : out.n()) : 0));
       ops_.push_back(o);
@@ -828,7 +837,9 @@ int drm_debug_conv(int device, const float *in, int D, int H, int W, int Cin, co
       std::vector<float> ha(add, add + an);
       d_add = arena.upload(ha);
     }
-    ConvPlanOut P = plan_conv(L, mode, d_in, D, H, W, Cin, d_out, d_add, add_up2 ? 2 : 1, arena);
+    // DR_CONV_RANK (test hook): build the rank-th candidate of the planner's ranking instead of its first choice
+    const char *rk = getenv("DR_CONV_RANK");
+    ConvPlanOut P = plan_conv(L, mode, d_in, D, H, W, Cin, d_out, d_add, add_up2 ? 2 : 1, arena, rk ? atoi(rk) : 0);
     for (auto &cl : P.launches) launch_conv(cl, nullptr);
     DR_HIP(hipDeviceSynchronize());
     DR_HIP(hipGetLastError());

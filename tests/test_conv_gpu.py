@@ -56,8 +56,7 @@ def torch_ref(x, w, stride, transposed, scale, bias, relu, add, add_mode):
     return y[0].permute(1, 2, 3, 0).contiguous().numpy()
 
 
-@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_conv_matches_torch(case):
+def run_case(case):
     from tandem_amd.dr_mvsnet import debug_conv
     name, dims, cin, cout, k, stride, transposed, relu, add_mode = case
     rng = np.random.RandomState(abs(hash(name)) % (2 ** 31))
@@ -81,3 +80,29 @@ def test_conv_matches_torch(case):
     err = np.abs(got - ref).max()
     tol = 2e-5 * max(1.0, np.abs(ref).max())  # fp32 reassociation only (MFMA fp32 == fmaf chain)
     assert err <= tol, f"{name}: max|err| {err:.3e} > {tol:.3e}"
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_matches_torch(case):
+    run_case(case)
+
+
+SWEEP = [
+    ("sweep 1x1 8->32 +up2, 7 views", (7, 16, 64), 8, 32, (1, 1, 1), (1, 1, 1), False, False, "up2"),
+    ("sweep 3x3 32->16", (3, 16, 32), 32, 16, (1, 3, 3), (1, 1, 1), False, False, "none"),
+    ("sweep 3x3x3 16->16", (10, 8, 32), 16, 16, (3, 3, 3), (1, 1, 1), False, True, "none"),
+    ("sweep 3x3x3 s2 8->16", (12, 16, 32), 8, 16, (3, 3, 3), (2, 2, 2), False, True, "none"),
+    ("sweep deconv 32->16 +skip", (5, 6, 16), 32, 16, (3, 3, 3), (2, 2, 2), True, True, "same"),
+]
+
+
+@pytest.mark.parametrize("case", SWEEP, ids=[c[0] for c in SWEEP])
+def test_every_plan_candidate_is_correct(case, monkeypatch):
+    """The planner ranks ~100 (channel pass, row tiles, position tiles, tile shape) candidates per layer and the
+    autotuner / conv_tuned.h may pick any of them: each must compute the same convolution (this sweep is what caught
+    the divisor-1 case of the halo decode: tiles with one input row but several planes)."""
+    for rank in range(0, 400, 1):
+        monkeypatch.setenv("DR_CONV_RANK", str(rank))
+        run_case(case)
+        if rank > 160:  # beyond the candidate count the last one repeats
+            break
