@@ -583,6 +583,7 @@ class MvsEngine {
       a.vol = T("volume" + std::to_string(s)).d;
       a.V = V; a.h = h; a.w = w;
       a.dchunk = s == 1 ? 4 : (D >= 16 ? 8 : D);  // enough workgroups to fill 256 CUs at every stage
+      if (const char *e = getenv(s == 1 ? "DR_CV_DCHUNK1" : (s == 2 ? "DR_CV_DCHUNK2" : "DR_CV_DCHUNK3"))) a.dchunk = std::max(1, std::min(D, atoi(e)));  // tuning hook
       a.view_aggregation = blob_.view_aggregation;
       // view sharding: this rank's window holds a subset of the source views, the divisor stays the whole window's
       if (shard_nsrc_ && !blob_.view_aggregation) fail(DR_ERR_UNSUPPORTED, "view sharding needs a view-aggregation model (the variance volume is not a sum over views)");
@@ -668,7 +669,11 @@ class MvsEngine {
           break;
         case Op::PROB:
         {
-          const int zchunk = o.d0 >= 32 ? 8 : (o.d0 >= 8 ? 4 : o.d0);
+          // z-march chunk: long chunks amortise the 2 halo planes, but the launch needs ~1000 waves to fill the chip
+          // (tools/gpu_sweep_chunks.sh: 48x120x160 -> 4, 32x240x320 -> 8, 8x480x640 -> 8)
+          int zchunk = std::min(o.d0, 8);
+          while (zchunk > 2 && cdiv(o.d1 * (o.d2 / 4), 64) * cdiv(o.d0, zchunk) < 800) zchunk /= 2;
+          if (const char *e = getenv("DR_PROB_ZCHUNK")) zchunk = std::max(1, std::min(o.d0, atoi(e)));  // tuning hook
           hipLaunchKernelGGL(k_prob, dim3(cdiv(o.d1 * (o.d2 / 4), 256), cdiv(o.d0, zchunk)), dim3(256), 0, stream_, o.p0, o.p1, o.p2,
                              o.d0, o.d1, o.d2, zchunk);
         }
