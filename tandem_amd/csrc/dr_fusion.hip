@@ -50,7 +50,9 @@ struct FusionDev {  // everything the kernels need, passed by value
   int *err;                  // [0] pool exhausted, [1] coordinate out of packing range
   unsigned long long *cnt;   // [0] voxels updated by the current scan, [1] total, [2] round-trip mismatches
   float *sd;                 // [H*W] per-pixel surface distance |GetPoint3d(i, depth)| of the current scan
+  unsigned *present;         // kPresentBits^3-bit map: bit set <=> that block is in the table (a cache of the table, no state)
 };
+constexpr int kPresentBits = 9;  // blocks within [-256, 256)^3 (+-10 m at 4 cm blocks): 16 MiB, L2/MALL resident
 
 // ---- CUDA float->int conversion semantics (cvt.rzi: saturate, NaN -> 0), see oracle header (4) ----
 __device__ inline int f2i(float f) {
@@ -126,13 +128,26 @@ __device__ inline int find_block(const FusionDev &d, I3 p) {
   return -1;
 }
 // Insert-if-absent (HashTable::AllocateBlock, hash_table.cu:80-115, without the try-lock drop).
+// The allocation DDA asks for ~60 blocks per pixel and, once a map exists, almost all of them are there already.  A
+// dense presence bitmap answers that with one load from a 16 MiB array instead of a probe into the (much larger) key
+// table; blocks outside its range, and first-time inserts, take the table path.
+__device__ inline bool present_index(I3 p, unsigned &idx) {
+  constexpr int H = 1 << (kPresentBits - 1);
+  const unsigned x = (unsigned)(p.x + H), y = (unsigned)(p.y + H), z = (unsigned)(p.z + H);
+  if ((x | y | z) >> kPresentBits) return false;
+  idx = (x << (2 * kPresentBits)) | (y << kPresentBits) | z;
+  return true;
+}
 __device__ inline void allocate_block(const FusionDev &d, I3 p) {
+  unsigned pidx = 0;
+  const bool in_map = present_index(p, pidx);
+  if (in_map && ((d.present[pidx >> 5] >> (pidx & 31)) & 1u)) return;
   unsigned long long key;
   if (!pack_key(p, key)) { d.err[1] = 1; return; }
   unsigned s = hash_key(key) & d.cmask;
   for (unsigned probe = 0; probe <= d.cmask; ++probe) {
     unsigned long long cur = __hip_atomic_load(&d.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cur == key) return;
+    if (cur == key) { if (in_map) atomicOr(&d.present[pidx >> 5], 1u << (pidx & 31)); return; }
     if (cur == kEmptyKey) {
       cur = atomicCAS(&d.keys[s], kEmptyKey, key);
       if (cur == kEmptyKey) {  // we own the slot: take a pool block
@@ -140,9 +155,10 @@ __device__ inline void allocate_block(const FusionDev &d, I3 p) {
         if (idx >= d.o.num_blocks) { d.err[0] = 1; d.vals[s] = -1; return; }
         d.vals[s] = idx;
         d.blk_key[idx] = key;
+        if (in_map) atomicOr(&d.present[pidx >> 5], 1u << (pidx & 31));
         return;
       }
-      if (cur == key) return;
+      if (cur == key) { if (in_map) atomicOr(&d.present[pidx >> 5], 1u << (pidx & 31)); return; }
     }
     s = (s + 1) & d.cmask;
   }
@@ -443,6 +459,8 @@ class FusionEngine {
     d_.err = d_.n_alloc + 1;
     d_.cnt = dalloc<unsigned long long>(4);
     d_.sd = dalloc<float>(npix_);
+    d_.present = dalloc<unsigned>((size_t)1 << (3 * kPresentBits - 5));
+    DR_HIP(hipMemsetAsync(d_.present, 0, (size_t)1 << (3 * kPresentBits - 3), int_stream_));
     hipLaunchKernelGGL(k_fill_keys, dim3(1024), dim3(256), 0, int_stream_, d_.keys, cap);
     DR_HIP(hipMemsetAsync(d_.vox, 0, (size_t)o.num_blocks * 512 * sizeof(Voxel), int_stream_));  // hash_table.cu:28-32
     DR_HIP(hipMemsetAsync(d_.n_alloc, 0, 16, int_stream_));
@@ -471,7 +489,7 @@ class FusionEngine {
     (void)hipSetDevice(device_);
     (void)hipDeviceSynchronize();
     (void)hipFree(d_.keys); (void)hipFree(d_.vals); (void)hipFree(d_.blk_key); (void)hipFree(d_.vox);
-    (void)hipFree(d_.n_alloc); (void)hipFree(d_.cnt); (void)hipFree(d_.sd); (void)hipFree(d_bgr_in_); (void)hipFree(d_depth_in_);
+    (void)hipFree(d_.n_alloc); (void)hipFree(d_.cnt); (void)hipFree(d_.sd); (void)hipFree(d_.present); (void)hipFree(d_bgr_in_); (void)hipFree(d_depth_in_);
     (void)hipHostFree(h_bgr_in_); (void)hipHostFree(h_depth_in_);
     for (auto &r : renders_) {
       (void)hipFree(r.d_bgr); (void)hipFree(r.d_depth);
