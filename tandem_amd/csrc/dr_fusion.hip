@@ -55,11 +55,13 @@ struct FusionDev {  // everything the kernels need, passed by value
 constexpr int kPresentBits = 9;  // blocks within [-256, 256)^3 (+-10 m at 4 cm blocks): 16 MiB, L2/MALL resident
 
 // ---- CUDA float->int conversion semantics (cvt.rzi: saturate, NaN -> 0), see oracle header (4) ----
+// v_cvt_i32_f32 IS that conversion (truncate, saturate, NaN -> 0: CDNA ISA "V_CVT_I32_F32"); written as inline asm
+// because a C cast leaves out-of-range inputs undefined for the optimiser.  tests/test_fusion_gpu.py holds the kernels
+// to the oracle's explicit branches bit for bit, out-of-range projections included.
 __device__ inline int f2i(float f) {
-  if (f != f) return 0;
-  if (f >= 2147483648.0f) return 2147483647;
-  if (f <= -2147483648.0f) return -2147483647 - 1;
-  return (int)f;
+  int r;
+  asm("v_cvt_i32_f32_e32 %0, %1" : "=v"(r) : "v"(f));
+  return r;
 }
 __device__ inline unsigned char f2u8(float f) {
   if (!(f > 0.0f)) return 0;
@@ -283,6 +285,63 @@ __global__ __launch_bounds__(256) void k_integrate(const FusionDev d, const unsi
     project(o, center, cx, cy);
     if (!(cx >= 0 && cy >= 0 && cx < o.width && cy < o.height)) continue;
     Voxel *blk_vox = d.vox + (size_t)e * (bs * bs * bs);
+    // UpdateVoxel's world -> cam -> world round trip (below) is, per voxel, the map  vp -> T*(Ti*vp)  = an affine map
+    // plus fp32 rounding noise (< 1e-4 m for |coordinates| < 64 m).  An affine deviation is extremal at the corners of
+    // the block's voxel lattice, so if its 8 corner voxels come back within 0.1 voxel of themselves, every voxel of the
+    // block comes back within 0.1 + noise/vs < 0.25 voxel, i.e. onto itself (see the per-voxel test's comment): the
+    // round trip is then skipped for the whole block.  Lanes 0..7 test one corner each; any failure, a far-away block or
+    // a sub-2 mm grid leaves the per-voxel test in charge.
+    bool block_same = false;
+    {
+      const int kx = (lane & 1) ? bs - 1 : 0, ky = (lane & 2) ? bs - 1 : 0, kz = (lane & 4) ? bs - 1 : 0;
+      F3 cv; cv.x = position.x + kx * vs; cv.y = position.y + ky * vs; cv.z = position.z + kz * vs;
+      const F3 cw = xform(T, xform(Ti, cv));
+      const bool near = fabsf(cw.x * inv_vs - (float)(P.x * bs + kx)) < 0.1f && fabsf(cw.y * inv_vs - (float)(P.y * bs + ky)) < 0.1f &&
+                        fabsf(cw.z * inv_vs - (float)(P.z * bs + kz)) < 0.1f;
+      const bool small = fabsf(cv.x) < 64.f && fabsf(cv.y) < 64.f && fabsf(cv.z) < 64.f && fabsf(pc.x) < 64.f && fabsf(pc.y) < 64.f && fabsf(pc.z) < 64.f;
+      block_same = (__ballot(near && small) & 0xffull) == 0xffull && vs >= 0.002f;
+    }
+    if (block_same) {
+      // Fast path (every voxel is known to map onto itself): the 8 slabs' loads are independent, so issue all of them
+      // before any is consumed -- the kernel is bound by the depth -> surface/colour -> voxel load chain, not by ALU.
+      F3 vpc[bs];
+      int pix[bs];
+      float dep8[bs], sd8[bs];
+      Voxel cur8[bs];
+      unsigned col8[bs];
+#pragma unroll
+      for (int bx = 0; bx < bs; ++bx) {
+        F3 vp; vp.x = position.x + bx * vs; vp.y = position.y + by * vs; vp.z = position.z + bz * vs;
+        vpc[bx] = xform(Ti, vp);
+        int ix, iy;
+        project(o, vpc[bx], ix, iy);
+        const bool inb = ix >= 0 && iy >= 0 && ix < o.width && iy < o.height;
+        pix[bx] = inb ? iy * o.width + ix : -1;
+        const int idx = inb ? pix[bx] : 0;
+        dep8[bx] = depth[idx];
+        sd8[bx] = d.sd[idx];
+        col8[bx] = (unsigned)bgr[3 * idx] | ((unsigned)bgr[3 * idx + 1] << 8) | ((unsigned)bgr[3 * idx + 2] << 16);
+        cur8[bx] = blk_vox[bx * (bs * bs) + lane];
+      }
+#pragma unroll
+      for (int bx = 0; bx < bs; ++bx) {
+        const float dep = dep8[bx], sd = sd8[bx];
+        if (pix[bx] < 0 || dep <= 0 || dep < o.min_sensor_depth || dep > o.max_sensor_depth) continue;
+        const float vd = norm3(vpc[bx]);
+        Voxel v;
+        bool hit = false;
+        if (vd > sd - trunc && vd < sd + trunc && dep < o.max_sensor_depth) { v.sdf = sd - vd; hit = true; }
+        else if (vd < sd - trunc) { v.sdf = trunc; hit = true; }
+        if (!hit) continue;
+        v.c[0] = (unsigned char)(col8[bx] & 255u); v.c[1] = (unsigned char)((col8[bx] >> 8) & 255u); v.c[2] = (unsigned char)((col8[bx] >> 16) & 255u);
+        v.weight = 1;
+        Voxel cur = cur8[bx];
+        combine(cur, v, (unsigned char)o.max_sdf_weight);
+        blk_vox[bx * (bs * bs) + lane] = cur;
+        ++upd;
+      }
+      continue;
+    }
 #pragma unroll 2
     for (int bx = 0; bx < bs; ++bx) {
       const int li = bx * (bs * bs) + lane;
@@ -310,8 +369,9 @@ __global__ __launch_bounds__(256) void k_integrate(const FusionDev d, const unsi
       // Sufficient test without the three divisions: if |wp * (1/vs) - n| < 0.25 for this lane's own global voxel
       // index n on every axis, then |wp/vs - n| < 0.3 and the truncation above yields exactly n (for n = 0 as well),
       // i.e. the round trip lands on this lane's voxel.  Otherwise the literal path decides.
-      const F3 wp = xform(T, vp);
       Voxel *dst = blk_vox + li;
+      if (!block_same) {
+      const F3 wp = xform(T, vp);
       const bool same = fabsf(wp.x * inv_vs - (float)(P.x * bs + bx)) < 0.25f && fabsf(wp.y * inv_vs - (float)(P.y * bs + by)) < 0.25f &&
                         fabsf(wp.z * inv_vs - (float)(P.z * bs + bz)) < 0.25f;
       if (!same) {
@@ -323,6 +383,7 @@ __global__ __launch_bounds__(256) void k_integrate(const FusionDev d, const unsi
           if (target < 0) continue;
           dst = d.vox + (size_t)target * (bs * bs * bs) + local;
         }
+      }
       }
       Voxel cur = *dst;
       combine(cur, v, (unsigned char)o.max_sdf_weight);
