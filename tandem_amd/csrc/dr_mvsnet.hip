@@ -681,10 +681,12 @@ class MvsEngine {
         case Op::COSTVOL: {
           const CostVolArgs &a = cv_[o.stage - 1];
           const int C = 32 >> (o.stage - 1), pxb = 256 / (C >= 16 ? C / 8 : C / 4);
-          dim3 grid(cdiv(a.w, pxb), a.h, cdiv(a.planes.D, a.dchunk));
-          if (C == 32) hipLaunchKernelGGL(k_costvol<32>, grid, dim3(256), 0, stream_, a);
-          else if (C == 16) hipLaunchKernelGGL(k_costvol<16>, grid, dim3(256), 0, stream_, a);
-          else hipLaunchKernelGGL(k_costvol<8>, grid, dim3(256), 0, stream_, a);
+          CostVolArgs b = a;
+          b.gx = cdiv(a.w, pxb); b.gz = cdiv(a.planes.D, a.dchunk); b.nwg = b.gx * b.gz * a.h;
+          dim3 grid(8 * cdiv(b.nwg, 8));
+          if (C == 32) hipLaunchKernelGGL(k_costvol<32>, grid, dim3(256), 0, stream_, b);
+          else if (C == 16) hipLaunchKernelGGL(k_costvol<16>, grid, dim3(256), 0, stream_, b);
+          else hipLaunchKernelGGL(k_costvol<8>, grid, dim3(256), 0, stream_, b);
           break;
         }
         case Op::REGRESS: {
