@@ -73,7 +73,12 @@ __global__ __launch_bounds__(kConvThreads) void k_conv(const ConvArgs a) {
   const ConvClass cls = a.cls[blockIdx.y];
   const int ct0 = blockIdx.z * CT;
 
-  int b = blockIdx.x;
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (own L2 each), so XCD k takes the k-th
+  // contiguous range of tiles (x fastest, then y, then z): neighbouring tiles, which share their halo, share an L2.
+  // grid.x is padded to a multiple of 8 (so that XCD == blockIdx.x % 8 for every row group); surplus workgroups exit.
+  const int ntiles = a.tilesD * a.tilesH * a.tilesW, per_xcd = (ntiles + 7) >> 3;
+  int b = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
+  if (b >= ntiles) return;
   const int tw = b % a.tilesW;
   b /= a.tilesW;
   const int th = b % a.tilesH, td = b / a.tilesH;
@@ -527,7 +532,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   a.addH = R.outH / 2; a.addW = (mode == CONV_NORMAL ? R.outW : outWv) / 2;
   a.tilesD = cdiv(nPD, TZ); a.tilesH = cdiv(nPH, TY); a.tilesW = cdiv(nPW, TXT * 16);
   cl.ci = CI; cl.ct = CT; cl.pt = PT;
-  cl.grid = dim3(a.tilesD * a.tilesH * a.tilesW, ncls, CTtot / CT);
+  cl.grid = dim3(8 * cdiv(a.tilesD * a.tilesH * a.tilesW, 8), ncls, CTtot / CT);
   int nu_max = 0;
   for (auto &c : cls) nu_max = std::max(nu_max, c.NU);
   a.nuMax = nu_max;

@@ -439,7 +439,22 @@ __global__ __launch_bounds__(64) void k_raycast(const FusionDev d, const Mat pos
                                                 float *__restrict__ depth_out) {
   const drf_options_t &o = d.o;
   const int size = o.height * o.width;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < size; i += gridDim.x * blockDim.x) {
+  // One wave = one 8x8 pixel tile (a row of 64 pixels fans out over ~6 voxel blocks at 2 m, a tile over 1-2, and
+  // PMC showed 4.5 GB of L2 misses per 640x480 render with row-wise waves); tiles are dealt to the 8 XCDs in bands of
+  // rows so that neighbouring tiles share an L2.  Sizes that are not multiples of 8 keep the row-wise order.
+  const bool tiled = (o.width % 8 == 0) && (o.height % 8 == 0) && blockDim.x == 64;
+  const int ntile = tiled ? size / 64 : 0, per_xcd = (ntile + 7) >> 3;
+  for (int w0 = blockIdx.x; w0 < (tiled ? 8 * per_xcd : (size + 63) / 64); w0 += gridDim.x) {
+    int i;
+    if (tiled) {
+      const int t = (w0 & 7) * per_xcd + (w0 >> 3);
+      if (t >= ntile) continue;
+      const int tw = o.width / 8, tx = t % tw, ty = t / tw;
+      i = (ty * 8 + (threadIdx.x >> 3)) * o.width + tx * 8 + (threadIdx.x & 7);
+    } else {
+      i = w0 * 64 + threadIdx.x;
+      if (i >= size) continue;
+    }
     float cur = 0.f;
     while (cur < o.max_sensor_depth) {
       const Voxel v = get_interpolated_voxel(d, xform(pose, point3d(o, i, cur)));
@@ -590,7 +605,7 @@ class FusionEngine {
       Render &r = renders_[i];
       Mat P; memcpy(P.m, poses[i], 64);
       DR_HIP(hipStreamWaitEvent(r.stream, int_done_, 0));
-      hipLaunchKernelGGL(k_raycast, dim3(cdiv((int)npix_, 64)), dim3(64), 0, r.stream, d_, P, r.d_bgr, r.d_depth);
+      hipLaunchKernelGGL(k_raycast, dim3(8 * cdiv(cdiv((int)npix_, 64), 8)), dim3(64), 0, r.stream, d_, P, r.d_bgr, r.d_depth);
       DR_HIP(hipMemcpyAsync(r.h_bgr[free_slot_], r.d_bgr, npix_ * 3, hipMemcpyDeviceToHost, r.stream));
       DR_HIP(hipMemcpyAsync(r.h_depth[free_slot_], r.d_depth, npix_ * 4, hipMemcpyDeviceToHost, r.stream));
       DR_HIP(hipEventRecord(r.done, r.stream));
