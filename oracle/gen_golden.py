@@ -4,7 +4,7 @@
   tests/golden/mvsnet_<name>.npz    inputs at the DrMvsnet boundary + the REFERENCE model's outputs
 
 and checks, while doing so, that oracle/mvsnet_oracle.py reproduces the reference bit-for-bit on them.
-Usage: python oracle/gen_golden.py
+Usage: python oracle/gen_golden.py [case names]   (no names = all cases, incl. the weight blob)
 """
 import os
 import sys
@@ -18,11 +18,12 @@ from oracle import mvsnet_oracle as O  # noqa: E402
 from oracle import ref_model, scene  # noqa: E402
 from tandem_amd import weights as Wt  # noqa: E402
 
-CASES = [  # name, H, W, V, planes, discard, weights
-    ("v3_64x96", 64, 96, 3, (48, 32, 8), 2.5, "trained"),
-    ("v7_64x96", 64, 96, 7, (48, 32, 8), 10.0, "trained"),
-    ("v3_64x64_d4", 64, 64, 3, (48, 4, 4), 10.0, "trained"),
-    ("v4_96x128_rand", 96, 128, 4, (48, 32, 8), 5.0, "random"),
+CASES = [  # name, H, W, V, planes, discard, weights, view_aggregation
+    ("v3_64x96", 64, 96, 3, (48, 32, 8), 2.5, "trained", True),
+    ("v7_64x96", 64, 96, 7, (48, 32, 8), 10.0, "trained", True),
+    ("v3_64x64_d4", 64, 64, 3, (48, 4, 4), 10.0, "trained", True),
+    ("v4_96x128_rand", 96, 128, 4, (48, 32, 8), 5.0, "random", True),
+    ("v5_64x96_novar", 64, 96, 5, (48, 32, 8), 5.0, "random", False),  # plain-variance volume (abl01/02 models)
 ]
 
 
@@ -34,14 +35,17 @@ def main():
     blob = os.path.join(ROOT, "weights/tandem_va.tdmw")
     Wt.write_blob(blob, sd, depth_num=(48, 32, 8))
     print("wrote", blob, os.path.getsize(blob))
-    for name, H, Wd, V, planes, disc, wsrc in CASES:
+    only = sys.argv[1:]
+    for name, H, Wd, V, planes, disc, wsrc, va in CASES:
+        if only and name not in only:
+            continue
         if wsrc == "trained":
             state = {k: v.numpy() for k, v in sd.items() if v.dtype.is_floating_point}
         else:
             state = Wt.random_state(planes, seed=7)
-        net, cva = ref_model.build(planes, state)
+        net, cva = ref_model.build(planes, state, view_aggregation=va)
         win = scene.make_window(H, Wd, V, seed=len(name))
-        w = O.Weights(dict(depth_num=planes, interval_ratio=(1.0, 0.5, 0.25), view_aggregation=True,
+        w = O.Weights(dict(depth_num=planes, interval_ratio=(1.0, 0.5, 0.25), view_aggregation=va,
                            base_channels=8), state)
         image, Ks, c2w = O.preprocess(win["bgrs"], win["K"], win["c2ws"], win["ref_index"])
         ref = ref_model.run(net, cva, image, Ks, c2w, win["depth_min"], win["depth_max"], disc)
@@ -49,7 +53,8 @@ def main():
                          win["depth_max"], disc)
         save = dict(bgrs=np.stack(win["bgrs"]), K=win["K"], c2ws=win["c2ws"], ref_index=win["ref_index"],
                     depth_min=np.float32(win["depth_min"]), depth_max=np.float32(win["depth_max"]),
-                    discard=np.float32(disc), planes=np.array(planes), weights=wsrc, gt_depth=win["gt_depth"])
+                    discard=np.float32(disc), planes=np.array(planes), weights=wsrc, gt_depth=win["gt_depth"],
+                    view_aggregation=np.int32(va))
         for s in (1, 2, 3):
             for k in ("depth", "confidence", "depth_dense", "confidence_dense"):
                 r = getattr(ref[s - 1], k)[0].numpy()

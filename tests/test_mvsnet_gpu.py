@@ -40,8 +40,9 @@ def blob_for(g, trained_blob, tmp_path):
         _, tens = Wt.read_blob(trained_blob)
     else:
         tens = Wt.random_state(planes, seed=7)
+    va = bool(int(g["view_aggregation"])) if "view_aggregation" in g.files else True
     p = str(tmp_path / "w.tdmw")
-    Wt.write_blob(p, tens, depth_num=planes)
+    Wt.write_blob(p, tens, depth_num=planes, view_aggregation=va)
     return p
 
 
