@@ -25,20 +25,10 @@ WORKER = textwrap.dedent("""
 
 
 def test_two_rank_gloo_replicas(tmp_path):
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    from conftest import launch_gloo_ranks
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    outs = []
-    for p in procs:
-        o, e = p.communicate(timeout=120)
-        assert p.returncode == 0, e
-        import json
-        outs.append(json.loads(o.strip().splitlines()[-1]))
-    outs.sort(key=lambda d: d["rank"])
+    outs = launch_gloo_ranks(script, timeout=120)
     assert outs[0]["mine"] == [0, 2, 4, 6, 8, 10] and outs[1]["mine"] == [1, 3, 5, 7, 9]
     assert outs[0]["units"] == outs[1]["units"] == 11
     assert outs[0]["tmax"] == outs[1]["tmax"] == max(outs[0]["dt"], outs[1]["dt"])

@@ -98,19 +98,10 @@ WORKER = textwrap.dedent("""
 
 
 def test_two_rank_gloo_view_shard(tmp_path):
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    from conftest import launch_gloo_ranks
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    outs = []
-    for p in procs:
-        o, e = p.communicate(timeout=600)
-        assert p.returncode == 0, e[-3000:]
-        outs.append(json.loads(o.strip().splitlines()[-1]))
-    outs.sort(key=lambda d: d["rank"])
+    outs = launch_gloo_ranks(script, timeout=600)
     a, b = outs
     assert a["mine"][0] == b["mine"][0] and sorted(a["mine"][1:] + b["mine"][1:]) == [i for i in range(5) if i != a["mine"][0]]
     for o in outs:
