@@ -116,10 +116,13 @@ def test_two_process_bench_path_on_one_gpu(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-tsdf"]
-    p = subprocess.run(cmd, env=dict(os.environ, DR_BENCH_ONE_DEVICE="1"), capture_output=True, text=True, timeout=600, cwd=root)
+    for attempt in range(3):  # the rendezvous port is found by bind-and-release; retry if another process wins it
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-tsdf"]
+        p = subprocess.run(cmd, env=dict(os.environ, DR_BENCH_ONE_DEVICE="1"), capture_output=True, text=True, timeout=600, cwd=root)
+        if p.returncode == 0:
+            break
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "rank 0 prints exactly one JSON line"
