@@ -4,7 +4,7 @@
 // It replaces every dense contraction the reference hands to cuDNN through ATen
 // (FeatureNet.forward cva_mvsnet/models/module.py:496-531, CostRegNet.forward module.py:577-600):
 // Conv2d 3x3 / 5x5-stride-2 / 1x1, Conv3d 3^3 (stride 1, 2, (1,2,2)) and ConvTranspose3d 3^3
-// stride 2 (as 8 output-parity classes), with the eval-mode BatchNorm folded into a per-channel
+// stride 2 (as ONE stride-1 conv with 8*Cout parity rows), with the eval-mode BatchNorm folded into a per-channel
 // scale/bias, ReLU, the UNet residual adds and FeatureNet's nearest-upsample-add fused in the epilogue.
 //
 // Data layout: channels-last everywhere, tensor = (D|V, H, W, C) fp32.
@@ -17,7 +17,7 @@
 // consecutive cin of "its" tap) from the LDS-staged input tile and ONE float4 of pre-packed weights,
 // and feeds four back-to-back MFMAs (k-order inside the dot product is free, so lane-group g owns
 // K = 16q+4g .. +3).  Taps are a runtime table of LDS offsets, which is what lets the same kernel do
-// strided convs, transposed-conv parity classes and the two "shifted-weights" modes:
+// strided convs, transposed convs (dense parity rows) and the two "shifted-weights" modes:
 //   XPAIR: a Cout=8 layer is run as a stride-(1,1,2) conv with a 4-wide kernel and 16 output rows
 //          (8 channels x 2 adjacent x) on the output viewed as (D,H,W/2,16): 75 % MFMA row use, not 50 %.
 //   X8   : the Cout=1 `prob` layer is run as 8 x-shifts per column on the output viewed as (D,H,W/8,8).

@@ -3,7 +3,7 @@
 // Replaces tandem/libdr/dr_mvsnet/src/dr_mvsnet.cpp (libtorch TorchScript interpreter + cuDNN)
 // with a fixed launch plan of hand-written gfx950 kernels (conv_mfma.h, mvs_kernels.h):
 //   CallAsync   dr_mvsnet.cpp:125-283  -> MvsEngine::stage_inputs + worker thread
-//   forward     dr_mvsnet.cpp:285-331  -> MvsEngine::forward (cva_mvsnet.py:98-184 as ~120 launches)
+//   forward     dr_mvsnet.cpp:285-331  -> MvsEngine::forward (cva_mvsnet.py:98-184 as ~75 launches)
 //   GetResult   dr_mvsnet.cpp:95-107   -> drm_get_result
 // The threading contract is the reference's: one worker thread, one mutex, two condition variables;
 // CallAsync blocks only while the previous input is still unprocessed.
