@@ -545,7 +545,11 @@ class FusionEngine {
     d_depth_in_ = dalloc<float>(npix_);
     DR_HIP(hipHostMalloc((void **)&h_bgr_in_, npix_ * 3, hipHostMallocDefault));
     DR_HIP(hipHostMalloc((void **)&h_depth_in_, npix_ * 4, hipHostMallocDefault));
-    integrate_grid_ = std::min(cdiv(o.num_blocks, 4), 8192);
+    // 12 workgroups per CU: enough to keep every SIMD's 4 resident waves busy, few enough that the blocks being worked on
+    // at any moment are neighbours in the pool (sweep on the bench map: 1024 / 3072 / 4096 / 6144 / 8192 / 16384
+    // workgroups -> 0.341 / 0.327 / 0.329 / 0.363 / 0.443 / 0.697 ms per scan)
+    integrate_grid_ = std::min(cdiv(o.num_blocks, 4), 3072);
+    if (const char *e = getenv("DR_INT_GRID")) integrate_grid_ = std::max(1, atoi(e));  // tuning hook
     DR_HIP(hipEventCreateWithFlags(&int_done_, hipEventDisableTiming));
     for (int i = 0; i < o.num_render_streams; ++i) {
       Render r;
