@@ -1,0 +1,6 @@
+// TEST INFRASTRUCTURE (oracle/): the launch coordinates of oracle/ref_stub/cuda_runtime.h, defined once per shared object.
+#include "cuda_runtime.h"
+extern "C" {
+dim3 threadIdx, blockIdx, blockDim, gridDim;
+int cpu_launch_reverse_threads = 0;
+}

@@ -491,3 +491,51 @@ long tsdf_extract_mesh(const tsdf_t *t, const float *lower, const float *upper, 
   }
   return ntri;
 }
+
+/* ---- pins: the helpers above, one by one, for tests/test_ref_fusion.py, which compares each with the REFERENCE's own
+ * header code compiled for the host (oracle/_ref/libdr_fusion_ref.so, oracle/ref_fusion_capi.cpp) ---- */
+void tsdf_pin_combine(float sdf, const unsigned char *c, unsigned char w, float vsdf, const unsigned char *vc, unsigned char vw,
+                      unsigned char max_weight, float *sdf_out, unsigned char *c_out, unsigned char *w_out) {
+  voxel_t a = {sdf, {c[0], c[1], c[2]}, w}, b = {vsdf, {vc[0], vc[1], vc[2]}, vw};
+  combine(&a, &b, max_weight);
+  *sdf_out = a.sdf; c_out[0] = a.c[0]; c_out[1] = a.c[1]; c_out[2] = a.c[2]; *w_out = a.weight;
+}
+void tsdf_pin_combine_colour_table(unsigned char w, unsigned char *out) {
+  for (int c = 0; c < 256; ++c)
+    for (int vc = 0; vc < 256; ++vc) {
+      voxel_t a = {0.0f, {(unsigned char)c, (unsigned char)c, (unsigned char)c}, w};
+      voxel_t b = {0.0f, {(unsigned char)vc, (unsigned char)vc, (unsigned char)vc}, 1};
+      combine(&a, &b, 255);
+      out[c * 256 + vc] = a.c[0];
+    }
+}
+static tsdf_options pin_opts(const float *k4, int rows, int cols) {
+  tsdf_options o; memset(&o, 0, sizeof o);
+  o.fx = k4[0]; o.fy = k4[1]; o.cx = k4[2]; o.cy = k4[3]; o.height = rows; o.width = cols;
+  return o;
+}
+void tsdf_pin_point3d(const float *k4, int rows, int cols, int i, float depth, float *out3) {
+  tsdf_options o = pin_opts(k4, rows, cols);
+  f3 p = point3d(&o, i, depth);
+  out3[0] = p.x; out3[1] = p.y; out3[2] = p.z;
+}
+void tsdf_pin_project(const float *k4, int rows, int cols, const float *p3, int *out2) {
+  tsdf_options o = pin_opts(k4, rows, cols);
+  f3 p = {p3[0], p3[1], p3[2]};
+  project(&o, p, &out2[0], &out2[1]);
+}
+float tsdf_pin_norm(const float *p3) { f3 p = {p3[0], p3[1], p3[2]}; return norm3(p); }
+void tsdf_pin_xform(const float *m16, const float *p3, float *out3) {
+  f3 p = {p3[0], p3[1], p3[2]};
+  f3 r = xform(m16, p);
+  out3[0] = r.x; out3[1] = r.y; out3[2] = r.z;
+}
+void tsdf_pin_world_maps(const tsdf_t *t, const float *p3, int *global_voxel3, int *block3, int *local3, float *back3) {
+  f3 p = {p3[0], p3[1], p3[2]};
+  i3 g = world_to_global_voxel(t, p), b = world_to_block(t, p), l = world_to_local_voxel(t, p);
+  global_voxel3[0] = g.x; global_voxel3[1] = g.y; global_voxel3[2] = g.z;
+  block3[0] = b.x; block3[1] = b.y; block3[2] = b.z;
+  local3[0] = l.x; local3[1] = l.y; local3[2] = l.z;
+  /* GlobalVoxelToWorld, tsdf_volume.cu:103-107 */
+  back3[0] = g.x * t->o.voxel_size; back3[1] = g.y * t->o.voxel_size; back3[2] = g.z * t->o.voxel_size;
+}
