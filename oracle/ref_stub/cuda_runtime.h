@@ -21,7 +21,7 @@
 #define __device__
 #define __global__
 #define __forceinline__ inline
-#define __restrict__
+#define __shared__ static
 #define __align__(n) __attribute__((aligned(n)))
 
 struct float2 { float x, y; };
@@ -56,8 +56,10 @@ extern dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 // `rev` runs the threads of a block in DESCENDING order (used for kernels whose thread 0 publishes a block reduction)
 extern "C" int cpu_launch_reverse_threads;
+extern "C" unsigned long long cpu_launch_id;
 template <class... P, class... A>
 static inline void cpu_launch(dim3 grid, dim3 block, void (*kernel)(P...), A&&... args) {
+  ++cpu_launch_id;
   gridDim = grid;
   blockDim = block;
   for (unsigned bz = 0; bz < grid.z; ++bz)
@@ -119,3 +121,9 @@ static inline cudaError_t cudaEventDestroy(cudaEvent_t) { return 0; }
 static inline cudaError_t cudaEventRecord(cudaEvent_t, cudaStream_t = nullptr) { return 0; }
 static inline cudaError_t cudaEventSynchronize(cudaEvent_t) { return 0; }
 static inline cudaError_t cudaEventQuery(cudaEvent_t) { return 0; }
+static inline cudaError_t cudaEventElapsedTime(float* ms, cudaEvent_t, cudaEvent_t) { *ms = 0.0f; return 0; }
+// CUDA puts the <math.h> classification functions in the global namespace for device code
+using std::isfinite;
+using std::abs;      // CUDA overloads ::abs for float/double; without this g++ would pick int abs(int)
+using std::isnan;
+using std::isinf;

@@ -3,4 +3,5 @@
 extern "C" {
 dim3 threadIdx, blockIdx, blockDim, gridDim;
 int cpu_launch_reverse_threads = 0;
+unsigned long long cpu_launch_id = 0;
 }

@@ -259,3 +259,14 @@ int trk_append_dense(trk_t *t, const float *depth, const float *KRKi, const floa
   t->n = n;
   return n;
 }
+
+/* ---- pin: the exact float inputs this restatement's calcRes / calcG "kernels" work from, so that tests/test_ref_tracker.py
+ * can hand the SAME inputs to the reference's own kernels compiled for the host (oracle/_ref/libcoarse_tracker_ref.so) ---- */
+void trk_kernel_inputs(const trk_t *t, const double *refToNew, float new_exposure, const double *aff_g2l, float cutoffTH,
+                       float *r2n16, float *Ki9, float *aff2, float *maxEnergy, float *ref_aff_b) {
+  for (int i = 0; i < 16; ++i) r2n16[i] = (float)refToNew[i];
+  for (int i = 0; i < 9; ++i) Ki9[i] = (float)t->Ki[i];
+  aff_ll(t->ref_exposure, new_exposure, t->ref_aff, aff_g2l, &aff2[0], &aff2[1]);
+  *maxEnergy = 2 * t->huber * cutoffTH - t->huber * t->huber;
+  *ref_aff_b = (float)t->ref_aff[1];
+}

@@ -34,6 +34,7 @@ def lib():
         L.trk_n.argtypes = [vp]
         L.trk_get_points.argtypes = [vp, vp, vp, vp, vp]
         L.trk_get_warped.argtypes = [vp, C.c_int, vp]
+        L.trk_kernel_inputs.argtypes = [vp, vp, C.c_float, vp, C.c_float, vp, vp, vp, vp, vp]
         L.trk_append_dense.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
         _lib = L
     return _lib
@@ -81,6 +82,14 @@ class TrackerOracle:
         H, b, raw = np.zeros((8, 8)), np.zeros(8), np.zeros(45)
         lib().trk_calc_g(self._h, H.ctypes.data, b.ctypes.data, new_exposure, aff.ctypes.data, raw.ctypes.data)
         return H, b, raw
+
+    def kernel_inputs(self, refToNew, new_exposure, aff_g2l, cutoffTH):
+        """The float inputs calcRes / calcG hand to their kernels: (r2n16, Ki9, affLL2, maxEnergy, ref_aff_b)."""
+        T, aff = _f64(refToNew).reshape(16), _f64(aff_g2l)
+        r2n, Ki, a2, me, rb = (np.zeros(k, np.float32) for k in (16, 9, 2, 1, 1))
+        lib().trk_kernel_inputs(self._h, T.ctypes.data, new_exposure, aff.ctypes.data, cutoffTH, r2n.ctypes.data, Ki.ctypes.data,
+                                a2.ctypes.data, me.ctypes.data, rb.ctypes.data)
+        return r2n, Ki, a2, float(me[0]), float(rb[0])
 
     def n(self):
         return lib().trk_n(self._h)

@@ -260,6 +260,16 @@ __device__ inline void combine(Voxel &a, const Voxel &b, unsigned char max_weigh
   a.weight = nw;
 }
 
+// Test hook (drf_test_combine): the SAME device function on arbitrary voxel pairs, so that the reciprocal shortcut above can be
+// checked exhaustively against the reference's Voxel::Combine.
+__global__ void k_test_combine(const Voxel *__restrict__ a, const Voxel *__restrict__ b, Voxel *__restrict__ out, size_t n, int max_weight) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    Voxel v = a[i];
+    combine(v, b[i], (unsigned char)max_weight);
+    out[i] = v;
+  }
+}
+
 // One WAVE per allocated pool block (4 waves per workgroup, grid-strided): per-block work (pose transform of the
 // block origin, frustum test) is done once per wave, then 8 iterations of 64 voxels (lane = y*8+z of slab x), each
 // a coalesced 512-byte read-modify-write of the block.
@@ -667,6 +677,17 @@ class FusionEngine {
     DR_HIP(hipMemcpy(voxels, d_.vox, (size_t)na * 4096, hipMemcpyDeviceToHost));
     if (n) *n = na;
   }
+  void test_combine(size_t n, const uint8_t *a, const uint8_t *b, int max_weight, uint8_t *out) {
+    DR_HIP(hipSetDevice(device_));
+    Voxel *da = nullptr, *db = nullptr, *dout = nullptr;
+    DR_HIP(hipMalloc(&da, n * 8)); DR_HIP(hipMalloc(&db, n * 8)); DR_HIP(hipMalloc(&dout, n * 8));
+    DR_HIP(hipMemcpy(da, a, n * 8, hipMemcpyHostToDevice));
+    DR_HIP(hipMemcpy(db, b, n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_test_combine, dim3(2048), dim3(256), 0, int_stream_, da, db, dout, n, max_weight);
+    DR_HIP(hipStreamSynchronize(int_stream_));
+    DR_HIP(hipMemcpy(out, dout, n * 8, hipMemcpyDeviceToHost));
+    DR_HIP(hipFree(da)); DR_HIP(hipFree(db)); DR_HIP(hipFree(dout));
+  }
   // ---- marching cubes: TsdfVolume::ExtractMeshAsync / GetMeshSync (tsdf_volume.cu:759-838) ----
   void extract_mesh_async(const float *lower, const float *upper) {
     if (!lower || !upper) fail(DR_ERR_ARG, "ExtractMeshAsync: null argument");
@@ -910,6 +931,9 @@ int drf_synchronize(drf_t *h) { return guarded([&] { h->e->synchronize(); }); }
 int drf_stats(drf_t *h, uint64_t out[4]) { return guarded([&] { h->e->stats(out); }); }
 int drf_export_blocks(drf_t *h, int max_blocks, int32_t *coords, uint8_t *voxels, int *n) {
   return guarded([&] { h->e->export_blocks(max_blocks, coords, voxels, n); });
+}
+int drf_test_combine(drf_t *h, size_t n, const uint8_t *a, const uint8_t *b, int max_weight, uint8_t *out) {
+  return guarded([&] { if (!a || !b || !out) dr::fail(DR_ERR_ARG, "drf_test_combine: null argument"); h->e->test_combine(n, a, b, max_weight, out); });
 }
 int drf_integrate_device(drf_t *h, const void *d_bgr, const void *d_depth, const float *pose16) {
   return guarded([&] { h->e->integrate_device(d_bgr, d_depth, pose16); });

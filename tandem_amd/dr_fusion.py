@@ -113,6 +113,15 @@ class DrFusion:
                                            vox.ctypes.data_as(u8p), C.byref(got)))
         return {tuple(int(v) for v in coords[i]): vox[i] for i in range(got.value)}
 
+    def test_combine(self, a, b, max_weight):
+        """Test hook: Combine(a[i], b[i]) by the integration kernel's device function; a, b: (n, 8) uint8 voxels."""
+        a, b = np.ascontiguousarray(a, np.uint8), np.ascontiguousarray(b, np.uint8)
+        assert a.shape == b.shape and a.shape[1] == 8
+        out = np.empty_like(a)
+        check(_lib.lib().drf_test_combine(self._h, a.shape[0], a.ctypes.data_as(u8p), b.ctypes.data_as(u8p), int(max_weight),
+                                          out.ctypes.data_as(u8p)))
+        return out
+
     def bench_integrate(self, bgrs, depths, poses):
         """Uploads the scans once, then times back-to-back allocate+integrate of all of them (HBM-resident)."""
         L = _lib.lib()

@@ -149,3 +149,122 @@ def test_full_size_properties():
     m = (rd[0] > 0) & (depth > 0)
     assert m.mean() > 0.9 and np.abs(rd[0][m] - depth[m]).mean() < vs
     f.close()
+
+
+def test_combine_exhaustive_against_reference_and_restatement():
+    """Voxel::Combine (voxel.h:21-50) as the integration kernel evaluates it -- v_rcp_f32 + half-gap bias instead of three
+    IEEE divisions for the colour blend -- over EVERY (c, vc in 0..255, w in 0..64) [4.26 M cases], plus 1 M random
+    sdf / weight / cap cases, against the reference's own Combine compiled for the host (oracle/_ref) when present and
+    against the restatement always."""
+    import ctypes as C
+    from oracle import ref_fusion, scene, tsdf_oracle
+    from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
+    sc = scene.make_scans(1, 8, 8)
+    f = DrFusion(DrFusionOptions(**options(sc, 8, 8, 0.02, num_blocks=64, num_buckets=64)))
+    O = tsdf_oracle.lib()
+    O.tsdf_pin_combine_colour_table.argtypes = [C.c_ubyte, C.c_void_p]
+    R = ref_fusion.lib() if ref_fusion.available() else None
+    c, vc = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), indexing="ij")
+    a = np.zeros((65536, 8), np.uint8)
+    b = np.zeros((65536, 8), np.uint8)
+    a[:, 4] = a[:, 5] = a[:, 6] = c.ravel()
+    b[:, 4] = b[:, 5] = b[:, 6] = vc.ravel()
+    b[:, 7] = 1
+    want = np.empty(65536, np.uint8)
+    for w in range(0, 65):
+        a[:, 7] = w
+        got = f.test_combine(a, b, 255)
+        O.tsdf_pin_combine_colour_table(w, want.ctypes.data)
+        for ch in (4, 5, 6):
+            assert np.array_equal(got[:, ch], want), f"w={w}: {np.count_nonzero(got[:, ch] != want)} colour blends differ from the restatement"
+        assert (got[:, 7] == w + 1).all()
+        if R is not None:
+            R.ref_combine_colour_table(w, want.ctypes.data)
+            assert np.array_equal(got[:, 4], want), f"w={w}: differs from the reference's Voxel::Combine"
+    # sdf running mean, weight increment and cap, vw = 1 (what IntegrateScanKernel passes) and vw = 2 (general branch)
+    rng = np.random.RandomState(0)
+    n = 1 << 20
+    a = rng.randint(0, 256, (n, 8)).astype(np.uint8)
+    b = rng.randint(0, 256, (n, 8)).astype(np.uint8)
+    a[:, :4] = rng.uniform(-0.05, 0.05, n).astype(np.float32).view(np.uint8).reshape(n, 4)
+    b[:, :4] = rng.uniform(-0.05, 0.05, n).astype(np.float32).view(np.uint8).reshape(n, 4)
+    a[:, 7] = rng.randint(0, 65, n)
+    b[:, 7] = 1 + (rng.rand(n) < 0.1)
+    got = f.test_combine(a, b, 64)
+    O.tsdf_pin_combine.argtypes = [C.c_float, C.c_void_p, C.c_ubyte, C.c_float, C.c_void_p, C.c_ubyte, C.c_ubyte, C.c_void_p, C.c_void_p, C.c_void_p]
+    # vectorised restatement of voxel.h:21-50 in numpy fp32 (division by IEEE), spot-checked against the C oracle below
+    w, vw = a[:, 7].astype(np.float32), b[:, 7].astype(np.float32)
+    col = ((a[:, 4:7].astype(np.float32) * w[:, None] + b[:, 4:7].astype(np.float32) * vw[:, None]) / (w + vw)[:, None]).astype(np.uint8)
+    sdf = (a[:, :4].copy().view(np.float32)[:, 0] * w + b[:, :4].copy().view(np.float32)[:, 0] * vw) / (w + vw)
+    nw = np.minimum(a[:, 7].astype(np.int32) + b[:, 7], 64).astype(np.uint8)
+    assert np.array_equal(got[:, 4:7], col) and np.array_equal(got[:, 7], nw)
+    assert np.array_equal(got[:, :4].copy().view(np.uint32)[:, 0], sdf.astype(np.float32).view(np.uint32))
+    s, co, wo = np.zeros(1, np.float32), np.zeros(3, np.uint8), np.zeros(1, np.uint8)
+    for i in range(0, n, 4099):
+        O.tsdf_pin_combine(float(a[i, :4].copy().view(np.float32)[0]), a[i, 4:7].copy().ctypes.data, int(a[i, 7]),
+                           float(b[i, :4].copy().view(np.float32)[0]), b[i, 4:7].copy().ctypes.data, int(b[i, 7]), 64,
+                           s.ctypes.data, co.ctypes.data, wo.ctypes.data)
+        assert s.view(np.uint32)[0] == got[i, :4].copy().view(np.uint32)[0] and tuple(co) == tuple(got[i, 4:7]) and wo[0] == got[i, 7]
+    f.close()
+
+
+@pytest.mark.parametrize("H,W,vs,n", [(96, 128, 0.02, 4), (60, 80, 0.01, 3)])
+def test_hip_path_equals_the_reference_build(H, W, vs, n):
+    """The HIP engine against the REFERENCE's own DrFusion compiled for the host (oracle/_ref/libdr_fusion_ref.so, built by
+    oracle/Makefile.ref from the sources under /root/reference; the prebuilt library travels to the GPU box): allocated
+    set, every voxel, ray-cast depth and colour bit-exact.  Scenes keep block (0,0,0) out of the frustum (the reference's
+    free-entry alias, tests/test_ref_fusion.py::test_origin_block_alias_is_the_only_deviation)."""
+    from oracle import ref_fusion, scene
+    from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
+    if not ref_fusion.available():
+        pytest.skip("oracle/_ref/libdr_fusion_ref.so not present")
+    sc = scene.make_scans(n, H, W, seed=H + n)
+    opt = options(sc, H, W, vs)
+    f, r = DrFusion(DrFusionOptions(**opt)), ref_fusion.RefFusion(**opt)
+    for i, (bgr, depth, pose) in enumerate(sc["scans"]):
+        f.IntegrateScanAsync(bgr, depth, pose)
+        view = sc["scans"][(i + 1) % n][2]
+        f.RenderAsync([view])
+        rb, rd = f.GetRenderResult()
+        r.integrate(bgr, depth, pose)
+        (ob, od), = r.render([view])
+        assert np.array_equal(rd[0].view(np.uint32), od.view(np.uint32)), f"scan {i}: ray-cast depth differs at {(rd[0] != od).sum()} px"
+        assert np.array_equal(rb[0], ob), f"scan {i}: ray-cast colour differs"
+    a, b = f.export_blocks(), r.export_blocks()
+    assert a.keys() == b.keys(), f"allocated sets differ: {len(a)} vs {len(b)}"
+    bad = [k for k in a if not np.array_equal(a[k], b[k])]
+    assert not bad, f"{len(bad)} of {len(a)} blocks differ, e.g. {bad[:3]}"
+    assert f.stats()["mismatches"] == 0
+    lo, hi = (-1.0, -1.0, 0.5), (1.0, 1.0, 3.0)
+    fv, fc = f.GetMesh(lo, hi)
+    rv, rc = r.extract_mesh(lo, hi)
+
+    def canon(v, c):
+        t = np.concatenate([v.reshape(-1, 9), c.reshape(-1, 9)], axis=1).view(np.uint32)
+        return t[np.lexsort(t.T[::-1])]
+    assert len(fv) == len(rv) > 0 and np.array_equal(canon(fv, fc), canon(rv, rc)), "mesh triangle sets differ"
+    f.close(); r.close()
+
+
+def test_full_size_bit_exact_against_the_oracle():
+    """BASELINE config 4's shape -- 640x480 scans into 5 mm voxels (truncation 20 mm) -- two scans, voxel state, update
+    counts and the ray-cast of the second view BIT-EXACT against oracle/tsdf_oracle.c (which tests/test_ref_fusion.py
+    pins to the reference build)."""
+    from oracle import scene
+    from oracle.tsdf_oracle import TsdfOracle
+    from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
+    H, W, vs = 480, 640, 0.005
+    sc = scene.make_scans(2, H, W, seed=0)
+    opt = options(sc, H, W, vs, num_blocks=600000, num_buckets=200000)
+    f, o = DrFusion(DrFusionOptions(**opt)), TsdfOracle(**opt)
+    for i, (bgr, depth, pose) in enumerate(sc["scans"]):
+        f.IntegrateScanAsync(bgr, depth, pose)
+        f.RenderAsync([pose])
+        rb, rd = f.GetRenderResult()
+        assert o.integrate(bgr, depth, pose) == 0
+        assert f.stats()["updated_last"] == o.stats()["updated_last"] > 10_000_000
+    ob, od = o.render(sc["scans"][-1][2])
+    assert np.array_equal(rd[0].view(np.uint32), od.view(np.uint32)) and np.array_equal(rb[0], ob)
+    assert_same_volume(f, o)
+    assert f.stats()["blocks"] > 80_000
+    f.close()

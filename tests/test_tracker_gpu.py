@@ -191,3 +191,33 @@ def test_render_to_tracker_handoff_stays_on_the_device():
     for a, b in zip(*lists):
         assert np.array_equal(bits(a), bits(b))
     f.close()
+
+
+@pytest.mark.parametrize("H,W,frac", [(120, 160, 0.2), (240, 320, 0.5)])
+def test_hip_kernels_equal_the_reference_build(H, W, frac):
+    """The HIP tracker against the REFERENCE's own calcResKernelNew / calcGKernel compiled for the host
+    (oracle/_ref/libcoarse_tracker_ref.so, oracle/Makefile.ref): warped buffers bit-exact; the reference's float
+    block sums + atomicAdd against the HIP path's double sums to fp32 accumulation noise."""
+    from oracle import ref_tracker
+    if not ref_tracker.available():
+        pytest.skip("oracle/_ref/libcoarse_tracker_ref.so not present")
+    p = pair(H, W, 5, frac)
+    g, o = both(p)
+    aff_ref, aff_new, cutoff, expo = [0.02, 1.5], [-0.01, -0.7], 12.0, 0.9
+    for t in (g, o):
+        t.setReference(p["pc_u"], p["pc_v"], p["pc_idepth"], p["pc_color"], 1.3, aff_ref)
+        t.setNew(p["dI_new"])
+    out_g, sums_g = g.calcRes(p["refToNew"], expo, aff_new, cutoff, return_sums=True)
+    r2n, Ki, a2, maxE, rb = o.kernel_inputs(p["refToNew"], expo, aff_new, cutoff)   # host-side input preparation only
+    rw, rout = ref_tracker.calc_res(9.0, W, H, p["fx"], p["fy"], p["cx"], p["cy"], r2n, Ki, a2, maxE, cutoff,
+                                    p["pc_u"], p["pc_v"], p["pc_idepth"], p["pc_color"], p["dI_new"])
+    for k, (a, b) in enumerate(zip(g.warped(), rw)):
+        assert np.array_equal(bits(a), bits(b)), f"warped[{k}] differs from the reference kernel at {(bits(a) != bits(b)).sum()} points"
+    for k in (1, 2, 3, 6):
+        assert sums_g[k] == rout[k]
+    assert rout[3] > 0 and rout[2] > 1000
+    np.testing.assert_allclose(rout[[0, 4, 5]], np.asarray(sums_g)[[0, 4, 5]], rtol=2e-5)
+    Hg, bg, rg = g.calcG(expo, aff_new, return_raw=True)
+    rd1 = ref_tracker.calc_g(p["fx"], p["fy"], a2, rb, p["pc_color"], rw, loops=1, double=True)
+    np.testing.assert_allclose(rg, rd1, rtol=1e-11, atol=1e-11 * np.abs(rd1).max())
+    g.close()
