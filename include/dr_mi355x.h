@@ -184,6 +184,12 @@ int dr_memcpy_d2d(void *dst, const void *src, size_t bytes); /* returns after th
 int drf_bench_integrate(drf_t *h, const void *d_bgr, const void *d_depth, const float *poses16, int nscans,
                         float *ms, float *kernel_ms);
 
+/* BASELINE configs[3] loop (dr_debug_example.cpp:78-162) over nframes frames resident in HBM (d_bgr: nframes*H*W*3 u8,
+ * d_depth: nframes*H*W f32, poses16: nframes*16): allocate + integrate per frame and, if render != 0, one ray-cast per
+ * render stream from the frame's pose with the D2H of its result.  ms[0] whole run (hipEvents), ms[1..4] sums of the
+ * allocate / integrate / ray-cast / D2H intervals, ms[5] host wall clock. */
+int drf_bench_sequence(drf_t *h, const void *d_bgr, const void *d_depth, const float *poses16, int nframes, int render, float ms[6]);
+
 /* ======================================================================================================
  * DrCoarseTracker -- the dense coarse tracker operator.  Replaces
  *   tandem/libdr/cuda_coarse_tracker/include/public/cuda_coarse_tracker.h   (class CudaCoarseTracker)

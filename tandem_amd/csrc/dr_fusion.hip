@@ -18,6 +18,7 @@
 #include <cfloat>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <memory>
 
 #include <rocprim/rocprim.hpp>  // device radix sort (block keys) and exclusive scan (triangle offsets) of the mesh path
@@ -756,6 +757,62 @@ class FusionEngine {
     check_device_flags();
   }
 
+  // BASELINE configs[3] loop (dr_debug_example.cpp:78-162: GetRenderResult(k-1) / IntegrateScanAsync(k) / RenderAsync(k) per
+  // frame, map growing) over `n` frames whose inputs are resident in HBM: allocate + integrate on the integration stream,
+  // then -- render != 0 -- one ray-cast per render stream from the frame's own pose with the D2H of its result into the
+  // pinned double buffers, ordered by the same events as the operator path.  ms[0] = first allocate .. last copy
+  // (hipEvents), ms[1..4] = sums of the allocate / integrate / ray-cast / D2H intervals, ms[5] = host wall clock.
+  void bench_sequence(const void *d_bgr, const void *d_depth, const float *poses, int n, int render, float ms[6]) {
+    if (!d_bgr || !d_depth || !poses || !ms || n <= 0) fail(DR_ERR_ARG, "bench_sequence: bad argument");
+    expect(kIntegrate, "bench_sequence starts where IntegrateScanAsync may be called.");
+    DR_HIP(hipSetDevice(device_));
+    const int nr = render ? (int)renders_.size() : 0;
+    const size_t per = 3 + (size_t)3 * nr;
+    std::vector<hipEvent_t> ev(per * n);
+    for (auto &e : ev) DR_HIP(hipEventCreate(&e));
+    DR_HIP(hipDeviceSynchronize());
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int s = 0; s < n; ++s) {
+      hipEvent_t *e = &ev[per * s];
+      for (auto &r : renders_) DR_HIP(hipStreamWaitEvent(int_stream_, r.done, 0));  // the previous frame's renders read the volume
+      DR_HIP(hipEventRecord(e[0], int_stream_));
+      kernel_events_[0] = e[1]; kernel_events_[1] = e[2];
+      enqueue_scan((const unsigned char *)d_bgr + (size_t)s * npix_ * 3, (const float *)d_depth + (size_t)s * npix_, poses + 16 * s);
+      kernel_events_[0] = kernel_events_[1] = nullptr;
+      DR_HIP(hipEventRecord(int_done_, int_stream_));
+      free_slot_ ^= 1;
+      for (int i = 0; i < nr; ++i) {
+        Render &r = renders_[i];
+        Mat P; memcpy(P.m, poses + 16 * s, 64);
+        DR_HIP(hipStreamWaitEvent(r.stream, int_done_, 0));
+        DR_HIP(hipEventRecord(e[3 + 3 * i], r.stream));
+        hipLaunchKernelGGL(k_raycast, dim3(8 * cdiv(cdiv((int)npix_, 64), 8)), dim3(64), 0, r.stream, d_, P, r.d_bgr, r.d_depth);
+        DR_HIP(hipEventRecord(e[4 + 3 * i], r.stream));
+        DR_HIP(hipMemcpyAsync(r.h_bgr[free_slot_], r.d_bgr, npix_ * 3, hipMemcpyDeviceToHost, r.stream));
+        DR_HIP(hipMemcpyAsync(r.h_depth[free_slot_], r.d_depth, npix_ * 4, hipMemcpyDeviceToHost, r.stream));
+        DR_HIP(hipEventRecord(e[5 + 3 * i], r.stream));
+        DR_HIP(hipEventRecord(r.done, r.stream));
+      }
+    }
+    DR_HIP(hipDeviceSynchronize());
+    ms[5] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (int k = 0; k < 5; ++k) ms[k] = 0.f;
+    float q = 0.f;
+    hipEvent_t last = nr ? ev[per * (n - 1) + 5 + 3 * (nr - 1)] : ev[per * (n - 1) + 2];
+    DR_HIP(hipEventElapsedTime(&ms[0], ev[0], last));
+    for (int s = 0; s < n; ++s) {
+      hipEvent_t *e = &ev[per * s];
+      DR_HIP(hipEventElapsedTime(&q, e[0], e[1])); ms[1] += q;
+      DR_HIP(hipEventElapsedTime(&q, e[1], e[2])); ms[2] += q;
+      for (int i = 0; i < nr; ++i) {
+        DR_HIP(hipEventElapsedTime(&q, e[3 + 3 * i], e[4 + 3 * i])); ms[3] += q;
+        DR_HIP(hipEventElapsedTime(&q, e[4 + 3 * i], e[5 + 3 * i])); ms[4] += q;
+      }
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    check_device_flags();
+  }
+
  private:
   enum Next { kIntegrate, kRender, kGetRender };
   void expect(Next want, const char *msg) {
@@ -949,6 +1006,9 @@ int dr_memcpy_d2d(void *dst, const void *src, size_t bytes) {
   return guarded([&] { DR_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice)); DR_HIP(hipDeviceSynchronize()); });
 }
 int dr_memcpy_d2h(void *dst, const void *dptr, size_t bytes) { return guarded([&] { DR_HIP(hipMemcpy(dst, dptr, bytes, hipMemcpyDeviceToHost)); }); }
+int drf_bench_sequence(drf_t *h, const void *d_bgr, const void *d_depth, const float *poses16, int nframes, int render, float ms[6]) {
+  return guarded([&] { h->e->bench_sequence(d_bgr, d_depth, poses16, nframes, render, ms); });
+}
 int drf_bench_integrate(drf_t *h, const void *d_bgr, const void *d_depth, const float *poses16, int nscans, float *ms, float *kernel_ms) {
   return guarded([&] { h->e->bench_integrate(d_bgr, d_depth, poses16, nscans, ms, kernel_ms); });
 }

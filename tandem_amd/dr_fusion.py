@@ -122,6 +122,14 @@ class DrFusion:
                                           out.ctypes.data_as(u8p)))
         return out
 
+    def bench_sequence(self, d_bgr, d_depth, poses, render=True):
+        """BASELINE configs[3] loop over frames resident in HBM (device pointers; poses (n, 16) float32): dict of
+        milliseconds -- total (hipEvents), allocate / integrate / raycast / d2h sums, host wall clock."""
+        ps = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
+        ms = (C.c_float * 6)()
+        check(_lib.lib().drf_bench_sequence(self._h, C.c_void_p(d_bgr), C.c_void_p(d_depth), fptr(ps), ps.shape[0], int(bool(render)), ms))
+        return dict(total=ms[0], allocate=ms[1], integrate=ms[2], raycast=ms[3], d2h=ms[4], wall=ms[5])
+
     def bench_integrate(self, bgrs, depths, poses):
         """Uploads the scans once, then times back-to-back allocate+integrate of all of them (HBM-resident)."""
         L = _lib.lib()

@@ -201,8 +201,9 @@ def test_combine_exhaustive_against_reference_and_restatement():
     assert np.array_equal(got[:, :4].copy().view(np.uint32)[:, 0], sdf.astype(np.float32).view(np.uint32))
     s, co, wo = np.zeros(1, np.float32), np.zeros(3, np.uint8), np.zeros(1, np.uint8)
     for i in range(0, n, 4099):
-        O.tsdf_pin_combine(float(a[i, :4].copy().view(np.float32)[0]), a[i, 4:7].copy().ctypes.data, int(a[i, 7]),
-                           float(b[i, :4].copy().view(np.float32)[0]), b[i, 4:7].copy().ctypes.data, int(b[i, 7]), 64,
+        ca, cb = a[i, 4:7].copy(), b[i, 4:7].copy()   # keep the temporaries alive across the call
+        O.tsdf_pin_combine(float(a[i, :4].copy().view(np.float32)[0]), ca.ctypes.data, int(a[i, 7]),
+                           float(b[i, :4].copy().view(np.float32)[0]), cb.ctypes.data, int(b[i, 7]), 64,
                            s.ctypes.data, co.ctypes.data, wo.ctypes.data)
         assert s.view(np.uint32)[0] == got[i, :4].copy().view(np.uint32)[0] and tuple(co) == tuple(got[i, 4:7]) and wo[0] == got[i, 7]
     f.close()

@@ -203,9 +203,9 @@ def test_hip_kernels_equal_the_reference_build(H, W, frac):
         pytest.skip("oracle/_ref/libcoarse_tracker_ref.so not present")
     p = pair(H, W, 5, frac)
     g, o = both(p)
-    aff_ref, aff_new, cutoff, expo = [0.02, 1.5], [-0.01, -0.7], 12.0, 0.9
+    aff_ref, aff_new, cutoff, expo = [0.02, 1.5], [0.03, 1.2], 12.0, 1.0
     for t in (g, o):
-        t.setReference(p["pc_u"], p["pc_v"], p["pc_idepth"], p["pc_color"], 1.3, aff_ref)
+        t.setReference(p["pc_u"], p["pc_v"], p["pc_idepth"], p["pc_color"], 1.0, aff_ref)
         t.setNew(p["dI_new"])
     out_g, sums_g = g.calcRes(p["refToNew"], expo, aff_new, cutoff, return_sums=True)
     r2n, Ki, a2, maxE, rb = o.kernel_inputs(p["refToNew"], expo, aff_new, cutoff)   # host-side input preparation only
