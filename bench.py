@@ -10,8 +10,15 @@ A "step" is one pass of the DrMvsnet hot path (pre-process .. edge filter) over 
 that is already resident in HBM when the timed region starts.  Workload at every N = BASELINE configs[1]:
 640x480, ref + 6 src views, 3-stage cascade with (48,32,8) depth planes, fp32, view aggregation on.
 Multi-GPU: independent replicas, one window stream per rank, no data-path collective ("scaling": "weak");
-value = depth maps of all ranks / max-over-ranks time.  Rank 0 prints ONE JSON line; the TSDF half of the
-metric (BASELINE configs[3] shape: 640x480 scans into a 5 mm hashed grid) rides along in its "tsdf" object.
+value = depth maps of all ranks / max-over-ranks time.  Rank 0 prints ONE JSON line.  Riding along in it:
+  "boundary"  the same windows through the operator boundary the reference times (CallAsync / Ready / GetResult,
+              dr_mvsnet.cpp:540-545): host u8 images in, four float maps out -- PCIe-inclusive, never `value`;
+  "tsdf"      BASELINE configs[3]: 1000 distinct depth maps of a camera loop through an analytic room fused into a 5 mm
+              hashed voxel grid, integrate + ray-cast per frame, map growing (dr_debug_example.cpp:78-162);
+  "tandem_loop"  BASELINE configs[4] stand-in: TandemBackend's call order (depth network of keyframe k beside fusion +
+              ray-cast of k-1) through the C++ shim on one GPU, keyframes/s;
+  "tracker", "view_sharded" (N > 1).
+`python bench.py --gpus N` without a torch.distributed.run environment spawns the N ranks itself.
 """
 import argparse
 import json
@@ -36,6 +43,24 @@ def pmc_traffic(kernel):
     if not e or "fetch_bytes_corrected" not in e or "write_bytes" not in e:
         return None
     return e["fetch_bytes_corrected"] + e["write_bytes"]
+
+
+def host_cores():
+    """(physical cores, logical CPUs) of this box, from /proc/cpuinfo."""
+    phys, logical = set(), 0
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("processor"):
+                logical += 1
+            elif line.startswith("physical id"):
+                pid = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":")[1].strip()
+                phys.add((pid, cid))
+    except OSError:
+        pass
+    return (len(phys) or os.cpu_count() or 1), (logical or os.cpu_count() or 1)
 
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA (== fp32 vector) peak
@@ -83,9 +108,10 @@ def mvsnet_leg(args, rank, dev, world):
     replicas.barrier(dev)
     tmax, units = replicas.reduce_max_sum(t1 - t0, args.steps, dev)
     res = dict(value=units / tmax, ms_per_step=1e3 * tmax / args.steps, event_ms_per_step=max(ev) / args.steps, engines_per_gpu=E)  # engines run concurrently: the slowest one's hipEvent span covers the job
-    if E > 1 and rank == 0:  # the single-window latency next to the throughput figure
-        lat = m.forward(10) / 10
-        res["single_engine"] = dict(ms_per_depth_map=lat, depth_maps_per_s=1e3 / lat)
+    if rank == 0:  # the single-window latency (ONE DrMvsnet object = TANDEM's usage) next to the throughput figure
+        nlat = max(10, min(100, args.steps))
+        lat = m.forward(nlat) / nlat
+        res["single_engine"] = dict(ms_per_depth_map=lat, depth_maps_per_s=1e3 / lat, forwards=nlat)
     for extra in engines[1:]:
         extra.close()
     if rank == 0:
@@ -113,76 +139,173 @@ def mvsnet_leg(args, rank, dev, world):
 
 
 def mvsnet_cpu_baseline(win, blob):
-    """The CPU restatement of the reference model (oracle, kind "port": same ATen op family as the reference's
-    eval path) on the host cores of this box, same window, model forward only."""
+    """The reference's CPU path on the host cores of this box, same window, model forward only (eval.py's FPS also
+    counts its DataLoader and metrics, which cannot run without the dataset).  kind "reference": the reference's own
+    CvaMVSNet imported from /root/reference (oracle/ref_model.py) when that checkout exists (the build container);
+    kind "port": oracle/mvsnet_oracle.py -- the same ATen CPU ops, bit-identical to the reference model on the committed
+    fixtures -- where it does not (the GPU box)."""
     import torch
-    from oracle import mvsnet_oracle as O
     from tandem_amd import weights as Wt
     meta, tens = Wt.read_blob(blob)
-    w = O.Weights(meta, tens)
-    cores = torch.get_num_threads()
-    run = lambda: O.forward(w, win["bgrs"], win["K"], win["c2ws"], win["ref_index"], win["depth_min"], win["depth_max"], DISCARD)
+    phys, logical = host_cores()
+    torch.set_num_threads(phys)
+    kind, run = "port", None
+    if os.path.isdir("/root/reference/cva_mvsnet"):
+        try:
+            from oracle import mvsnet_oracle as O, ref_model
+            net, cva = ref_model.build((48, 32, 8), tens, view_aggregation=True)
+            image, Ks, c2w = O.preprocess(win["bgrs"], win["K"], win["c2ws"], win["ref_index"])
+            run = lambda: ref_model.run(net, cva, image, Ks, c2w, win["depth_min"], win["depth_max"], DISCARD)
+            kind = "reference"
+        except Exception as e:  # fall back to the port, say why
+            print("bench.py: reference model not usable (%s); timing the port" % e, file=sys.stderr)
+    if run is None:
+        from oracle import mvsnet_oracle as O
+        w = O.Weights(meta, tens)
+        run = lambda: O.forward(w, win["bgrs"], win["K"], win["c2ws"], win["ref_index"], win["depth_min"], win["depth_max"], DISCARD)
     run()  # warm-up
     times = []
-    while len(times) < 3 and sum(times) < 20.0:
+    while len(times) < 5 and sum(times) < 25.0:
         t0 = time.perf_counter(); run(); times.append(time.perf_counter() - t0)
-    best = min(times)
-    return dict(value=1.0 / best, unit="depth-maps/s", cores=cores, kind="port",
-                sample="%d timed forwards of the same 640x480x7-view (48,32,8) window after 1 warm-up, torch CPU fp32, best %.2f s" % (len(times), best))
+    med = sorted(times)[len(times) // 2]
+    return dict(value=1.0 / med, unit="depth-maps/s", cores=torch.get_num_threads(), physical_cores=phys, logical_cpus=logical, kind=kind,
+                sample="%d timed forwards of the same 640x480x7-view (48,32,8) window after 1 warm-up, torch CPU fp32, %d threads; median %.2f s, best %.2f s"
+                       % (len(times), torch.get_num_threads(), med, min(times)))
+
+
+def boundary_leg(args, dev):
+    """The operator boundary as the reference times it (test_dr_mvsnet, dr_mvsnet.cpp:540-545): CallAsync(host u8 images,
+    K, poses) -> Ready -> GetResult (four host float maps) per window, E engines = E independent DrMvsnet objects.
+    PCIe-inclusive: 6.45 MB in, 4.9 MB out per depth map."""
+    import threading
+    from oracle import scene
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    blob = os.path.join(ROOT, "weights", "tandem_va.tdmw")
+    out = {}
+    per = max(10, min(60, args.steps // 3))
+    for E in (1, 3):
+        engines = [DrMvsnet(blob, device=dev) for _ in range(E)]
+        wins = [scene.make_window(H, W, V, seed=40 + e) for e in range(E)]
+        call_ms = [0.0] * E
+
+        def loop(e, n):
+            m, w = engines[e], wins[e]
+            for _ in range(n):
+                t0 = time.perf_counter()
+                m.CallAsync(H, W, V, w["ref_index"], w["bgrs"], w["K"], list(w["c2ws"]), w["depth_min"], w["depth_max"], DISCARD)
+                call_ms[e] += 1e3 * (time.perf_counter() - t0)
+                m.GetResult()
+        for e in range(E):
+            loop(e, 3)  # warm-up (plans, pinned buffers)
+        call_ms = [0.0] * E
+        threads = [threading.Thread(target=loop, args=(e, per)) for e in range(E)]
+        t0 = time.perf_counter()
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        dt = time.perf_counter() - t0
+        out["engines_%d" % E] = dict(depth_maps_per_s=E * per / dt, ms_per_depth_map_per_engine=1e3 * dt / per,
+                                     call_async_ms=sum(call_ms) / (E * per), windows=E * per)
+        for m in engines:
+            m.close()
+    out["note"] = "CallAsync(host u8 BGR x7, K, poses) -> GetResult (4 float maps) per window; host reorder + H2D + forward + D2H"
+    return out
 
 
 def tsdf_leg(args, rank, dev, world):
+    """BASELINE configs[3] as dr_debug_example.cpp:78-162 runs it: `--tsdf-frames` DISTINCT depth maps from a camera loop
+    through an analytic room (oracle/room.py, generated straight into HBM), per frame allocate + integrate and one
+    ray-cast from the frame's pose (incl. the D2H of the rendered images), into a map that starts empty and keeps
+    growing.  value = voxels updated by the whole run / its duration (hipEvents, first allocate .. last copy)."""
     import torch
-    from oracle import scene
+    from oracle import room
     from tandem_amd import replicas
     from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
-    distinct, cycles = args.tsdf_scans, args.tsdf_cycles
-    sc = scene.make_scans(distinct, H, W, seed=100 + rank, texture_terms=3)
-    opt = dict(voxel_size=0.005, num_buckets=400000, bucket_size=10, num_blocks=2000000, block_size=8, max_sdf_weight=64,
+    n = args.tsdf_frames
+    poses = room.loop_poses(n, seed=7 + rank)
+    fr = room.render_frames(poses, H, W, device="cuda:%d" % dev, seed=rank)
+    opt = dict(voxel_size=0.005, num_buckets=500000, bucket_size=10, num_blocks=2500000, block_size=8, max_sdf_weight=64,
                truncation_distance=0.02, max_sensor_depth=10.0, min_sensor_depth=0.1, num_render_streams=1,
-               fx=sc["fx"], fy=sc["fy"], cx=sc["cx"], cy=sc["cy"], height=H, width=W)
+               fx=fr["fx"], fy=fr["fy"], cx=fr["cx"], cy=fr["cy"], height=H, width=W)
+    torch.cuda.synchronize()
+    warm = DrFusion(DrFusionOptions(**dict(opt, num_blocks=400000)), device=dev)  # loads the kernels; its map is thrown away
+    warm.bench_sequence(fr["bgr"].data_ptr(), fr["depth"].data_ptr(), poses[:2], render=True)
+    warm.close()
     f = DrFusion(DrFusionOptions(**opt), device=dev)
-    bgrs = [s[0] for s in sc["scans"]] * cycles
-    depths = [s[1] for s in sc["scans"]] * cycles
-    poses = [s[2] for s in sc["scans"]] * cycles
-    f.bench_integrate(bgrs[:distinct], depths[:distinct], poses[:distinct])  # warm-up pass: allocates the map once
-    before = f.stats()
     replicas.barrier(dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ms, kms = f.bench_integrate(bgrs, depths, poses)  # resident scans; hipEvents on the integration stream
+    ms = f.bench_sequence(fr["bgr"].data_ptr(), fr["depth"].data_ptr(), poses, render=True)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     replicas.barrier(dev)
-    after = f.stats()
-    vox = after["updated_total"] - before["updated_total"]
-    tmax, units = replicas.reduce_max_sum(ms * 1e-3, vox, dev)
-    res = dict(metric="TSDF voxels integrated/sec", value=units / tmax, unit="voxels/s", scans=len(bgrs),
-               ms_per_scan=1e3 * tmax / len(bgrs), wall_ms_per_scan_incl_upload=1e3 * (t1 - t0) / len(bgrs),
-               blocks=after["blocks"], voxels_per_scan=vox / len(bgrs),
-               config=dict(workload="%d integrations (%d distinct synthetic 640x480 scans x %d cycles) into a 5 mm hashed voxel grid, truncation 20 mm, "
-                                    "allocate + integrate kernels, scans resident in HBM" % (len(bgrs), distinct, cycles)))
+    st = f.stats()
+    vox = st["updated_total"]
+    tmax, units = replicas.reduce_max_sum(ms["total"] * 1e-3, vox, dev)
+    res = dict(metric="TSDF voxels integrated/sec", value=units / tmax, unit="voxels/s", frames=n,
+               ms_per_frame=1e3 * tmax / n, wall_ms_per_frame=1e3 * (t1 - t0) / n, frames_per_s=n * world / tmax,
+               blocks=st["blocks"], voxels_per_frame=vox / n, mismatches=st["mismatches"],
+               kernel_ms_per_frame=dict(allocate=ms["allocate"] / n, integrate=ms["integrate"] / n, raycast=ms["raycast"] / n,
+                                        render_d2h=ms["d2h"] / n),
+               integrate_only_voxels_per_s=vox / (ms["integrate"] * 1e-3),
+               config=dict(workload="%d distinct synthetic 640x480 depth maps (camera loop through a 6x4x3 m room with a sphere, 2.5 %% invalid "
+                                    "pixels) fused into an initially empty 5 mm hashed voxel grid (truncation 20 mm, 2.5 M blocks = 10 GB): per frame "
+                                    "allocate + integrate + one ray-cast from the frame's pose incl. D2H of the render; frames resident in HBM" % n))
     if rank == 0:
-        n = len(bgrs)
-        ach = 16.0 * vox / (kms * 1e-3) / 1e9
-        res["roofline"] = dict(bound="hbm", kernel="k_integrate", avg_launch_ms=kms / n, bytes_per_launch=16.0 * vox / n,
+        ach = 16.0 * vox / (ms["integrate"] * 1e-3) / 1e9
+        res["roofline"] = dict(bound="hbm", kernel="k_integrate", avg_launch_ms=ms["integrate"] / n, bytes_per_launch=16.0 * vox / n,
                                achieved=ach, peak=PEAK_HBM_GBPS, unit="GB/s", frac=ach / PEAK_HBM_GBPS, traffic=pmc_traffic("k_integrate"))
-        # raycast (DrFusion::RenderAsync) of the fused map, one 640x480 view
-        f.IntegrateScanAsync(*sc["scans"][0])
-        t0 = time.perf_counter(); f.RenderAsync([poses[0]]); f.GetRenderResult(); t1 = time.perf_counter()
-        res["raycast_ms_incl_d2h"] = 1e3 * (t1 - t0)
         # marching cubes (DrFusion::ExtractMeshAsync + GetMeshSync) of the fused map over TANDEM's (-5..5 m)^3 box
         # (tandem_backend.cpp:80-81): device time = until the triangle count is known, total adds the D2H copy
         lo, hi = (-5.0, -5.0, -5.0), (5.0, 5.0, 5.0)
-        f.ExtractMeshAsync(lo, hi); f.GetMeshSync()  # first call allocates the 1.44 GB triangle buffers
+        f.ExtractMeshAsync(lo, hi); f.GetMeshSync()  # first call allocates the triangle buffers
         t0 = time.perf_counter(); f.ExtractMeshAsync(lo, hi); ntri = f.mesh_num_triangles(); t1 = time.perf_counter()
         f.GetMeshSync(); t2 = time.perf_counter()
-        res["mesh"] = dict(triangles=ntri, blocks=after["blocks"], extract_ms=1e3 * (t1 - t0), get_ms_incl_d2h=1e3 * (t2 - t1),
+        res["mesh"] = dict(triangles=ntri, blocks=st["blocks"], extract_ms=1e3 * (t1 - t0), get_ms_incl_d2h=1e3 * (t2 - t1),
                            lattice="2000^3 cells at 5 mm, visited per allocated block")
         if world == 1 and not args.no_cpu:
-            res["cpu_baseline"] = tsdf_cpu_baseline(sc, opt)
+            k = min(n, 8)
+            res["cpu_baseline"] = tsdf_cpu_baseline([(fr["bgr"][i].cpu().numpy(), fr["depth"][i].cpu().numpy(), poses[i]) for i in range(k)], opt)
     f.close()
+    del fr
+    torch.cuda.empty_cache()
     return res
+
+
+def tandem_loop_leg(args, dev):
+    """BASELINE configs[4] stand-in (the DSO front-end cannot run here): TandemBackend's call order through the C++ shim,
+    tools/tandem_loop.cpp compiled with g++ against tandem_amd/libdr/*.h and the C ABI -- CallAsync(k) beside
+    IntegrateScanAsync / RenderAsync / GetRenderResult of k-1 -- on this GPU, host buffers at the boundary."""
+    import subprocess
+    import tempfile
+    from oracle import scene
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from export_fixture import write_tdms
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "tandem_loop")
+        try:
+            subprocess.check_call(["g++", "-std=c++14", "-O2", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tandem_amd", "libdr"),
+                                   os.path.join(ROOT, "tools", "tandem_loop.cpp"), "-o", exe, "-L" + os.path.join(ROOT, "tandem_amd"),
+                                   "-ldr_mi355x", "-Wl,-rpath," + os.path.join(ROOT, "tandem_amd")])
+        except (OSError, subprocess.CalledProcessError) as e:
+            return dict(error="g++ build of tools/tandem_loop.cpp failed: %s" % e)
+        blob = os.path.join(ROOT, "weights", "tandem_va.tdmw")
+        for name, (h, w, vs) in (("640x480_5mm", (480, 640, "0.005")), ("640x480_10mm", (480, 640, "0.01"))):
+            win = scene.make_window(h, w, V, seed=5)
+            sample = os.path.join(td, name + ".tdms")
+            z = np.zeros((h, w), np.float32)
+            write_tdms(sample, np.stack(win["bgrs"]), win["K"], win["c2ws"], win["ref_index"], win["depth_min"], win["depth_max"], DISCARD, z, z)
+            env = dict(os.environ, HIP_VISIBLE_DEVICES=str(dev)) if dev else dict(os.environ)
+            r = subprocess.run([exe, blob, sample, str(args.loop_keyframes), vs, "0", "1"], capture_output=True, text=True, timeout=900, env=env)
+            if r.returncode != 0:
+                out[name] = dict(error=(r.stdout + r.stderr)[-500:])
+                continue
+            out[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    out["note"] = ("tandem_backend.cpp:137-283 call order through the header-compatible shim; depth network of keyframe k overlaps fusion + "
+                   "ray-cast of keyframe k-1; (48,32,8) planes, discard 10 %, dense tracking render on; TANDEM's own setting is 10 mm")
+    return out
 
 
 def tracker_leg(args, dev):
@@ -276,39 +399,53 @@ def view_shard_leg(args, rank, dev, world):
                 note="one window sharded over the ranks; 3 fp32 volume all-reduces (RCCL) per depth map; phases host-synchronised")
 
 
-def tsdf_cpu_baseline(sc, opt):
+def tsdf_cpu_baseline(scans, opt):
     from oracle.tsdf_oracle import TsdfOracle
-    o = TsdfOracle(**dict(opt, num_blocks=400000))
-    n, t, upd = 0, 0.0, 0
-    for bgr, depth, pose in sc["scans"]:
+    o = TsdfOracle(**dict(opt, num_blocks=600000))
+    n, t = 0, 0.0
+    for bgr, depth, pose in scans:
         t0 = time.perf_counter(); o.integrate(bgr, depth, pose); t += time.perf_counter() - t0
         n += 1
         if t > 15.0:
             break
     upd = o.stats()["updated_total"]
     return dict(value=upd / t, unit="voxels/s", cores=1, kind="port",
-                sample="first %d of the same 640x480 scans, single-threaded C restatement (oracle/tsdf_oracle.c), %.1f s" % (n, t))
+                sample="allocate + integrate of the first %d of the same frames, single-threaded C restatement (oracle/tsdf_oracle.c, pinned to the "
+                       "reference build by tests/test_ref_fusion.py), %.1f s" % (n, t))
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` without a torch.distributed.run environment: launch the N ranks ourselves."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--tsdf-scans", type=int, default=50, help="distinct synthetic scans for the TSDF leg")
-    ap.add_argument("--tsdf-cycles", type=int, default=20, help="times the scan set is re-integrated (default 50 x 20 = 1000 integrations)")
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--tsdf-frames", type=int, default=1000, help="distinct synthetic depth maps fused by the TSDF leg (BASELINE configs[3])")
+    ap.add_argument("--loop-keyframes", type=int, default=100, help="keyframes of the TandemBackend-shaped loop (tools/tandem_loop.cpp)")
+    ap.add_argument("--no-boundary", action="store_true", help="skip the operator-boundary (CallAsync/GetResult) leg")
+    ap.add_argument("--no-loop", action="store_true", help="skip the TandemBackend-shaped loop leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
     ap.add_argument("--engines", type=int, default=3, help="DrMvsnet engines (independent windows in flight) per GPU; 1 = latency configuration")
     ap.add_argument("--no-tsdf", action="store_true")
     ap.add_argument("--no-view-shard", action="store_true", help="N > 1 only: skip the view-sharded (configs[2]) leg")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args)
     import torch
     from tandem_amd import replicas
     rank, local_rank, world = replicas.env_world()
     if world != args.gpus and rank == 0:
-        print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run (running %d replica%s)"
-              % (args.gpus, world, world, "" if world == 1 else "s"), file=sys.stderr)
+        print("bench.py: --gpus %d but WORLD_SIZE=%d (running %d replica%s)" % (args.gpus, world, world, "" if world == 1 else "s"), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
     # test scaffolding for 1-GPU boxes: DR_BENCH_ONE_DEVICE=1 runs every rank on cuda:0 over gloo (RCCL refuses two ranks
@@ -322,6 +459,8 @@ def main():
     mv = mvsnet_leg(args, rank, local_rank, world)
     ts = None if args.no_tsdf else tsdf_leg(args, rank, local_rank, world)
     tr = tracker_leg(args, local_rank) if (rank == 0 and not args.no_tsdf) else None
+    bd = boundary_leg(args, local_rank) if (rank == 0 and world == 1 and not args.no_boundary) else None
+    lp = tandem_loop_leg(args, local_rank) if (rank == 0 and world == 1 and not args.no_loop) else None
     vs = None
     if world > 1 and not args.no_view_shard:
         vs = view_shard_leg(args, rank, local_rank, world)
@@ -344,6 +483,10 @@ def main():
                 out[k] = mv[k]
         if ts is not None:
             out["tsdf"] = ts
+        if bd is not None:
+            out["boundary"] = bd
+        if lp is not None:
+            out["tandem_loop"] = lp
         if tr is not None:
             out["tracker"] = tr
         if vs is not None:

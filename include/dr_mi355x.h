@@ -168,6 +168,10 @@ int drf_stats(drf_t *h, uint64_t out[4]);
 /* Canonical dump for bit-exact comparison: coords[3*i..] block coordinates, voxels[4096*i..] the
  * 512 8-byte voxels {f32 sdf, u8 b,g,r, u8 weight} of block i in index order x*64+y*8+z. */
 int drf_export_blocks(drf_t *h, int max_blocks, int32_t *coords, uint8_t *voxels, int *n);
+/* The engine divides by voxel_size, fx and fy with a 3-instruction exact sequence (reciprocal + FMA correction) after
+ * checking it against IEEE division for all 2^32 dividends at construction: *enabled = 1 if every check passed (else the
+ * kernels use IEEE division), *mismatches = number of disagreeing dividends found. */
+int drf_fast_div_status(drf_t *h, int *enabled, uint64_t *mismatches);
 /* Test hook: out[i] = Combine(a[i], b[i], max_weight) evaluated by the integration kernel's own device function
  * (voxel.h:21-50), n 8-byte voxels {f32 sdf, u8 b,g,r, u8 weight} each -- lets a test sweep every colour/weight case. */
 int drf_test_combine(drf_t *h, size_t n, const uint8_t *a, const uint8_t *b, int max_weight, uint8_t *out);

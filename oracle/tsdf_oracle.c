@@ -63,6 +63,7 @@ typedef struct {
   int *table;             /* open-addressing map: slot -> block index or -1 */
   unsigned tmask;
   unsigned long long updated_last, updated_total, mismatches;
+  unsigned long long dda_capped; /* rays whose DDA ran into ORACLE_MAX_DDA (the reference would not terminate) */
   int overflow;
 } tsdf_t;
 
@@ -300,6 +301,7 @@ static void allocate_from_depth(tsdf_t *t, const float *depth, const float *T) {
       }
       allocate_block(t, bp);
     }
+    if (steps > ORACLE_MAX_DDA) t->dda_capped++;
   }
 }
 
@@ -393,6 +395,7 @@ void tsdf_render(const tsdf_t *t, const float *pose16, unsigned char *bgr_out, f
 }
 
 int tsdf_num_blocks(const tsdf_t *t) { return t->nblk; }
+unsigned long long tsdf_dda_capped(const tsdf_t *t) { return t->dda_capped; }
 void tsdf_stats(const tsdf_t *t, unsigned long long out[4]) {
   out[0] = (unsigned long long)t->nblk; out[1] = t->updated_last; out[2] = t->updated_total; out[3] = t->mismatches;
 }

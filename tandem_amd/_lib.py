@@ -72,6 +72,7 @@ SIGNATURES = {
     "drf_synchronize": (C.c_int, [vp]),
     "drf_stats": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "drf_export_blocks": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int32), u8p, C.POINTER(C.c_int)]),
+    "drf_fast_div_status": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
     "drf_test_combine": (C.c_int, [vp, C.c_size_t, u8p, u8p, C.c_int, u8p]),
     "drf_integrate_device": (C.c_int, [vp, vp, vp, f32p]),
     "drt_create": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.POINTER(vp)]),

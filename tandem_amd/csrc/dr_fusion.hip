@@ -51,9 +51,22 @@ struct FusionDev {  // everything the kernels need, passed by value
   int *err;                  // [0] pool exhausted, [1] coordinate out of packing range
   unsigned long long *cnt;   // [0] voxels updated by the current scan, [1] total, [2] round-trip mismatches
   float *sd;                 // [H*W] per-pixel surface distance |GetPoint3d(i, depth)| of the current scan
-  unsigned *present;         // kPresentBits^3-bit map: bit set <=> that block is in the table (a cache of the table, no state)
+  unsigned *present;         // kPresentBits^3-bit map: bit set <=> that block is allocated (a cache of `grid`, no state)
+  // Dense direct-mapped block index for the block coordinates [-256, 256)^3 (+-10 m at 5 mm voxels, +-20 m at 1 cm): one
+  // int per cell, 512 MiB of the 288 GB -- 0 = absent, -1 = requested by the allocation pass of the current scan,
+  // p + 1 = pool block p.  A block lookup inside the region is ONE load (ray-cast: 9 lookups per sphere-tracing step);
+  // blocks outside it live in the open-addressing table above (keys / vals).
+  int *grid;
+  unsigned *req;             // [num_blocks] grid cells requested by the current scan (k_allocate -> k_alloc_commit)
+  int *req_count;
+  int *vis;                  // [num_blocks] pool blocks that pass IntegrateScanKernel's per-block test for the current scan
+  int *vis_count;            // (k_cull -> k_integrate; == req_count + 1)
+  unsigned *wg_upd;          // [integrate grid] voxels updated per workgroup of k_integrate (summed by k_fold_counter)
+  float vs_rcp, fx_rcp, fy_rcp;  // correctly rounded reciprocals of voxel_size, fx, fy for the exact fast divisions below
+  int fast_div;              // 1: the three reciprocals passed the exhaustive check against IEEE division (verify_fast_div)
 };
-constexpr int kPresentBits = 9;  // blocks within [-256, 256)^3 (+-10 m at 4 cm blocks): 16 MiB, L2/MALL resident
+constexpr int kPresentBits = 9;  // blocks within [-256, 256)^3: 16 MiB bitmap, L2/MALL resident
+constexpr int kGridBits = kPresentBits;
 
 // ---- CUDA float->int conversion semantics (cvt.rzi: saturate, NaN -> 0), see oracle header (4) ----
 // v_cvt_i32_f32 IS that conversion (truncate, saturate, NaN -> 0: CDNA ISA "V_CVT_I32_F32"); written as inline asm
@@ -68,6 +81,34 @@ __device__ inline unsigned char f2u8(float f) {
   if (!(f > 0.0f)) return 0;
   if (f >= 255.0f) return 255;
   return (unsigned char)f;
+}
+
+// Exact fp32 division by a per-engine constant b (voxel_size, fx, fy) in three instructions instead of the ~12 of the IEEE
+// sequence (v_div_scale/v_rcp/4 v_fma/v_div_fmas/v_div_fixup + two denormal-mode switches): with y = RN(1/b),
+//   q0 = RN(a*y);  r = a - b*q0 (exact, one FMA);  q = RN(q0 + r*y)  ==  RN(a/b)
+// (Markstein's correction step: q0 is within one ulp of a/b, the FMA residual is exact, the final FMA rounds correctly).
+// Not taken on trust: FusionEngine's constructor checks q against a/b for ALL 2^32 dividends for each of the three
+// divisors (k_verify_fast_div, ~10 ms each) and the kernels use the IEEE division if any finite dividend with
+// 2^-100 <= |a| <= 2^100 (or a = 0) disagrees; dividends outside that range always take the IEEE path (in_fast_range).
+__device__ inline float div_exact(float a, float b, float y) {
+  const float q0 = a * y;
+  const float r = __builtin_fmaf(-q0, b, a);
+  return __builtin_fmaf(r, y, q0);
+}
+__device__ inline bool in_fast_range(float a) {  // 0, or 2^-100 <= |a| <= 2^100 (also false for NaN / Inf)
+  const float m = fabsf(a);
+  return a == 0.0f || (m >= 7.8886090522101181e-31f && m <= 1.2676506002282294e30f);
+}
+__global__ void k_verify_fast_div(float b, float y, unsigned long long *mismatches) {
+  unsigned long long bad = 0;
+  for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < (1ull << 32); i += (unsigned long long)gridDim.x * blockDim.x) {
+    const float a = __uint_as_float((unsigned)i);
+    if (!in_fast_range(a)) continue;
+    const float q = div_exact(a, b, y), e = a / b;
+    // +-0 compare equal on purpose: every use adds a signed 0.5 / subtracts floor() / feeds f2i (see get_voxel2)
+    if (!(q == e)) ++bad;
+  }
+  if (bad) atomicAdd(mismatches, bad);
 }
 
 struct F3 { float x, y, z; };
@@ -118,7 +159,14 @@ __device__ inline unsigned hash_key(unsigned long long k) {
   k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
   return (unsigned)k;
 }
-__device__ inline int find_block(const FusionDev &d, I3 p) {
+__device__ inline bool grid_index(I3 p, unsigned &idx) {  // dense region [-256, 256)^3, z fastest
+  constexpr int H = 1 << (kGridBits - 1);
+  const unsigned x = (unsigned)(p.x + H), y = (unsigned)(p.y + H), z = (unsigned)(p.z + H);
+  if ((x | y | z) >> kGridBits) return false;
+  idx = (x << (2 * kGridBits)) | (y << kGridBits) | z;
+  return true;
+}
+__device__ inline int find_block_table(const FusionDev &d, I3 p) {  // blocks outside the dense region
   unsigned long long key;
   if (!pack_key(p, key)) return -1;
   unsigned s = hash_key(key) & d.cmask;
@@ -130,27 +178,28 @@ __device__ inline int find_block(const FusionDev &d, I3 p) {
   }
   return -1;
 }
-// Insert-if-absent (HashTable::AllocateBlock, hash_table.cu:80-115, without the try-lock drop).
-// The allocation DDA asks for ~60 blocks per pixel and, once a map exists, almost all of them are there already.  A
-// dense presence bitmap answers that with one load from a 16 MiB array instead of a probe into the (much larger) key
-// table; blocks outside its range, and first-time inserts, take the table path.
-__device__ inline bool present_index(I3 p, unsigned &idx) {
-  constexpr int H = 1 << (kPresentBits - 1);
-  const unsigned x = (unsigned)(p.x + H), y = (unsigned)(p.y + H), z = (unsigned)(p.z + H);
-  if ((x | y | z) >> kPresentBits) return false;
-  idx = (x << (2 * kPresentBits)) | (y << kPresentBits) | z;
-  return true;
+__device__ inline int find_block(const FusionDev &d, I3 p) {
+  unsigned idx;
+  if (grid_index(p, idx)) return d.grid[idx] - 1;  // 0 / -1 (absent / only requested) -> negative
+  return find_block_table(d, p);
 }
-__device__ inline void allocate_block(const FusionDev &d, I3 p) {
-  unsigned pidx = 0;
-  const bool in_map = present_index(p, pidx);
-  if (in_map && ((d.present[pidx >> 5] >> (pidx & 31)) & 1u)) return;
+// Insert-if-absent (HashTable::AllocateBlock, hash_table.cu:80-115, without the try-lock drop).
+// The allocation DDA asks for ~60 blocks per pixel and, once a map exists, almost all of them are there already: a dense
+// presence bitmap answers that with one load from a 16 MiB array.  A block that is NOT there yet is wanted by every ray
+// that crosses it -- a few hundred lanes at about the same moment -- so the insert itself is made once per block:
+//   * inside the dense region the first lane to turn the block's grid cell from 0 (absent) to -1 (requested) appends the
+//     cell to the request list (lanes of one wave that want the same cell elect one of them first, so the word is hit by
+//     one CAS per wave instead of one per lane; everybody else sees -1 with a plain load); k_alloc_commit then hands out
+//     the pool blocks, one lane per request, no contention.  (Measured on the BASELINE configs[3] loop: the old path --
+//     atomic load + CAS + atomicOr per lane per new block -- took 0.42-1.4 ms per frame while the map grew, 0.04 built.)
+//   * outside it (|block coordinate| >= 256) the open-addressing table takes the insert directly, as before.
+__device__ inline void allocate_block_table(const FusionDev &d, I3 p) {
   unsigned long long key;
   if (!pack_key(p, key)) { d.err[1] = 1; return; }
   unsigned s = hash_key(key) & d.cmask;
   for (unsigned probe = 0; probe <= d.cmask; ++probe) {
     unsigned long long cur = __hip_atomic_load(&d.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cur == key) { if (in_map) atomicOr(&d.present[pidx >> 5], 1u << (pidx & 31)); return; }
+    if (cur == key) return;
     if (cur == kEmptyKey) {
       cur = atomicCAS(&d.keys[s], kEmptyKey, key);
       if (cur == kEmptyKey) {  // we own the slot: take a pool block
@@ -158,14 +207,68 @@ __device__ inline void allocate_block(const FusionDev &d, I3 p) {
         if (idx >= d.o.num_blocks) { d.err[0] = 1; d.vals[s] = -1; return; }
         d.vals[s] = idx;
         d.blk_key[idx] = key;
-        if (in_map) atomicOr(&d.present[pidx >> 5], 1u << (pidx & 31));
+        atomicAdd(&d.n_alloc[3], 1);  // blocks living in the table (outside the dense grid)
         return;
       }
-      if (cur == key) { if (in_map) atomicOr(&d.present[pidx >> 5], 1u << (pidx & 31)); return; }
+      if (cur == key) return;
     }
     s = (s + 1) & d.cmask;
   }
   d.err[0] = 1;
+}
+// Called by every lane of the wave in lockstep (`want` false for lanes that have nothing to insert at this DDA step).
+__device__ inline void allocate_block(const FusionDev &d, I3 p, bool want) {
+  unsigned idx = 0;
+  const bool in_grid = want && grid_index(p, idx);
+  bool need = in_grid && !((d.present[idx >> 5] >> (idx & 31)) & 1u);
+  if (need) need = __hip_atomic_load(&d.grid[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+  unsigned long long todo = __ballot(need);
+  if (todo) {
+    const int lane = (int)(threadIdx.x & 63);
+    bool won = false;
+    while (todo) {  // one CAS per distinct cell per wave
+      const int leader = __ffsll((long long)todo) - 1;
+      const unsigned lidx = (unsigned)__builtin_amdgcn_readlane((int)idx, leader);
+      const unsigned long long same = __ballot(need && idx == lidx);
+      if (lane == leader) won = atomicCAS(&d.grid[idx], 0, -1) == 0;
+      todo &= ~same;
+    }
+    const unsigned long long wm = __ballot(won);  // the wave's new requests go to the list with ONE atomicAdd
+    if (wm) {
+      int base = 0;
+      if (lane == __ffsll((long long)wm) - 1) base = atomicAdd(d.req_count, __popcll(wm));
+      base = __builtin_amdgcn_readlane(base, __ffsll((long long)wm) - 1);
+      if (won) {
+        const int r = base + __popcll(wm & ((1ull << lane) - 1));
+        if (r < d.o.num_blocks) d.req[r] = idx; else d.err[0] = 1;
+      }
+    }
+  }
+  if (want && !in_grid) allocate_block_table(d, p);
+}
+// One lane per requested cell: take a pool block (one atomicAdd per wave), publish it in the grid and the bitmap.
+__global__ __launch_bounds__(256) void k_alloc_commit(const FusionDev d) {
+  const int n = min(*d.req_count, d.o.num_blocks);
+  const int lane = threadIdx.x & 63;
+  for (int i0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63; i0 < n; i0 += gridDim.x * blockDim.x) {
+    const int i = i0 + lane;
+    const bool act = i < n;
+    const unsigned long long m = __ballot(act);
+    int base = 0;
+    if (lane == 0) base = atomicAdd(d.n_alloc, __popcll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (!act) continue;
+    const int p = base + __popcll(m & ((1ull << lane) - 1));
+    const unsigned idx = d.req[i];
+    if (p >= d.o.num_blocks) { d.err[0] = 1; d.grid[idx] = 0; continue; }
+    constexpr int H = 1 << (kGridBits - 1);
+    I3 c; c.x = (int)(idx >> (2 * kGridBits)) - H; c.y = (int)((idx >> kGridBits) & ((1u << kGridBits) - 1)) - H; c.z = (int)(idx & ((1u << kGridBits) - 1)) - H;
+    unsigned long long key = 0;
+    pack_key(c, key);
+    d.blk_key[p] = key;
+    d.grid[idx] = p + 1;
+    atomicOr(&d.present[idx >> 5], 1u << (idx & 31));
+  }
 }
 
 // ---- coordinate maps, tsdf_volume.cu:109-145 ----
@@ -193,14 +296,18 @@ __global__ __launch_bounds__(256) void k_allocate(const FusionDev d, const float
   const float trunc = o.truncation_distance;
   const float bsz = o.block_size * o.voxel_size;
   F3 start; start.x = T.m[3]; start.y = T.m[7]; start.z = T.m[11];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < size; i += gridDim.x * blockDim.x) {
-    const float dep = depth[i];
+  // every lane of a wave walks its own ray, but the insert helper is called in lockstep (it elects one lane per distinct
+  // block): lanes without a (valid) pixel, and lanes whose ray has ended, go along with want = false
+  const int i_end = ((size + 63) / 64) * 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < i_end; i += gridDim.x * blockDim.x) {
+    bool live = i < size;
+    const float dep = live ? depth[i] : 0.0f;
     // IntegrateScanKernel recomputes distance(0, GetPoint3d(idx, depth[idx])) for every voxel that projects to
     // pixel idx (tsdf_volume.cu:485-486); it depends on the pixel only, so it is evaluated once here.
-    d.sd[i] = norm3(point3d(o, i, dep));
-    if (dep < o.min_sensor_depth || dep > o.max_sensor_depth) continue;
-    const F3 point = xform(T, point3d(o, i, dep));
-    if (point.x == 0 && point.y == 0 && point.z == 0) continue;
+    if (live) d.sd[i] = norm3(point3d(o, i, dep));
+    if (dep < o.min_sensor_depth || dep > o.max_sensor_depth) live = false;
+    const F3 point = xform(T, point3d(o, live ? i : 0, dep));
+    if (point.x == 0 && point.y == 0 && point.z == 0) live = false;
     F3 dv; dv.x = point.x - start.x; dv.y = point.y - start.y; dv.z = point.z - start.z;
     const float dn = norm3(dv);
     F3 dir; dir.x = dv.x / dn; dir.y = dv.y / dn; dir.z = dv.z / dn;
@@ -224,16 +331,23 @@ __global__ __launch_bounds__(256) void k_allocate(const FusionDev d, const float
     if (bp.x != be.x && dir.x < 0) { diff.x--; neg = true; }
     if (bp.y != be.y && dir.y < 0) { diff.y--; neg = true; }
     if (bp.z != be.z && dir.z < 0) { diff.z--; neg = true; }
-    allocate_block(d, bp);
-    if (neg) { bp.x += diff.x; bp.y += diff.y; bp.z += diff.z; allocate_block(d, bp); }
+    allocate_block(d, bp, live);
+    if (__any(live && neg)) {
+      if (live && neg) { bp.x += diff.x; bp.y += diff.y; bp.z += diff.z; }
+      allocate_block(d, bp, live && neg);
+    }
     int steps = 0;
-    while ((bp.x != be.x || bp.y != be.y || bp.z != be.z) && steps++ < kMaxDDA) {
-      if (mt.x < mt.y) {
-        if (mt.x < mt.z) { bp.x += st.x; mt.x += dt.x; } else { bp.z += st.z; mt.z += dt.z; }
-      } else {
-        if (mt.y < mt.z) { bp.y += st.y; mt.y += dt.y; } else { bp.z += st.z; mt.z += dt.z; }
+    for (;;) {
+      const bool go = live && (bp.x != be.x || bp.y != be.y || bp.z != be.z) && steps++ < kMaxDDA;
+      if (!__any(go)) break;
+      if (go) {
+        if (mt.x < mt.y) {
+          if (mt.x < mt.z) { bp.x += st.x; mt.x += dt.x; } else { bp.z += st.z; mt.z += dt.z; }
+        } else {
+          if (mt.y < mt.z) { bp.y += st.y; mt.y += dt.y; } else { bp.z += st.z; mt.z += dt.z; }
+        }
       }
-      allocate_block(d, bp);
+      allocate_block(d, bp, go);
     }
   }
 }
@@ -274,6 +388,52 @@ __global__ void k_test_combine(const Voxel *__restrict__ a, const Voxel *__restr
 // One WAVE per allocated pool block (4 waves per workgroup, grid-strided): per-block work (pose transform of the
 // block origin, frustum test) is done once per wave, then 8 iterations of 64 voxels (lane = y*8+z of slab x), each
 // a coalesced 512-byte read-modify-write of the block.
+// IntegrateScanKernel's per-block test (tsdf_volume.cu:451-470: block origin in front of the camera plane, block centre
+// projects into the image) for EVERY allocated block, one LANE per block; survivors go to the visible list (one
+// atomicAdd per wave).  The map keeps growing while the camera sees a room-sized part of it: with one wave per allocated
+// block this test was half of k_integrate's instructions at 110 k blocks and would dominate at a million.
+__global__ __launch_bounds__(256) void k_cull(const FusionDev d, const Mat Ti) {
+  const drf_options_t &o = d.o;
+  constexpr int bs = kBS;
+  const float vs = o.voxel_size;
+  const int lane = threadIdx.x & 63;
+  const int n_blocks = min(*d.n_alloc, o.num_blocks);  // written by k_alloc_commit earlier on this stream
+  __shared__ int wcount[4], wbase;
+  for (int e0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63; (e0 & ~255) < n_blocks; e0 += gridDim.x * blockDim.x) {  // uniform per workgroup
+    const int e = e0 + lane;
+    bool vis = false;
+    if (e < n_blocks) {
+      const I3 P = unpack_key(d.blk_key[e]);
+      F3 position; position.x = P.x * vs * bs; position.y = P.y * vs * bs; position.z = P.z * vs * bs;
+      const F3 pc = xform(Ti, position);
+      if (!(pc.z < 0)) {
+        F3 center;  // tsdf_volume.cu:461-465 -- the half-block offset is added in double
+        center.x = (float)((double)pc.x + 0.5 * (double)vs * (double)bs);
+        center.y = (float)((double)pc.y + 0.5 * (double)vs * (double)bs);
+        center.z = (float)((double)pc.z + 0.5 * (double)vs * (double)bs);
+        int cx, cy;
+        project(o, center, cx, cy);
+        vis = cx >= 0 && cy >= 0 && cx < o.width && cy < o.height;
+      }
+    }
+    // one atomicAdd per WORKGROUP and iteration (a single address takes ~10^8 atomics/s: one per wave was measurable)
+    const unsigned long long m = __ballot(vis);
+    const int wave = threadIdx.x >> 6;
+    if (lane == 0) wcount[wave] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int tot = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+      wbase = tot ? atomicAdd(d.vis_count, tot) : 0;
+    }
+    __syncthreads();
+    int base = wbase;
+    for (int w = 0; w < wave; ++w) base += wcount[w];
+    if (vis) d.vis[base + __popcll(m & ((1ull << lane) - 1))] = e;
+    __syncthreads();
+  }
+}
+
+// One WAVE per VISIBLE block (k_cull's list).
 __global__ __launch_bounds__(256) void k_integrate(const FusionDev d, const unsigned char *__restrict__ bgr,
                                                    const float *__restrict__ depth, const Mat T, const Mat Ti) {
   const drf_options_t &o = d.o;
@@ -282,19 +442,12 @@ __global__ __launch_bounds__(256) void k_integrate(const FusionDev d, const unsi
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int by = lane >> 3, bz = lane & 7;
   unsigned upd = 0;
-  const int n_blocks = min(*d.n_alloc, o.num_blocks);  // written by k_allocate earlier on this stream
-  for (int e = blockIdx.x * 4 + wave; e < n_blocks; e += gridDim.x * 4) {
+  const int n_vis = *d.vis_count;
+  for (int iv = blockIdx.x * 4 + wave; iv < n_vis; iv += gridDim.x * 4) {
+    const int e = d.vis[iv];
     const I3 P = unpack_key(d.blk_key[e]);
     F3 position; position.x = P.x * vs * bs; position.y = P.y * vs * bs; position.z = P.z * vs * bs;
     const F3 pc = xform(Ti, position);
-    if (pc.z < 0) continue;  // uniform per block
-    F3 center;  // tsdf_volume.cu:461-465 -- the half-block offset is added in double
-    center.x = (float)((double)pc.x + 0.5 * (double)vs * (double)bs);
-    center.y = (float)((double)pc.y + 0.5 * (double)vs * (double)bs);
-    center.z = (float)((double)pc.z + 0.5 * (double)vs * (double)bs);
-    int cx, cy;
-    project(o, center, cx, cy);
-    if (!(cx >= 0 && cy >= 0 && cx < o.width && cy < o.height)) continue;
     Voxel *blk_vox = d.vox + (size_t)e * (bs * bs * bs);
     // UpdateVoxel's world -> cam -> world round trip (below) is, per voxel, the map  vp -> T*(Ti*vp)  = an affine map
     // plus fp32 rounding noise (< 1e-4 m for |coordinates| < 64 m).  An affine deviation is extremal at the corners of
@@ -402,8 +555,13 @@ __global__ __launch_bounds__(256) void k_integrate(const FusionDev d, const unsi
       ++upd;
     }
   }
+  // voxels updated: one plain store per workgroup (k_fold_counter adds them up) instead of an atomicAdd per wave on one
+  // address -- with one block per wave that atomic was the longest thing the kernel did
   for (int off = 32; off > 0; off >>= 1) upd += __shfl_down(upd, off);
-  if (lane == 0 && upd) atomicAdd(&d.cnt[0], (unsigned long long)upd);
+  __shared__ unsigned wupd[4];
+  if (lane == 0) wupd[wave] = upd;
+  __syncthreads();
+  if (threadIdx.x == 0) d.wg_upd[blockIdx.x] = wupd[0] + wupd[1] + wupd[2] + wupd[3];
 }
 
 // ------------------------------------------------------------------ raycast
@@ -483,8 +641,180 @@ __global__ __launch_bounds__(64) void k_raycast(const FusionDev d, const Mat pos
   }
 }
 
-__global__ void k_fold_counter(unsigned long long *cnt) {  // end of scan: last -> total
-  if (threadIdx.x == 0 && blockIdx.x == 0) { cnt[1] += cnt[0]; cnt[3] = cnt[0]; cnt[0] = 0; }
+// ---- ray-cast, second generation: same arithmetic, a fraction of the instructions and of the dependent loads ----
+// What GetInterpolatedVoxel costs when it is written out literally (above): 9 GetVoxel calls = 27 IEEE divisions by
+// voxel_size + 3 for the weights, and 9 block look-ups, each a probe chain into the hash table -- per sphere-tracing step,
+// ~100 steps per pixel.  Here:
+//   * every division by voxel_size / fx / fy is div_exact (3 instructions, verified equal to the IEEE quotient);
+//   * the 8 dual-grid corners differ per axis in ONE of two coordinates, so 6 voxel coordinates are computed, not 24
+//     (each coordinate goes through exactly the expression the reference evaluates for it);
+//   * blocks are looked up in the dense grid (one load), once per distinct block of the 2x2x2 corner set (almost
+//     always one) and shared with the centre voxel's look-up; the 8 corner loads are then independent of each other;
+//   * colour is only interpolated for the final sample of a ray.
+template <bool FAST>
+__device__ inline float div_by(float a, float b, float y) { return FAST ? div_exact(a, b, y) : a / b; }
+
+// Block look-up of the fast ray-caster: dense grid only.  A coordinate outside the grid is absent if the table holds no
+// block at all (d.n_alloc[3] counts table inserts; the usual case), otherwise the pixel bails out to the literal pass.
+__device__ inline int find_block_xyz(const FusionDev &d, int x, int y, int z, bool far_blocks, bool &bail) {
+  I3 p; p.x = x; p.y = y; p.z = z;
+  unsigned idx;
+  if (grid_index(p, idx)) return d.grid[idx] - 1;
+  if (far_blocks) bail = true;
+  return -1;
+}
+
+template <bool FAST, bool COLOUR>
+__device__ inline Voxel interp_voxel(const FusionDev &d, F3 pos, bool far_blocks, bool &bail) {  // == get_interpolated_voxel(d, pos), tsdf_volume.cu:161-289
+  const float vs = d.o.voxel_size, hv = vs / 2.0f, y = d.vs_rcp;
+  Voxel zero; zero.sdf = 0.f; zero.c[0] = zero.c[1] = zero.c[2] = 0; zero.weight = 0;
+  // GetVoxel(position): WorldToGlobalVoxel (tsdf_volume.cu:109-113), then block = floor(g / 8), local = g mod 8
+  const float qx = div_by<FAST>(pos.x, vs, y), qy = div_by<FAST>(pos.y, vs, y), qz = div_by<FAST>(pos.z, vs, y);
+  const int g0x = f2i(qx + signf_(pos.x) * 0.5f), g0y = f2i(qy + signf_(pos.y) * 0.5f), g0z = f2i(qz + signf_(pos.z) * 0.5f);
+  const int c0x = g0x >> 3, c0y = g0y >> 3, c0z = g0z >> 3;
+  const int b0 = find_block_xyz(d, c0x, c0y, c0z, far_blocks, bail);
+  Voxel v0 = zero;
+  if (b0 >= 0) v0 = d.vox[(size_t)b0 * 512 + (((g0x & 7) << 6) | ((g0y & 7) << 3) | (g0z & 7))];
+  if (v0.weight == 0) return v0;
+  const float pdx = pos.x - hv, pdy = pos.y - hv, pdz = pos.z - hv;
+  const float wx = qx - floorf(qx), wy = qy - floorf(qy), wz = qz - floorf(qz);  // voxel_position = position / voxel_size is q
+  // per-axis corner coordinates: pos_dual + 0.0f and pos_dual + voxel_size
+  int gx[2], gy[2], gz[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float ax = pdx + (j ? vs : 0.0f), ay = pdy + (j ? vs : 0.0f), az = pdz + (j ? vs : 0.0f);
+    gx[j] = f2i(div_by<FAST>(ax, vs, y) + signf_(ax) * 0.5f);
+    gy[j] = f2i(div_by<FAST>(ay, vs, y) + signf_(ay) * 0.5f);
+    gz[j] = f2i(div_by<FAST>(az, vs, y) + signf_(az) * 0.5f);
+  }
+  const int bx0 = gx[0] >> 3, bx1 = gx[1] >> 3, by0 = gy[0] >> 3, by1 = gy[1] >> 3, bz0 = gz[0] >> 3, bz1 = gz[1] >> 3;
+  auto look = [&](int x, int yy, int z) { return (x == c0x && yy == c0y && z == c0z) ? b0 : find_block_xyz(d, x, yy, z, far_blocks, bail); };
+  int P[8];  // pool block of corner c (bit0 = x, bit1 = y, bit2 = z)
+  P[0] = look(bx0, by0, bz0);
+  P[1] = bx1 == bx0 ? P[0] : look(bx1, by0, bz0);
+  P[2] = by1 == by0 ? P[0] : look(bx0, by1, bz0);
+  P[3] = bx1 == bx0 ? P[2] : (by1 == by0 ? P[1] : look(bx1, by1, bz0));
+  P[4] = bz1 == bz0 ? P[0] : look(bx0, by0, bz1);
+  P[5] = bz1 == bz0 ? P[1] : (bx1 == bx0 ? P[4] : look(bx1, by0, bz1));
+  P[6] = bz1 == bz0 ? P[2] : (by1 == by0 ? P[4] : look(bx0, by1, bz1));
+  P[7] = bz1 == bz0 ? P[3] : (bx1 == bx0 ? P[6] : (by1 == by0 ? P[5] : look(bx1, by1, bz1)));
+  Voxel cv[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int local = ((gx[c & 1] & 7) << 6) | ((gy[(c >> 1) & 1] & 7) << 3) | (gz[(c >> 2) & 1] & 7);
+    cv[c] = zero;
+    if (P[c] >= 0) cv[c] = d.vox[(size_t)P[c] * 512 + local];
+  }
+  float dist = 0.0f, cx = 0.0f, cy = 0.0f, cz = 0.0f;
+  const int order[8] = {0, 1, 2, 4, 3, 6, 5, 7};  // the reference's corner order: 000 100 010 001 110 011 101 111
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = order[k];
+    const float a = (c & 1) ? wx : (1.0f - wx), b = (c & 2) ? wy : (1.0f - wy), cc = (c & 4) ? wz : (1.0f - wz);
+    const float wt = a * b * cc;
+    const Voxel &src = cv[c].weight == 0 ? v0 : cv[c];
+    dist += wt * src.sdf;
+    if (COLOUR) {
+      cx = cx + (float)src.c[0] * wt;
+      cy = cy + (float)src.c[1] * wt;
+      cz = cz + (float)src.c[2] * wt;
+    }
+  }
+  Voxel v;
+  v.c[0] = f2u8(cx); v.c[1] = f2u8(cy); v.c[2] = f2u8(cz);
+  v.weight = v0.weight;
+  v.sdf = dist;
+  return v;
+}
+// Pixels are flagged for the literal pass (k_raycast_fix) with depth -1 when a sample leaves the range div_exact was
+// verified on, or needs a block outside the dense grid while the table is not empty.  Neither happens in a room-sized map.
+template <bool FAST>
+__global__ __launch_bounds__(64) void k_raycast2(const FusionDev d, const Mat pose, unsigned char *__restrict__ bgr,
+                                                 float *__restrict__ depth_out, int *__restrict__ n_flagged) {
+  const drf_options_t &o = d.o;
+  const int size = o.height * o.width;
+  const bool far_blocks = d.n_alloc[3] != 0;
+  // one wave = one 8x8 pixel tile, tiles dealt to the 8 XCDs in bands of rows (see k_raycast)
+  const bool tiled = (o.width % 8 == 0) && (o.height % 8 == 0) && blockDim.x == 64;
+  const int ntile = tiled ? size / 64 : 0, per_xcd = (ntile + 7) >> 3;
+  for (int w0 = blockIdx.x; w0 < (tiled ? 8 * per_xcd : (size + 63) / 64); w0 += gridDim.x) {
+    int i;
+    if (tiled) {
+      const int t = (w0 & 7) * per_xcd + (w0 >> 3);
+      if (t >= ntile) continue;
+      const int tw = o.width / 8, tx = t % tw, ty = t / tw;
+      i = (ty * 8 + (threadIdx.x >> 3)) * o.width + tx * 8 + (threadIdx.x & 7);
+    } else {
+      i = w0 * 64 + threadIdx.x;
+      if (i >= size) continue;
+    }
+    // GetPoint3d(i, cur, sensor) (utils.h:93-101): x = (u - cx) * z / fx, the pixel part is constant along the ray
+    const int pv = i / o.width, pu = i - o.width * pv;
+    const float ucx = (float)pu - o.cx, vcy = (float)pv - o.cy;
+    bool bail = false;
+    auto sample_pos = [&](float cur) {
+      F3 p;
+      p.z = cur;
+      const float tx = ucx * cur, ty = vcy * cur;
+      p.x = div_by<FAST>(tx, o.fx, d.fx_rcp);
+      p.y = div_by<FAST>(ty, o.fy, d.fy_rcp);
+      const F3 q = xform(pose, p);
+      if (FAST && !(in_fast_range(q.x) && in_fast_range(q.y) && in_fast_range(q.z) && in_fast_range(tx) && in_fast_range(ty))) bail = true;
+      return q;
+    };
+    float cur = 0.f;
+    while (cur < o.max_sensor_depth) {
+      const Voxel v = interp_voxel<FAST, false>(d, sample_pos(cur), far_blocks, bail);
+      if (bail) break;
+      if (v.weight == 0) cur += o.truncation_distance; else cur += v.sdf;
+      if (v.weight != 0 && v.sdf < o.voxel_size) break;
+    }
+    if (!bail && cur < o.max_sensor_depth) {
+      const Voxel v = interp_voxel<FAST, true>(d, sample_pos(cur), far_blocks, bail);
+      bgr[3 * i] = v.c[0]; bgr[3 * i + 1] = v.c[1]; bgr[3 * i + 2] = v.c[2];
+      depth_out[i] = cur;
+    } else {
+      bgr[3 * i] = bgr[3 * i + 1] = bgr[3 * i + 2] = 0;
+      depth_out[i] = 0.0f;
+    }
+    if (bail) { depth_out[i] = -1.0f; atomicAdd(n_flagged, 1); }
+  }
+}
+// The literal ray-caster for the pixels k_raycast2 flagged; exits at once when there are none.
+__global__ __launch_bounds__(64) void k_raycast_fix(const FusionDev d, const Mat pose, unsigned char *__restrict__ bgr,
+                                                    float *__restrict__ depth_out, int *__restrict__ n_flagged) {
+  if (*n_flagged == 0) return;
+  const drf_options_t &o = d.o;
+  const int size = o.height * o.width;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < size; i += gridDim.x * blockDim.x) {
+    if (!(depth_out[i] == -1.0f)) continue;
+    float cur = 0.f;
+    while (cur < o.max_sensor_depth) {
+      const Voxel v = get_interpolated_voxel(d, xform(pose, point3d(o, i, cur)));
+      if (v.weight == 0) cur += o.truncation_distance; else cur += v.sdf;
+      if (v.weight != 0 && v.sdf < o.voxel_size) break;
+    }
+    if (cur < o.max_sensor_depth) {
+      const Voxel v = get_interpolated_voxel(d, xform(pose, point3d(o, i, cur)));
+      bgr[3 * i] = v.c[0]; bgr[3 * i + 1] = v.c[1]; bgr[3 * i + 2] = v.c[2];
+      depth_out[i] = cur;
+    } else {
+      bgr[3 * i] = bgr[3 * i + 1] = bgr[3 * i + 2] = 0;
+      depth_out[i] = 0.0f;
+    }
+  }
+}
+__global__ void k_zero_int(int *p) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = 0; }
+
+__global__ __launch_bounds__(256) void k_fold_counter(unsigned long long *cnt, int *req_count, const unsigned *wg_upd, int n_wg) {
+  // end of scan: this scan's update count -> last / total, request and visible lists emptied
+  __shared__ unsigned long long part[256];
+  unsigned long long a = 0;
+  for (int i = threadIdx.x; i < n_wg; i += 256) a += wg_upd[i];
+  part[threadIdx.x] = a;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) { if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off]; __syncthreads(); }
+  if (threadIdx.x == 0) { const unsigned long long u = part[0] + cnt[0]; cnt[1] += u; cnt[3] = u; cnt[0] = 0; req_count[0] = 0; req_count[1] = 0; }
 }
 __global__ void k_fill_keys(unsigned long long *keys, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) keys[i] = kEmptyKey;
@@ -526,6 +856,7 @@ class FusionEngine {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= device) fail(DR_ERR_DEVICE, "DrFusion: no HIP device %d (found %d) -- the MI355X path has no CPU fallback", device, n);
     if (o.block_size != 8) fail(DR_ERR_UNSUPPORTED, "DrFusion: block_size must be 8 (got %d)", o.block_size);
+    if (o.num_blocks >= (1 << 30) - 1) fail(DR_ERR_UNSUPPORTED, "DrFusion: num_blocks must be below 2^30 - 1 (got %d)", o.num_blocks);
     if (o.height <= 0 || o.width <= 0 || o.num_blocks <= 0 || o.num_buckets <= 0 || o.bucket_size <= 0 || o.num_render_streams < 0)
       fail(DR_ERR_ARG, "DrFusion: invalid options");
     DR_HIP(hipSetDevice(device_));
@@ -548,6 +879,15 @@ class FusionEngine {
     d_.sd = dalloc<float>(npix_);
     d_.present = dalloc<unsigned>((size_t)1 << (3 * kPresentBits - 5));
     DR_HIP(hipMemsetAsync(d_.present, 0, (size_t)1 << (3 * kPresentBits - 3), int_stream_));
+    d_.grid = dalloc<int>((size_t)1 << (3 * kGridBits));
+    DR_HIP(hipMemsetAsync(d_.grid, 0, sizeof(int) << (3 * kGridBits), int_stream_));
+    d_.req = dalloc<unsigned>(o.num_blocks);
+    d_.req_count = dalloc<int>(4);
+    d_.vis_count = d_.req_count + 1;
+    d_.vis = dalloc<int>(o.num_blocks);
+    d_.wg_upd = dalloc<unsigned>(65536);
+    DR_HIP(hipMemsetAsync(d_.req_count, 0, 16, int_stream_));
+    setup_fast_div();
     hipLaunchKernelGGL(k_fill_keys, dim3(1024), dim3(256), 0, int_stream_, d_.keys, cap);
     DR_HIP(hipMemsetAsync(d_.vox, 0, (size_t)o.num_blocks * 512 * sizeof(Voxel), int_stream_));  // hash_table.cu:28-32
     DR_HIP(hipMemsetAsync(d_.n_alloc, 0, 16, int_stream_));
@@ -560,13 +900,14 @@ class FusionEngine {
     // at any moment are neighbours in the pool (sweep on the bench map: 1024 / 3072 / 4096 / 6144 / 8192 / 16384
     // workgroups -> 0.341 / 0.327 / 0.329 / 0.363 / 0.443 / 0.697 ms per scan)
     integrate_grid_ = std::min(cdiv(o.num_blocks, 4), 3072);
-    if (const char *e = getenv("DR_INT_GRID")) integrate_grid_ = std::max(1, atoi(e));  // tuning hook
+    if (const char *e = getenv("DR_INT_GRID")) integrate_grid_ = std::min(65536, std::max(1, atoi(e)));  // tuning hook
     DR_HIP(hipEventCreateWithFlags(&int_done_, hipEventDisableTiming));
     for (int i = 0; i < o.num_render_streams; ++i) {
       Render r;
       DR_HIP(hipStreamCreateWithPriority(&r.stream, hipStreamNonBlocking, lo));
       r.d_bgr = dalloc<unsigned char>(npix_ * 3);
       r.d_depth = dalloc<float>(npix_);
+      r.d_flag = dalloc<int>(4);
       for (int k = 0; k < 2; ++k) {  // double-buffered host results ("blocked"/"free", tsdf_volume.cu:846-872)
         DR_HIP(hipHostMalloc((void **)&r.h_bgr[k], npix_ * 3, hipHostMallocDefault));
         DR_HIP(hipHostMalloc((void **)&r.h_depth[k], npix_ * 4, hipHostMallocDefault));
@@ -580,10 +921,10 @@ class FusionEngine {
     (void)hipSetDevice(device_);
     (void)hipDeviceSynchronize();
     (void)hipFree(d_.keys); (void)hipFree(d_.vals); (void)hipFree(d_.blk_key); (void)hipFree(d_.vox);
-    (void)hipFree(d_.n_alloc); (void)hipFree(d_.cnt); (void)hipFree(d_.sd); (void)hipFree(d_.present); (void)hipFree(d_bgr_in_); (void)hipFree(d_depth_in_);
+    (void)hipFree(d_.n_alloc); (void)hipFree(d_.cnt); (void)hipFree(d_.sd); (void)hipFree(d_.present); (void)hipFree(d_.grid); (void)hipFree(d_.req); (void)hipFree(d_.req_count); (void)hipFree(d_.vis); (void)hipFree(d_.wg_upd); (void)hipFree(d_bgr_in_); (void)hipFree(d_depth_in_);
     (void)hipHostFree(h_bgr_in_); (void)hipHostFree(h_depth_in_);
     for (auto &r : renders_) {
-      (void)hipFree(r.d_bgr); (void)hipFree(r.d_depth);
+      (void)hipFree(r.d_bgr); (void)hipFree(r.d_depth); (void)hipFree(r.d_flag);
       for (int k = 0; k < 2; ++k) { (void)hipHostFree(r.h_bgr[k]); (void)hipHostFree(r.h_depth[k]); }
       (void)hipEventDestroy(r.done); (void)hipStreamDestroy(r.stream);
     }
@@ -609,6 +950,14 @@ class FusionEngine {
     enqueue_scan(d_bgr_in_, d_depth_in_, pose16);
     DR_HIP(hipEventRecord(int_done_, int_stream_));
   }
+  void launch_raycast(hipStream_t st, unsigned char *d_bgr, float *d_depth, int *d_flag, const Mat &P) {
+    const dim3 grid(8 * cdiv(cdiv((int)npix_, 64), 8)), block(64);
+    if (raycast_v1_) { hipLaunchKernelGGL(k_raycast, grid, block, 0, st, d_, P, d_bgr, d_depth); return; }
+    hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(1), 0, st, d_flag);
+    if (d_.fast_div) hipLaunchKernelGGL(k_raycast2<true>, grid, block, 0, st, d_, P, d_bgr, d_depth, d_flag);
+    else hipLaunchKernelGGL(k_raycast2<false>, grid, block, 0, st, d_, P, d_bgr, d_depth, d_flag);
+    hipLaunchKernelGGL(k_raycast_fix, dim3(512), dim3(64), 0, st, d_, P, d_bgr, d_depth, d_flag);
+  }
   // tsdf_volume.cu:634-700
   void render_async(const float *const *poses, int n) {
     expect(kRender, "Please call the functions like IntegrateScanAsync -> RenderAsync -> GetRenderResult.");
@@ -620,7 +969,7 @@ class FusionEngine {
       Render &r = renders_[i];
       Mat P; memcpy(P.m, poses[i], 64);
       DR_HIP(hipStreamWaitEvent(r.stream, int_done_, 0));
-      hipLaunchKernelGGL(k_raycast, dim3(8 * cdiv(cdiv((int)npix_, 64), 8)), dim3(64), 0, r.stream, d_, P, r.d_bgr, r.d_depth);
+      launch_raycast(r.stream, r.d_bgr, r.d_depth, r.d_flag, P);
       DR_HIP(hipMemcpyAsync(r.h_bgr[free_slot_], r.d_bgr, npix_ * 3, hipMemcpyDeviceToHost, r.stream));
       DR_HIP(hipMemcpyAsync(r.h_depth[free_slot_], r.d_depth, npix_ * 4, hipMemcpyDeviceToHost, r.stream));
       DR_HIP(hipEventRecord(r.done, r.stream));
@@ -678,6 +1027,7 @@ class FusionEngine {
     DR_HIP(hipMemcpy(voxels, d_.vox, (size_t)na * 4096, hipMemcpyDeviceToHost));
     if (n) *n = na;
   }
+  void fast_div_status(int *enabled, unsigned long long *mismatches) const { if (enabled) *enabled = d_.fast_div; if (mismatches) *mismatches = fast_div_mismatches_; }
   void test_combine(size_t n, const uint8_t *a, const uint8_t *b, int max_weight, uint8_t *out) {
     DR_HIP(hipSetDevice(device_));
     Voxel *da = nullptr, *db = nullptr, *dout = nullptr;
@@ -786,7 +1136,7 @@ class FusionEngine {
         Mat P; memcpy(P.m, poses + 16 * s, 64);
         DR_HIP(hipStreamWaitEvent(r.stream, int_done_, 0));
         DR_HIP(hipEventRecord(e[3 + 3 * i], r.stream));
-        hipLaunchKernelGGL(k_raycast, dim3(8 * cdiv(cdiv((int)npix_, 64), 8)), dim3(64), 0, r.stream, d_, P, r.d_bgr, r.d_depth);
+        launch_raycast(r.stream, r.d_bgr, r.d_depth, r.d_flag, P);
         DR_HIP(hipEventRecord(e[4 + 3 * i], r.stream));
         DR_HIP(hipMemcpyAsync(r.h_bgr[free_slot_], r.d_bgr, npix_ * 3, hipMemcpyDeviceToHost, r.stream));
         DR_HIP(hipMemcpyAsync(r.h_depth[free_slot_], r.d_depth, npix_ * 4, hipMemcpyDeviceToHost, r.stream));
@@ -826,10 +1176,12 @@ class FusionEngine {
     memcpy(T.m, pose16, 64);
     inverse4_host(T.m, Ti.m);
     hipLaunchKernelGGL(k_allocate, dim3(cdiv((int)npix_, 256)), dim3(256), 0, int_stream_, d_, d_depth, T);
+    hipLaunchKernelGGL(k_alloc_commit, dim3(64), dim3(256), 0, int_stream_, d_);
     if (kernel_events_[0]) DR_HIP(hipEventRecord(kernel_events_[0], int_stream_));
+    hipLaunchKernelGGL(k_cull, dim3(512), dim3(256), 0, int_stream_, d_, Ti);
     hipLaunchKernelGGL(k_integrate, dim3(integrate_grid_), dim3(256), 0, int_stream_, d_, d_bgr, d_depth, T, Ti);
     if (kernel_events_[1]) DR_HIP(hipEventRecord(kernel_events_[1], int_stream_));
-    hipLaunchKernelGGL(k_fold_counter, dim3(1), dim3(1), 0, int_stream_, d_.cnt);
+    hipLaunchKernelGGL(k_fold_counter, dim3(1), dim3(256), 0, int_stream_, d_.cnt, d_.req_count, d_.wg_upd, integrate_grid_);
     DR_HIP(hipGetLastError());
   }
   static int f2i_host(float f) {  // make_int3(float...) on CUDA: cvt.rzi (saturating, NaN -> 0)
@@ -908,6 +1260,25 @@ class FusionEngine {
     if (t > kMeshMaxTriangles) fail(DR_ERR_CAPACITY, "Triangles limit reached! (%llu > %u)", t, kMeshMaxTriangles);
     return (size_t)t;
   }
+  // Correctly rounded reciprocals of the three per-engine divisors, each checked against IEEE division over all 2^32
+  // dividends (see div_exact); DR_FUSION_IEEE_DIV=1 forces the IEEE sequences (A/B and fallback testing).
+  static float rcp_rn(float b) { return (float)(1.0 / (double)b); }  // double rounding cannot bite: 1/b is never within 2^-49 of a float midpoint
+  void setup_fast_div() {
+    d_.vs_rcp = rcp_rn(o_.voxel_size); d_.fx_rcp = rcp_rn(o_.fx); d_.fy_rcp = rcp_rn(o_.fy);
+    d_.fast_div = 0;
+    if (getenv("DR_FUSION_IEEE_DIV")) return;
+    unsigned long long *bad = dalloc<unsigned long long>(1), h = 0;
+    DR_HIP(hipMemsetAsync(bad, 0, 8, int_stream_));
+    const float b[3] = {o_.voxel_size, o_.fx, o_.fy}, y[3] = {d_.vs_rcp, d_.fx_rcp, d_.fy_rcp};
+    for (int k = 0; k < 3; ++k)
+      if (b[k] > 0.0f && b[k] < 1e30f) hipLaunchKernelGGL(k_verify_fast_div, dim3(4096), dim3(256), 0, int_stream_, b[k], y[k], bad);
+      else h = 1;
+    DR_HIP(hipMemcpyAsync(&fast_div_mismatches_, bad, 8, hipMemcpyDeviceToHost, int_stream_));
+    DR_HIP(hipStreamSynchronize(int_stream_));
+    DR_HIP(hipFree(bad));
+    fast_div_mismatches_ += h;
+    d_.fast_div = fast_div_mismatches_ == 0 ? 1 : 0;
+  }
   void check_device_flags() {
     int f[4];
     DR_HIP(hipMemcpy(f, d_.n_alloc, 16, hipMemcpyDeviceToHost));
@@ -918,6 +1289,7 @@ class FusionEngine {
     hipStream_t stream;
     unsigned char *d_bgr, *h_bgr[2];
     float *d_depth, *h_depth[2];
+    int *d_flag;  // pixels the fast ray-caster handed to the literal pass
     hipEvent_t done;
   };
   int device_;
@@ -930,6 +1302,8 @@ class FusionEngine {
   unsigned char *d_bgr_in_ = nullptr, *h_bgr_in_ = nullptr;
   float *d_depth_in_ = nullptr, *h_depth_in_ = nullptr;
   int integrate_grid_ = 4096;
+  unsigned long long fast_div_mismatches_ = 0;
+  bool raycast_v1_ = getenv("DR_RAYCAST_V1") != nullptr;  // A/B hook: the literal first-generation ray-caster
   std::vector<Render> renders_;
   int free_slot_ = 0;
   Next next_ = kIntegrate;
@@ -988,6 +1362,9 @@ int drf_synchronize(drf_t *h) { return guarded([&] { h->e->synchronize(); }); }
 int drf_stats(drf_t *h, uint64_t out[4]) { return guarded([&] { h->e->stats(out); }); }
 int drf_export_blocks(drf_t *h, int max_blocks, int32_t *coords, uint8_t *voxels, int *n) {
   return guarded([&] { h->e->export_blocks(max_blocks, coords, voxels, n); });
+}
+int drf_fast_div_status(drf_t *h, int *enabled, uint64_t *mismatches) {
+  return guarded([&] { unsigned long long m = 0; h->e->fast_div_status(enabled, &m); if (mismatches) *mismatches = m; });
 }
 int drf_test_combine(drf_t *h, size_t n, const uint8_t *a, const uint8_t *b, int max_weight, uint8_t *out) {
   return guarded([&] { if (!a || !b || !out) dr::fail(DR_ERR_ARG, "drf_test_combine: null argument"); h->e->test_combine(n, a, b, max_weight, out); });

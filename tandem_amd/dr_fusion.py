@@ -113,6 +113,12 @@ class DrFusion:
                                            vox.ctypes.data_as(u8p), C.byref(got)))
         return {tuple(int(v) for v in coords[i]): vox[i] for i in range(got.value)}
 
+    def fast_div_status(self):
+        """(enabled, mismatches) of the exact fast division self-check run at construction."""
+        en, mm = C.c_int(), C.c_uint64()
+        check(_lib.lib().drf_fast_div_status(self._h, C.byref(en), C.byref(mm)))
+        return bool(en.value), int(mm.value)
+
     def test_combine(self, a, b, max_weight):
         """Test hook: Combine(a[i], b[i]) by the integration kernel's device function; a, b: (n, 8) uint8 voxels."""
         a, b = np.ascontiguousarray(a, np.uint8), np.ascontiguousarray(b, np.uint8)

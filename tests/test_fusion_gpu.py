@@ -269,3 +269,77 @@ def test_full_size_bit_exact_against_the_oracle():
     assert_same_volume(f, o)
     assert f.stats()["blocks"] > 80_000
     f.close()
+
+
+@pytest.mark.parametrize("vs,f", [(0.005, 500.0), (0.01, 481.2), (0.02, 500.0), (0.04, 250.0), (0.0123, 617.3)])
+def test_exact_fast_division_is_verified_at_construction(vs, f):
+    """div_exact (reciprocal + FMA correction, 3 instructions) replaces the IEEE division by voxel_size / fx / fy in the
+    ray-caster: the engine checks it against a / b for ALL 2^32 dividends per divisor when it is created."""
+    from oracle import scene
+    from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
+    sc = scene.make_scans(1, 8, 8)
+    fu = DrFusion(DrFusionOptions(**options(sc, 8, 8, vs, num_blocks=64, num_buckets=64, fx=f, fy=f * 0.997)))
+    assert fu.fast_div_status() == (True, 0)
+    fu.close()
+
+
+def test_raycast_generations_agree_and_ieee_fallback(monkeypatch):
+    """k_raycast2 (dense-grid look-ups, exact fast division, shared corner coordinates) against the literal k_raycast and
+    against k_raycast2 with IEEE division, on the same volume: bit-identical depth and colour."""
+    from oracle import scene
+    from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
+    H, W = 120, 160
+    sc = scene.make_scans(3, H, W, seed=4)
+    outs = []
+    for env in ({}, {"DR_RAYCAST_V1": "1"}, {"DR_FUSION_IEEE_DIV": "1"}):
+        for k in ("DR_RAYCAST_V1", "DR_FUSION_IEEE_DIV"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        fu = DrFusion(DrFusionOptions(**options(sc, H, W, 0.01, num_render_streams=2)))
+        assert fu.fast_div_status()[0] == ("DR_FUSION_IEEE_DIV" not in env)
+        res = []
+        for i, (bgr, depth, pose) in enumerate(sc["scans"]):
+            fu.IntegrateScanAsync(bgr, depth, pose)
+            far = pose.copy(); far[:3, 3] += (0.3, -0.2, -0.4)       # a view from somewhere else: rays through unobserved space
+            fu.RenderAsync([sc["scans"][(i + 1) % 3][2], far])
+            rb, rd = fu.GetRenderResult()
+            res.append((rb[0].copy(), rd[0].copy(), rb[1].copy(), rd[1].copy()))
+        outs.append(res)
+        fu.close()
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            for x, y in zip(a, b):
+                assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
+    assert (outs[0][-1][1] > 0).mean() > 0.5
+
+
+def test_blocks_outside_the_dense_grid():
+    """The dense block grid covers block coordinates [-256, 256)^3; beyond it the open-addressing table takes over.  A scene
+    pushed 40.9 m along +x at 2 cm voxels (block edge 16 cm) straddles the border: allocation, integration, the
+    ray-caster's hand-over to the literal pass and the mesh all have to agree with the oracle bit for bit."""
+    from oracle import scene
+    from oracle.tsdf_oracle import TsdfOracle
+    from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
+    H, W, vs = 96, 128, 0.02
+    sc = scene.make_scans(3, H, W, seed=6)
+    opt = options(sc, H, W, vs)
+    f, o = DrFusion(DrFusionOptions(**opt)), TsdfOracle(**opt)
+    S = np.eye(4, dtype=np.float32)
+    c, s = np.cos(1.45), np.sin(1.45)
+    S[:3, :3] = [[c, 0, s], [0, 1, 0], [-s, 0, c]]      # look along +x
+    S[:3, 3] = (40.2, 0.3, -0.2)
+    for i, (bgr, depth, pose) in enumerate(sc["scans"]):
+        pose = (S @ pose).astype(np.float32)
+        f.IntegrateScanAsync(bgr, depth, pose)
+        f.RenderAsync([pose])
+        rb, rd = f.GetRenderResult()
+        assert o.integrate(bgr, depth, pose) == 0
+        ob, od = o.render(pose)
+        assert np.array_equal(rd[0].view(np.uint32), od.view(np.uint32)), f"scan {i}: {(rd[0] != od).sum()} px differ"
+        assert np.array_equal(rb[0], ob)
+    xs = [k[0] for k in f.export_blocks()]
+    assert min(xs) < 256 <= max(xs), (min(xs), max(xs))
+    assert_same_volume(f, o)
+    assert (od > 0).mean() > 0.3
+    f.close()
