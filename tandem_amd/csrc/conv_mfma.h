@@ -23,6 +23,7 @@
 //   X8   : the Cout=1 `prob` layer is run as 8 x-shifts per column on the output viewed as (D,H,W/8,8).
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <functional>
 
 #include "dr_common.h"
@@ -60,6 +61,117 @@ struct ConvArgs {
 
 constexpr int kConvThreads = 256;
 constexpr size_t kConvMaxLds = 160 * 1024;  // gfx950: 160 KiB LDS per CU, one workgroup may take all of it
+
+// ---- epilogue: folded BN, ReLU, residual / upsample add, one float4 (4 channels) per lane ----
+template <int CT, int PT>
+__device__ inline void conv_epilogue(const ConvArgs &a, const ConvClass &cls, floatx4 (&acc)[CT][PT], int wave, int j, int g, int ct0,
+                                     int pz0, int py0, int px0) {
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const int tau = wave * PT + pt;
+    const int xt = tau % a.TXT, yt = (tau / a.TXT) % a.TY, zt = tau / (a.TXT * a.TY);
+    const int qz = pz0 + zt, qy = py0 + yt, qx = px0 + xt * 16 + j;
+    if (qz >= a.nPD || qy >= a.nPH || qx >= a.nPW) continue;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int c0 = (ct0 + ct) * 16 + 4 * g;
+      if (c0 >= a.rows_valid) continue;
+      int oz = qz * a.omz + cls.ooz, oy = qy * a.omy + cls.ooy, ox = qx * a.omx + cls.oox, ch = c0;
+      if (a.par_rows) {  // transposed layer: this lane's 4 rows are 4 channels of output parity q
+        const int q = c0 / a.par_rows, bits = (a.par_map >> (3 * q)) & 7;
+        ch = c0 - q * a.par_rows;
+        oz += (bits >> 2) & 1; oy += (bits >> 1) & 1; ox += bits & 1;
+      }
+      const size_t obase = (((size_t)oz * a.outH + oy) * a.outW + ox) * a.outC + ch;
+      size_t abase = obase;
+      if (a.add_mode == 2) abase = (((size_t)oz * a.addH + (oy >> 1)) * a.addW + (ox >> 1)) * a.outC + ch;
+      const float4 sc = *reinterpret_cast<const float4 *>(a.scale + c0);
+      const float4 bi = *reinterpret_cast<const float4 *>(a.bias + c0);
+      float4 v;
+      v.x = acc[ct][pt][0] * sc.x + bi.x;
+      v.y = acc[ct][pt][1] * sc.y + bi.y;
+      v.z = acc[ct][pt][2] * sc.z + bi.z;
+      v.w = acc[ct][pt][3] * sc.w + bi.w;
+      if (a.relu) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      if (a.add_mode) {
+        const float4 r = *reinterpret_cast<const float4 *>(a.add + abase);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      *reinterpret_cast<float4 *>(a.out + obase) = v;
+    }
+  }
+}
+
+// ---- K loop over the chunks of one channel pass, operands of chunk u+1 fetched under the MFMAs of u ----
+// Two operand register sets used alternately (the loop is unrolled by two): renaming the prefetched set into the current
+// one at the end of every iteration costs 8 v_mov_b64 whose results the next MFMAs have to wait for -- 118 vs 104 TFLOP/s
+// (one wave per SIMD) and 138 vs 120-127 (two) in tools/ubench/mfma_lds2.hip, which isolates exactly this loop.
+template <int CT, int PT>
+__device__ inline void conv_chunk_mfma(const float4 (&av)[CT], const float4 (&bv)[PT], floatx4 (&acc)[CT][PT]) {
+  // consecutive MFMAs go to different accumulators (16x16x4: 32-cycle issue, 40-cycle dependent latency)
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct].x, bv[pt].x, acc[ct][pt], 0, 0, 0);
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct].y, bv[pt].y, acc[ct][pt], 0, 0, 0);
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct].z, bv[pt].z, acc[ct][pt], 0, 0, 0);
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct].w, bv[pt].w, acc[ct][pt], 0, 0, 0);
+}
+template <int CT, int PT>
+__device__ inline void conv_chunk_load(const float *lds, const float4 *wp, int toff, int u, const int (&base)[PT], float4 (&av)[CT],
+                                       float4 (&bv)[PT]) {
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) av[ct] = wp[(u * CT + ct) * 64];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) bv[pt] = *reinterpret_cast<const float4 *>(lds + base[pt] + toff);
+}
+// Anchor prefetched operands at the END of the MFMA block before them: without a use there hipcc sinks the loads in
+// front of their own MFMAs and every chunk eats a full LDS round trip.
+template <int CT, int PT>
+__device__ inline void conv_chunk_anchor(const float4 (&av)[CT], const float4 (&bv)[PT], int toff) {
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) asm volatile("" ::"v"(av[ct].x), "v"(av[ct].y), "v"(av[ct].z), "v"(av[ct].w));
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) asm volatile("" ::"v"(bv[pt].x), "v"(bv[pt].y), "v"(bv[pt].z), "v"(bv[pt].w));
+  asm volatile("" ::"v"(toff));
+}
+template <int CT, int PT>
+__device__ inline void conv_kloop(const float *lds, const float4 *wl, const int *tp, int TPC, int NU, int lane, const int (&base)[PT],
+                                  floatx4 (&acc)[CT][PT]) {
+  const float4 *wp = wl + lane;
+  float4 a0[CT], b0[PT], a1[CT], b1[PT];
+  // the tap offset of a chunk is itself an LDS read: it is fetched one chunk before the operands that need it
+  int tA = tp[0], tB = tp[min(1, NU - 1) * TPC];
+  conv_chunk_load<CT, PT>(lds, wp, tA, 0, base, a0, b0);
+  int u = 0;
+  for (; u + 1 < NU; u += 2) {
+    // sched_barrier: the operand reads of the NEXT chunk are issued before the MFMAs of this one and waited for after them
+    conv_chunk_load<CT, PT>(lds, wp, tB, u + 1, base, a1, b1);
+    tA = tp[min(u + 2, NU - 1) * TPC];
+    __builtin_amdgcn_sched_barrier(0);
+    conv_chunk_mfma<CT, PT>(a0, b0, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    conv_chunk_anchor<CT, PT>(a1, b1, tA);
+    conv_chunk_load<CT, PT>(lds, wp, tA, min(u + 2, NU - 1), base, a0, b0);
+    tB = tp[min(u + 3, NU - 1) * TPC];
+    __builtin_amdgcn_sched_barrier(0);
+    conv_chunk_mfma<CT, PT>(a1, b1, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    conv_chunk_anchor<CT, PT>(a0, b0, tB);
+  }
+  if (u < NU) conv_chunk_mfma<CT, PT>(a0, b0, acc);  // odd chunk count: set 0 holds the last chunk
+}
 
 // grid = (tiles, parity classes, output-row groups).  PT = position tiles (16 positions each) per wave.
 template <int CI, int CT, int PT>
@@ -116,6 +228,9 @@ __global__ __launch_bounds__(kConvThreads) void k_conv(const ConvArgs a) {
     // ---- stage CI channels of the input halo tile into LDS (zero outside the tensor).  Loads are issued in
     // batches of kStageBatch per lane BEFORE the first LDS write so their HBM/L2 latencies overlap. ----
     constexpr int kStageBatch = CT >= 4 ? 6 : 12;  // normally the whole stage: one exposed HBM/L2 latency per pass
+#ifdef DR_ABL_NO_STAGE
+    if (a.npass < 0)  // ablation build: no staging at all (results are garbage)
+#endif
     for (unsigned e0 = 0; e0 < total; e0 += kConvThreads * kStageBatch) {
       float4 v[kStageBatch];
       int dst[kStageBatch];
@@ -139,6 +254,9 @@ __global__ __launch_bounds__(kConvThreads) void k_conv(const ConvArgs a) {
     {  // this pass's packed weights -> LDS, so that the K loop below touches no global memory
       const float4 *wsrc = a.wpk + cls.w_base + ((size_t)p * NU * a.ctTot + ct0) * 64;
       constexpr int kWB = 8;
+#ifdef DR_ABL_NO_STAGE
+      if (a.npass < 0)
+#endif
       for (unsigned e0 = 0; e0 < n_w; e0 += kConvThreads * kWB) {
         float4 v[kWB];
 #pragma unroll
@@ -157,94 +275,13 @@ __global__ __launch_bounds__(kConvThreads) void k_conv(const ConvArgs a) {
     }
     __builtin_amdgcn_s_setprio(0);
     __syncthreads();
-    // ---- K loop over the chunks of this channel pass, operands of chunk u+1 fetched under the MFMAs of u ----
-    const float4 *wp = wl + lane;
-    float4 av[CT], bv[PT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) av[ct] = wp[ct * 64];
-    {
-      const int toff = tp[0];
-#pragma unroll
-      for (int pt = 0; pt < PT; ++pt) bv[pt] = *reinterpret_cast<const float4 *>(lds + base[pt] + toff);
-    }
-    for (int u = 0; u < NU; ++u) {
-      const int un = min(u + 1, NU - 1);
-      float4 an[CT], bn[PT];
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) an[ct] = wp[(un * CT + ct) * 64];
-      const int toff = tp[un * TPC];
-#pragma unroll
-      for (int pt = 0; pt < PT; ++pt) bn[pt] = *reinterpret_cast<const float4 *>(lds + base[pt] + toff);
-      // consecutive MFMAs go to different accumulators (16x16x4: 32-cycle issue, 40-cycle dependent latency)
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct].x, bv[pt].x, acc[ct][pt], 0, 0, 0);
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct].y, bv[pt].y, acc[ct][pt], 0, 0, 0);
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct].z, bv[pt].z, acc[ct][pt], 0, 0, 0);
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct].w, bv[pt].w, acc[ct][pt], 0, 0, 0);
-      // Anchor the prefetched operands at the END of this iteration: without a use here hipcc sinks the loads
-      // into the next iteration, right in front of their MFMAs, and every chunk eats a full L2 round trip.
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        asm volatile("" ::"v"(an[ct].x), "v"(an[ct].y), "v"(an[ct].z), "v"(an[ct].w));
-        av[ct] = an[ct];
-      }
-#pragma unroll
-      for (int pt = 0; pt < PT; ++pt) {
-        asm volatile("" ::"v"(bn[pt].x), "v"(bn[pt].y), "v"(bn[pt].z), "v"(bn[pt].w));
-        bv[pt] = bn[pt];
-      }
-    }
+#ifndef DR_ABL_NO_KLOOP
+    conv_kloop<CT, PT>(lds, wl, tp, TPC, NU, lane, base, acc);
+#endif
     __syncthreads();
   }
 
-  // ---- epilogue: folded BN, ReLU, residual / upsample add, one float4 (4 channels) per lane ----
-#pragma unroll
-  for (int pt = 0; pt < PT; ++pt) {
-    const int tau = wave * PT + pt;
-    const int xt = tau % a.TXT, yt = (tau / a.TXT) % a.TY, zt = tau / (a.TXT * a.TY);
-    const int qz = pz0 + zt, qy = py0 + yt, qx = px0 + xt * 16 + j;
-    if (qz >= a.nPD || qy >= a.nPH || qx >= a.nPW) continue;
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      const int c0 = (ct0 + ct) * 16 + 4 * g;
-      if (c0 >= a.rows_valid) continue;
-      int oz = qz * a.omz + cls.ooz, oy = qy * a.omy + cls.ooy, ox = qx * a.omx + cls.oox, ch = c0;
-      if (a.par_rows) {  // transposed layer: this lane's 4 rows are 4 channels of output parity q
-        const int q = c0 / a.par_rows, bits = (a.par_map >> (3 * q)) & 7;
-        ch = c0 - q * a.par_rows;
-        oz += (bits >> 2) & 1; oy += (bits >> 1) & 1; ox += bits & 1;
-      }
-      const size_t obase = (((size_t)oz * a.outH + oy) * a.outW + ox) * a.outC + ch;
-      size_t abase = obase;
-      if (a.add_mode == 2) abase = (((size_t)oz * a.addH + (oy >> 1)) * a.addW + (ox >> 1)) * a.outC + ch;
-      const float4 sc = *reinterpret_cast<const float4 *>(a.scale + c0);
-      const float4 bi = *reinterpret_cast<const float4 *>(a.bias + c0);
-      float4 v;
-      v.x = acc[ct][pt][0] * sc.x + bi.x;
-      v.y = acc[ct][pt][1] * sc.y + bi.y;
-      v.z = acc[ct][pt][2] * sc.z + bi.z;
-      v.w = acc[ct][pt][3] * sc.w + bi.w;
-      if (a.relu) {
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-      }
-      if (a.add_mode) {
-        const float4 r = *reinterpret_cast<const float4 *>(a.add + abase);
-        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-      }
-      *reinterpret_cast<float4 *>(a.out + obase) = v;
-    }
-  }
+  conv_epilogue<CT, PT>(a, cls, acc, wave, j, g, ct0, pz0, py0, px0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -547,17 +584,22 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   return R;
 }
 
+// MaxDynamicSharedMemorySize is a per-device attribute of each kernel: the opt-in is tracked per (device, instance).
+inline void conv_allow_big_lds(const void *fn, std::atomic<unsigned long long> &done, size_t lds_bytes) {
+  if (lds_bytes <= 64 * 1024) return;
+  int dev = 0;
+  DR_HIP(hipGetDevice(&dev));
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return;
+  DR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvMaxLds));
+  done.fetch_or(bit, std::memory_order_release);
+}
 template <int CI, int CT, int PT>
 inline void launch_conv_inst(const ConvLaunch &c, hipStream_t st) {
-  static bool big = false;
-  if (c.lds_bytes > 64 * 1024 && !big) {
-    DR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv<CI, CT, PT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)kConvMaxLds));
-    big = true;
-  }
+  static std::atomic<unsigned long long> done{0};  // bit d: set on device d
+  conv_allow_big_lds(reinterpret_cast<const void *>(&k_conv<CI, CT, PT>), done, c.lds_bytes);
   hipLaunchKernelGGL((k_conv<CI, CT, PT>), c.grid, dim3(kConvThreads), c.lds_bytes, st, c.args);
 }
-
 inline void launch_conv(const ConvLaunch &c, hipStream_t st) {
 #define DR_CONV_CASE(CI_, CT_)                                                  \
   if (c.ci == CI_ && c.ct == CT_) {                                             \

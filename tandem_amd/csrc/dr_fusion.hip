@@ -913,6 +913,7 @@ class FusionEngine {
         DR_HIP(hipHostMalloc((void **)&r.h_depth[k], npix_ * 4, hipHostMallocDefault));
       }
       DR_HIP(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
+      DR_HIP(hipEventCreateWithFlags(&r.cast, hipEventDisableTiming));
       renders_.push_back(r);
     }
     DR_HIP(hipStreamSynchronize(int_stream_));
@@ -926,7 +927,7 @@ class FusionEngine {
     for (auto &r : renders_) {
       (void)hipFree(r.d_bgr); (void)hipFree(r.d_depth); (void)hipFree(r.d_flag);
       for (int k = 0; k < 2; ++k) { (void)hipHostFree(r.h_bgr[k]); (void)hipHostFree(r.h_depth[k]); }
-      (void)hipEventDestroy(r.done); (void)hipStreamDestroy(r.stream);
+      (void)hipEventDestroy(r.done); (void)hipEventDestroy(r.cast); (void)hipStreamDestroy(r.stream);
     }
     (void)hipEventDestroy(int_done_);
     (void)hipStreamDestroy(int_stream_);
@@ -946,7 +947,8 @@ class FusionEngine {
     memcpy(h_depth_in_, depth, npix_ * 4);
     DR_HIP(hipMemcpyAsync(d_bgr_in_, h_bgr_in_, npix_ * 3, hipMemcpyHostToDevice, int_stream_));
     DR_HIP(hipMemcpyAsync(d_depth_in_, h_depth_in_, npix_ * 4, hipMemcpyHostToDevice, int_stream_));
-    for (auto &r : renders_) DR_HIP(hipStreamWaitEvent(int_stream_, r.done, 0));  // renders read the volume
+    // the ray-casts read the volume; their result copies do not (the reference waits for the copies, tsdf_volume.cu:553-556)
+    for (auto &r : renders_) DR_HIP(hipStreamWaitEvent(int_stream_, r.cast, 0));
     enqueue_scan(d_bgr_in_, d_depth_in_, pose16);
     DR_HIP(hipEventRecord(int_done_, int_stream_));
   }
@@ -970,6 +972,7 @@ class FusionEngine {
       Mat P; memcpy(P.m, poses[i], 64);
       DR_HIP(hipStreamWaitEvent(r.stream, int_done_, 0));
       launch_raycast(r.stream, r.d_bgr, r.d_depth, r.d_flag, P);
+      DR_HIP(hipEventRecord(r.cast, r.stream));
       DR_HIP(hipMemcpyAsync(r.h_bgr[free_slot_], r.d_bgr, npix_ * 3, hipMemcpyDeviceToHost, r.stream));
       DR_HIP(hipMemcpyAsync(r.h_depth[free_slot_], r.d_depth, npix_ * 4, hipMemcpyDeviceToHost, r.stream));
       DR_HIP(hipEventRecord(r.done, r.stream));
@@ -1124,7 +1127,7 @@ class FusionEngine {
     const auto t0 = std::chrono::steady_clock::now();
     for (int s = 0; s < n; ++s) {
       hipEvent_t *e = &ev[per * s];
-      for (auto &r : renders_) DR_HIP(hipStreamWaitEvent(int_stream_, r.done, 0));  // the previous frame's renders read the volume
+      for (auto &r : renders_) DR_HIP(hipStreamWaitEvent(int_stream_, r.cast, 0));  // the previous frame's ray-casts read the volume
       DR_HIP(hipEventRecord(e[0], int_stream_));
       kernel_events_[0] = e[1]; kernel_events_[1] = e[2];
       enqueue_scan((const unsigned char *)d_bgr + (size_t)s * npix_ * 3, (const float *)d_depth + (size_t)s * npix_, poses + 16 * s);
@@ -1138,6 +1141,7 @@ class FusionEngine {
         DR_HIP(hipEventRecord(e[3 + 3 * i], r.stream));
         launch_raycast(r.stream, r.d_bgr, r.d_depth, r.d_flag, P);
         DR_HIP(hipEventRecord(e[4 + 3 * i], r.stream));
+        DR_HIP(hipEventRecord(r.cast, r.stream));
         DR_HIP(hipMemcpyAsync(r.h_bgr[free_slot_], r.d_bgr, npix_ * 3, hipMemcpyDeviceToHost, r.stream));
         DR_HIP(hipMemcpyAsync(r.h_depth[free_slot_], r.d_depth, npix_ * 4, hipMemcpyDeviceToHost, r.stream));
         DR_HIP(hipEventRecord(e[5 + 3 * i], r.stream));
@@ -1290,7 +1294,7 @@ class FusionEngine {
     unsigned char *d_bgr, *h_bgr[2];
     float *d_depth, *h_depth[2];
     int *d_flag;  // pixels the fast ray-caster handed to the literal pass
-    hipEvent_t done;
+    hipEvent_t done, cast;  // result on the host / ray-cast kernels finished (the volume may be written again)
   };
   int device_;
   drf_options_t o_;
