@@ -375,16 +375,27 @@ def view_shard_leg(args, rank, dev, world):
                   depth_min=win["depth_min"], depth_max=win["depth_max"], discard=DISCARD)
     m = DrMvsnet(os.path.join(ROOT, "weights", "tandem_va.tdmw"), device=dev)
     mine = view_shard.upload(m, window, rank, world)
-    nmax = max(m.device_tensor("volume%d" % s)[1] for s in (1, 2, 3))
-    ar = view_shard.TorchAllReduce(dev, nmax)
-    for _ in range(warmup):
-        view_shard.forward(m, ar)
-    ar.bytes = 0
+    one_dev = os.environ.get("DR_BENCH_ONE_DEVICE") == "1"  # test scaffold: RCCL refuses two ranks on one device
+    if not one_dev:
+        # the engine's own collective: ncclAllReduce of each cost volume on the engine stream, no host step per phase
+        view_shard.init_engine_collective(m, rank, world)
+        step = lambda n: m.forward(n)
+        mode = "in-engine RCCL all-reduce of the fp32 cost volume after each stage's cost-volume kernel, stream-ordered"
+        nbytes = sum(m.device_tensor("volume%d" % s)[1] for s in (1, 2, 3)) * 4
+    else:
+        nmax = max(m.device_tensor("volume%d" % s)[1] for s in (1, 2, 3))
+        ar = view_shard.TorchAllReduce(dev, nmax)
+
+        def step(n):
+            for _ in range(n):
+                view_shard.forward(m, ar)
+        mode = "host-driven phases with torch.distributed all-reduce (one-device test scaffold)"
+        nbytes = sum(m.device_tensor("volume%d" % s)[1] for s in (1, 2, 3)) * 4
+    step(warmup)
     replicas.barrier(dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        view_shard.forward(m, ar)
+    step(steps)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     replicas.barrier(dev)
@@ -395,8 +406,8 @@ def view_shard_leg(args, rank, dev, world):
     m.close()
     return dict(depth_maps_per_s=steps / tmax, ms_per_depth_map=1e3 * tmax / steps, steps=steps, n_gpus=world,
                 source_views_total=int(nsrc), source_views_this_rank=len(mine) - 1,
-                allreduce_mb_per_depth_map=ar.bytes / steps / 1e6, ranks_agree=bool(same),
-                note="one window sharded over the ranks; 3 fp32 volume all-reduces (RCCL) per depth map; phases host-synchronised")
+                allreduce_mb_per_depth_map=nbytes / 1e6, ranks_agree=bool(same), collective=mode,
+                note="one window sharded over the ranks; 3 fp32 volume all-reduces (RCCL) per depth map")
 
 
 def tsdf_cpu_baseline(scans, opt):

@@ -85,6 +85,15 @@ int drm_set_view_shard(drm_t *h, int nsrc_total); /* 0 = off (default) */
 /* Enqueue phase 0..3 of the resident window and wait for it: 0 = pre-process, FeatureNet, cost volume 1;
  * p = 1,2: regularise + regress stage p, cost volume p+1; 3 = regularise + regress stage 3, edge filter. */
 int drm_forward_phase(drm_t *h, int phase);
+/* The same collective INSIDE the engine, for hosts without a collective library of their own (TANDEM's C++ back-end):
+ * rank 0 draws an id (drm_comm_unique_id) and hands the 128 bytes to every rank by any means; each rank calls
+ * drm_comm_init on its engine (RCCL communicator on the engine's device, librccl bound with dlopen).  From then on a
+ * sharded window (drm_set_view_shard > 0) needs no host step between phases: drm_call_async / drm_forward enqueue the
+ * cost-volume kernels each followed by an in-place ncclAllReduce(sum) of that volume on the engine's stream, overlapped
+ * with FeatureNet's stage-2/3 heads on the side stream.  drm_forward_phase keeps the host-reduced protocol. */
+int drm_comm_unique_id(uint8_t id[128]);
+int drm_comm_init(drm_t *h, int rank, int world, const uint8_t id[128]);
+int drm_comm_destroy(drm_t *h);
 /* Device pointer and element count of a named internal tensor ("volume1".."volume3", "feat1", "depth2", ...). */
 int drm_device_tensor(drm_t *h, const char *name, void **dptr, size_t *nfloats);
 /* Copy the last forward's stage-3 outputs to host (same four arrays as drm_get_result). */

@@ -24,6 +24,10 @@ CASES = [  # name, H, W, V, planes, discard, weights, view_aggregation
     ("v3_64x64_d4", 64, 64, 3, (48, 4, 4), 10.0, "trained", True),
     ("v4_96x128_rand", 96, 128, 4, (48, 32, 8), 5.0, "random", True),
     ("v5_64x96_novar", 64, 96, 5, (48, 32, 8), 5.0, "random", False),  # plain-variance volume (abl01/02 models)
+    # the shapes TANDEM actually runs: the shipped model (tandem/exported/tandem_512x320: 7 views, planes (48,4,4),
+    # cva_mvsnet/configs/abl04_fewer_depth_planes.yaml:8) and BASELINE configs[0] (320x256, ref + 2 src)
+    ("v7_320x512_shipped", 320, 512, 7, (48, 4, 4), 10.0, "trained", True),
+    ("v3_256x320_cfg0", 256, 320, 3, (48, 32, 8), 10.0, "trained", True),
 ]
 
 

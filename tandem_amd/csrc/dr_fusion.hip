@@ -1384,7 +1384,12 @@ int dr_memcpy_h2d(void *dptr, const void *src, size_t bytes) { return guarded([&
 int dr_memcpy_d2d(void *dst, const void *src, size_t bytes) {
   // a device-to-device hipMemcpy may return before the copy has run, and the engines' streams are non-blocking:
   // synchronise so that whatever the caller enqueues next (on any stream) sees the data
-  return guarded([&] { DR_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice)); DR_HIP(hipDeviceSynchronize()); });
+  return guarded([&] {
+    hipPointerAttribute_t at;  // synchronise the device that owns the destination, not whichever is current on this thread
+    if (hipPointerGetAttributes(&at, dst) == hipSuccess) DR_HIP(hipSetDevice(at.device));
+    DR_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice));
+    DR_HIP(hipDeviceSynchronize());
+  });
 }
 int dr_memcpy_d2h(void *dst, const void *dptr, size_t bytes) { return guarded([&] { DR_HIP(hipMemcpy(dst, dptr, bytes, hipMemcpyDeviceToHost)); }); }
 int drf_bench_sequence(drf_t *h, const void *d_bgr, const void *d_depth, const float *poses16, int nframes, int render, float ms[6]) {

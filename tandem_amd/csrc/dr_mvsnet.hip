@@ -8,12 +8,16 @@
 // The threading contract is the reference's: one worker thread, one mutex, two condition variables;
 // CallAsync blocks only while the previous input is still unprocessed.
 #include <cmath>
+#include <atomic>
 #include <condition_variable>
 #include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <thread>
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is bound with dlopen when a communicator is asked for
 
 #include "conv_mfma.h"
 #include "mvs_kernels.h"
@@ -117,6 +121,40 @@ struct Op {
   double flops = 0, bytes = 0;
 };
 
+// RCCL, bound lazily (drm_comm_*): an engine that never view-shards does not need the library, and inside a PyTorch
+// process the same librccl.so.1 that torch.distributed loaded is picked up (one RCCL per process).
+struct Rccl {
+  void *lib = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  static Rccl &get() {
+    static Rccl r;
+    static std::mutex m;
+    std::lock_guard<std::mutex> g(m);
+    if (!r.lib) {
+      for (const char *n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+        if ((r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+      if (!r.lib) fail(DR_ERR_UNSUPPORTED, "RCCL not found (librccl.so.1): %s", dlerror());
+      r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
+      r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
+      r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+      r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.lib, "ncclAllReduce"));
+      r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+      if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString) {
+        r.lib = nullptr;
+        fail(DR_ERR_UNSUPPORTED, "RCCL: missing symbols in librccl");
+      }
+    }
+    return r;
+  }
+  void check(ncclResult_t e, const char *what) const {
+    if (e != ncclSuccess) fail(DR_ERR_DEVICE, "RCCL %s: %s", what, GetErrorString(e));
+  }
+};
+
 class MvsEngine {
  public:
   MvsEngine(const char *path, int device) : device_(device), blob_(load_blob(path)) {
@@ -142,6 +180,7 @@ class MvsEngine {
     worker_.join();
     (void)hipSetDevice(device_);
     (void)hipStreamSynchronize(stream_);
+    if (comm_) { Rccl::get().CommDestroy(comm_); comm_ = nullptr; }
     release();
     if (h_out_) (void)hipHostFree(h_out_);
     if (h_in_) (void)hipHostFree(h_in_);
@@ -256,6 +295,31 @@ class MvsEngine {
     if (nsrc_total < 0 || nsrc_total > kMaxSrc) fail(DR_ERR_ARG, "set_view_shard: %d source views unsupported (0..%d)", nsrc_total, kMaxSrc);
     shard_nsrc_ = nsrc_total;
   }
+  // The view-shard collective inside the engine: with a communicator set, every cost-volume launch of a sharded window
+  // is followed -- on the engine's stream, no host round trip -- by an in-place RCCL sum all-reduce of that volume over
+  // the ranks, so drm_forward / CallAsync run the whole sharded depth map as one stream of work; FeatureNet's stage-2/3
+  // heads on the side stream and the reduce of stage 1 overlap.  (The host-driven protocol of forward_phase stays as
+  // the test double: RCCL refuses two ranks on one device, gloo can emulate them.)
+  void comm_init(int rank, int world, const void *unique_id) {
+    std::unique_lock<std::mutex> lk(mu_);
+    if (comm_) fail(DR_ERR_PROTOCOL, "comm_init: a communicator is already set");
+    if (!unique_id || rank < 0 || rank >= world) fail(DR_ERR_ARG, "comm_init: bad rank %d of %d", rank, world);
+    Rccl &r = Rccl::get();
+    DR_HIP(hipSetDevice(device_));
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof id);
+    r.check(r.CommInitRank(&comm_, world, id, rank), "ncclCommInitRank");
+    comm_world_ = world;
+  }
+  void comm_destroy() {
+    std::unique_lock<std::mutex> lk(mu_);
+    if (!comm_) return;
+    (void)hipSetDevice(device_);
+    (void)hipStreamSynchronize(stream_);
+    Rccl::get().CommDestroy(comm_);
+    comm_ = nullptr;
+    comm_world_ = 0;
+  }
   void forward_phase(int phase) {
     std::unique_lock<std::mutex> lk(mu_);
     require_config();
@@ -264,7 +328,9 @@ class MvsEngine {
     std::vector<size_t> cut{0};
     for (size_t i = 0; i < ops_.size(); ++i) if (ops_[i].kind == Op::COSTVOL) cut.push_back(i + 1);
     cut.push_back(ops_.size());
-    forward(nullptr, cut[phase], cut[phase + 1]);
+    phase_mode_ = true;  // the caller reduces between phases
+    try { forward(nullptr, cut[phase], cut[phase + 1]); } catch (...) { phase_mode_ = false; throw; }
+    phase_mode_ = false;
     DR_HIP(hipStreamSynchronize(stream_));
   }
   void device_tensor(const char *name, void **dptr, size_t *n) {
@@ -468,12 +534,26 @@ class MvsEngine {
     return add_conv(name, p + ".conv", p + ".bn", false, true, in, name, 3, 3, 3, sd, 2, 2, true, CONV_NORMAL, &skip, 1);
   }
 
+  // (Re)builds the whole plan for a new window shape.  The engine keeps H_ = W_ = V_ = 0 ("not configured") until the
+  // plan is complete: if anything below throws (out of memory, unsupported depth_num, missing tensor) everything
+  // allocated so far is released and the next call starts from scratch instead of running a half-built plan.
   void configure(int H, int W, int V) {
     if (H == H_ && W == W_ && V == V_) return;
     DR_HIP(hipStreamSynchronize(stream_));
     release();
-    plan_arena_.reset(new DeviceArena());
+    H_ = W_ = V_ = 0;
+    memset(cv_, 0, sizeof cv_);
+    memset(rg_, 0, sizeof rg_);
+    try {
+      build_plan(H, W, V);
+    } catch (...) {
+      release();
+      throw;
+    }
     H_ = H; W_ = W; V_ = V;
+  }
+  void build_plan(int H, int W, int V) {
+    plan_arena_.reset(new DeviceArena());
     if (h_out_) { (void)hipHostFree(h_out_); h_out_ = nullptr; }
     if (h_in_) { (void)hipHostFree(h_in_); h_in_ = nullptr; }
     DR_HIP(hipHostMalloc((void **)&h_out_, (size_t)H * W * 16, hipHostMallocDefault));
@@ -687,6 +767,11 @@ class MvsEngine {
           if (C == 32) hipLaunchKernelGGL(k_costvol<32>, grid, dim3(256), 0, stream_, b);
           else if (C == 16) hipLaunchKernelGGL(k_costvol<16>, grid, dim3(256), 0, stream_, b);
           else hipLaunchKernelGGL(k_costvol<8>, grid, dim3(256), 0, stream_, b);
+          if (comm_ && shard_nsrc_ && !phase_mode_) {  // view shard: sum the partial volumes of all ranks, in place, in stream order
+            const DevTensor &vol = T("volume" + std::to_string(o.stage));
+            Rccl &r = Rccl::get();
+            r.check(r.AllReduce(vol.d, vol.d, vol.n(), ncclFloat, ncclSum, comm_, stream_), "ncclAllReduce");
+          }
           break;
         }
         case Op::REGRESS: {
@@ -736,12 +821,15 @@ class MvsEngine {
   unsigned filter_rank_ = 0;
   int H_ = 0, W_ = 0, V_ = 0;
   int shard_nsrc_ = 0;  // > 0: view-shard rank, cost-volume divisor = source views of the whole window
+  ncclComm_t comm_ = nullptr;  // view-shard communicator (drm_comm_init); the volumes are reduced in stream order when set
+  int comm_world_ = 0;
+  bool phase_mode_ = false;
 
   std::thread worker_;
   std::mutex mu_;
   std::condition_variable input_cv_, done_cv_;
   bool running_ = true;
-  volatile bool unprocessed_ = false;
+  std::atomic<bool> unprocessed_{false};  // read without the lock by ready() (dr_mvsnet.cpp:54 does the same with a plain bool)
   bool has_output_ = false;
   std::string worker_error_;
 };
@@ -787,6 +875,18 @@ int drm_autotune(drm_t *h, int max_candidates, float *before_ms, float *after_ms
 }
 int drm_set_view_shard(drm_t *h, int nsrc_total) { return guarded([&] { h->e->set_view_shard(nsrc_total); }); }
 int drm_forward_phase(drm_t *h, int phase) { return guarded([&] { h->e->forward_phase(phase); }); }
+int drm_comm_unique_id(uint8_t id[128]) {
+  return guarded([&] {
+    if (!id) dr::fail(DR_ERR_ARG, "drm_comm_unique_id: null argument");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    dr::Rccl &r = dr::Rccl::get();
+    ncclUniqueId u;
+    r.check(r.GetUniqueId(&u), "ncclGetUniqueId");
+    memcpy(id, &u, 128);
+  });
+}
+int drm_comm_init(drm_t *h, int rank, int world, const uint8_t id[128]) { return guarded([&] { h->e->comm_init(rank, world, id); }); }
+int drm_comm_destroy(drm_t *h) { return guarded([&] { h->e->comm_destroy(); }); }
 int drm_device_tensor(drm_t *h, const char *name, void **dptr, size_t *nfloats) {
   return guarded([&] { if (!name) dr::fail(DR_ERR_ARG, "drm_device_tensor: null name"); h->e->device_tensor(name, dptr, nfloats); });
 }

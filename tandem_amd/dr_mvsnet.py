@@ -20,10 +20,21 @@ class DrMvsnetOutput:
         self.confidence_dense = np.empty((height, width), np.float32)
 
 
-def _marshal(bgrs, intrinsic_matrix, cam_to_worlds):
+def _marshal(bgrs, intrinsic_matrix, cam_to_worlds, height, width):
+    """The C ABI copies height*width*3 bytes per view, 16 floats per pose and 9 for K from raw pointers: sizes are
+    checked here so that a wrongly shaped array is an error, not an out-of-bounds host read."""
     bgrs = [np.ascontiguousarray(b, dtype=np.uint8) for b in bgrs]
-    c2ws = [np.ascontiguousarray(c, dtype=np.float32).reshape(16) for c in cam_to_worlds]
-    K = np.ascontiguousarray(intrinsic_matrix, dtype=np.float32).reshape(9)
+    for b in bgrs:
+        if b.size != height * width * 3:
+            raise ValueError("DrMvsnet: image of %d bytes, expected %d x %d x 3" % (b.size, height, width))
+    c2ws = [np.ascontiguousarray(c, dtype=np.float32) for c in cam_to_worlds]
+    if any(c.size != 16 for c in c2ws):
+        raise ValueError("DrMvsnet: every cam_to_world must hold 16 floats")
+    c2ws = [c.reshape(16) for c in c2ws]
+    K = np.ascontiguousarray(intrinsic_matrix, dtype=np.float32)
+    if K.size != 9:
+        raise ValueError("DrMvsnet: intrinsic_matrix must hold 9 floats")
+    K = K.reshape(9)
     V = len(bgrs)
     pb = (u8p * V)(*[b.ctypes.data_as(u8p) for b in bgrs])
     pc = (f32p * V)(*[fptr(c) for c in c2ws])
@@ -48,7 +59,7 @@ class DrMvsnet:
                   depth_max, discard_percentage, debug_print=False):
         """dr_mvsnet.h:43-53.  Blocking for the last input, non-blocking for this one."""
         assert len(bgrs) == view_num and len(cam_to_worlds) == view_num
-        keep = _marshal(bgrs, intrinsic_matrix, cam_to_worlds)
+        keep = _marshal(bgrs, intrinsic_matrix, cam_to_worlds, height, width)
         check(_lib.lib().drm_call_async(self._h, height, width, view_num, ref_index, keep[3], fptr(keep[2]), keep[4],
                                         depth_min, depth_max, discard_percentage))
         self._hw = (height, width)
@@ -71,7 +82,7 @@ class DrMvsnet:
     # ---- device-resident / introspection hooks (no reference counterpart) ----
     def upload(self, height, width, view_num, ref_index, bgrs, intrinsic_matrix, cam_to_worlds, depth_min, depth_max,
                discard_percentage):
-        keep = _marshal(bgrs, intrinsic_matrix, cam_to_worlds)
+        keep = _marshal(bgrs, intrinsic_matrix, cam_to_worlds, height, width)
         check(_lib.lib().drm_upload(self._h, height, width, view_num, ref_index, keep[3], fptr(keep[2]), keep[4],
                                     depth_min, depth_max, discard_percentage))
         self._hw = (height, width)
@@ -94,6 +105,21 @@ class DrMvsnet:
 
     def forward_phase(self, phase):
         check(_lib.lib().drm_forward_phase(self._h, int(phase)))
+
+    @staticmethod
+    def comm_unique_id():
+        """128-byte RCCL id drawn by one rank; hand it to every rank's comm_init."""
+        buf = (C.c_uint8 * 128)()
+        check(_lib.lib().drm_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, rank, world, unique_id):
+        """In-engine view-shard collective: afterwards a sharded window's cost volumes are all-reduced on the engine's stream."""
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        check(_lib.lib().drm_comm_init(self._h, int(rank), int(world), buf))
+
+    def comm_destroy(self):
+        check(_lib.lib().drm_comm_destroy(self._h))
 
     def device_tensor(self, name):
         """(device pointer, float count) of a named internal tensor, e.g. "volume2"."""

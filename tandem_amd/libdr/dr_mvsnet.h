@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -90,9 +91,10 @@ private:
 // `filename_inputs` is a TDMS sample file (tools/export_fixture.py) where the reference read sample_inputs.pt:
 //   "TDMS0001" | int32 V,H,W,ref_index | float depth_min,depth_max,discard | float K[9] | float c2w[V*16]
 //   | u8 bgr[V*H*W*3] | float depth_ref[H*W] | float confidence_ref[H*W]
+// `out_folder` (dr_mvsnet.cpp:515-538): the first repetition's filtered depth map is written to
+// <out_folder>pred_outputs.npy (H x W float32, NumPy format) where the reference pickles the same tensor to pred_outputs.pt.
 inline bool test_dr_mvsnet(DrMvsnet &model, char const *filename_inputs, bool print = false, int repetitions = 1,
                            char const *out_folder = NULL) {
-  (void) out_folder;
   FILE *f = fopen(filename_inputs, "rb");
   if (!f) { fprintf(stderr, "test_dr_mvsnet: cannot open %s\n", filename_inputs); return false; }
   char magic[8]; int hdr[4]; float sc[3], K[9];
@@ -132,6 +134,22 @@ inline bool test_dr_mvsnet(DrMvsnet &model, char const *filename_inputs, bool pr
     if (print) printf("Correctness:\n\tDepth correct     : %d, error: %g\n\tConfidence correct: %d, error: %g\n", ed < atol, ed, ec < atol, ec);
     correct &= ed < atol;
     correct &= ec < atol;
+    if (out_folder && rep == 0) {
+      const std::string out_name = std::string(out_folder) + "pred_outputs.npy";
+      printf("Writing Result to: %s\n", out_name.c_str());
+      FILE *fo = fopen(out_name.c_str(), "wb");
+      if (fo) {
+        char hdr[128];
+        int n = snprintf(hdr, sizeof hdr, "{'descr': '<f4', 'fortran_order': False, 'shape': (%d, %d), }", H, W);
+        while ((10 + n + 1) % 64) hdr[n++] = ' ';
+        hdr[n++] = '\n';
+        const unsigned char pre[10] = {0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0, (unsigned char) (n & 255), (unsigned char) (n >> 8)};
+        fwrite(pre, 1, 10, fo); fwrite(hdr, 1, (size_t) n, fo); fwrite(out->depth, 4, npx, fo);
+        fclose(fo);
+      } else {
+        fprintf(stderr, "test_dr_mvsnet: cannot write %s\n", out_name.c_str());
+      }
+    }
     delete out;
   }
   if (print) {

@@ -45,10 +45,10 @@ class TorchAllReduce:
         import torch.distributed as dist
         from . import _lib
         t = self.buf[:nfloats]
-        self.torch.cuda.synchronize()
+        self.torch.cuda.synchronize(self.buf.device)
         _lib.check(_lib.lib().dr_memcpy_d2d(t.data_ptr(), dptr, nfloats * 4))
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        self.torch.cuda.synchronize()
+        self.torch.cuda.synchronize(self.buf.device)
         _lib.check(_lib.lib().dr_memcpy_d2d(dptr, t.data_ptr(), nfloats * 4))
         self.bytes += nfloats * 4
 
@@ -73,6 +73,17 @@ def forward(model, allreduce):
         ptr, n = model.device_tensor("volume%d" % (p + 1))
         allreduce(ptr, n)
     model.forward_phase(3)
+
+
+def init_engine_collective(model, rank, world):
+    """Give `model` an RCCL communicator of its own (drm_comm_init): rank 0 draws the id, torch.distributed carries the 128
+    bytes to the other ranks.  Afterwards `model.forward(n)` / CallAsync run a sharded window without any host step."""
+    import torch
+    import torch.distributed as dist
+    uid = [model.comm_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(uid, src=0)
+    model.comm_init(rank, world, uid[0])
 
 
 def run(model, window, rank, world, allreduce):

@@ -131,3 +131,89 @@ def random_state(depth_num=(48, 32, 8), base=8, seed=0):
         bn(p + "1", 1)
         conv(p + "3", 1, 1, 1, 1, 1, bias=True); bn(p + "4", 1)
     return sd
+
+
+# ---- converter: the reference's training / export artefacts -> TDMW ----
+_PREFIXES = ("cva_mvsnet.", "model.cva_mvsnet.", "model.", "module.")
+
+
+def _strip(name):
+    for p in _PREFIXES:
+        if name.startswith(p):
+            return name[len(p):]
+    return name
+
+
+def load_reference_weights(path):
+    """Reads what the reference can hand over for a trained CVA-MVSNet and returns (state dict name -> float32 array,
+    hparams dict or None):
+      * a PyTorch-Lightning checkpoint written by cva_mvsnet/train.py (dict with 'state_dict' whose keys carry the
+        `cva_mvsnet.` prefix of models/tandem.py:16, and the hyper-parameters under 'hparams' / 'hyper_parameters');
+      * a TorchScript archive written by cva_mvsnet/export_model.py:197-209 (model.pt, unfrozen: parameters intact) --
+        key names are those of CvaMVSNet.state_dict() already, hyper-parameters are not stored in it;
+      * a plain state_dict saved with torch.save."""
+    import torch
+    hparams = None
+    try:
+        sd = torch.jit.load(path, map_location="cpu").state_dict()
+    except Exception:
+        obj = torch.load(path, map_location="cpu", weights_only=False)
+        if isinstance(obj, dict) and "state_dict" in obj:
+            hparams = obj.get("hparams") or obj.get("hyper_parameters")
+            sd = obj["state_dict"]
+        elif isinstance(obj, dict):
+            sd = obj
+        else:
+            sd = obj.state_dict()
+    out = OrderedDict()
+    for k, v in sd.items():
+        a = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+        if a.dtype.kind == "f":
+            out[_strip(k)] = np.ascontiguousarray(a, np.float32)
+    if not any(k.startswith("feature_net.") for k in out) or not any(k.startswith("cost_regularization_net.") for k in out):
+        raise ValueError("%s: no CvaMVSNet parameters found (feature_net.* / cost_regularization_net.*)" % path)
+    return out, (dict(hparams) if hparams else None)
+
+
+def convert(path, out_path, depth_num=None, interval_ratio=None, view_aggregation=None):
+    """`python -m tandem_amd.weights <ckpt | model.pt> out.tdmw`: header fields come from the checkpoint's hyper-parameters
+    (MODEL.DEPTH_NUM, MODEL.DEPTH_INTERVAL_RATIO, MODEL.VIEW_AGGREGATION, MODEL.FEATURE_NET_BASE_CHANNELS; config.py) when
+    it has them, else from the arguments; view aggregation is recognised by the volume_gates.* parameters."""
+    sd, hp = load_reference_weights(path)
+    hp = hp or {}
+    if (hp.get("MODEL.CONV2D_NORMALIZATION", "batchnorm") != "batchnorm" or hp.get("MODEL.CONV3D_NORMALIZATION", "batchnorm") != "batchnorm"
+            or hp.get("MODEL.CONV2D_USE_BN_SKIP", False)):
+        raise ValueError("only the batchnorm / no-BN-skip architecture TANDEM ships is supported")
+    dn = tuple(depth_num or hp.get("MODEL.DEPTH_NUM") or (48, 32, 8))
+    ratio = tuple(interval_ratio or hp.get("MODEL.DEPTH_INTERVAL_RATIO") or (1.0, 0.5, 0.25))
+    has_gates = any(k.startswith("volume_gates.") for k in sd)
+    va = has_gates if view_aggregation is None else bool(view_aggregation)
+    if "MODEL.VIEW_AGGREGATION" in hp and bool(hp["MODEL.VIEW_AGGREGATION"]) != va:
+        raise ValueError("MODEL.VIEW_AGGREGATION=%s contradicts the parameters (volume_gates.* %s)" % (hp["MODEL.VIEW_AGGREGATION"], "present" if has_gates else "absent"))
+    if va and not has_gates:
+        raise ValueError("view aggregation requested but the checkpoint has no volume_gates.* parameters")
+    base = int(hp.get("MODEL.FEATURE_NET_BASE_CHANNELS", sd["feature_net.conv0.0.conv.weight"].shape[0]))
+    if len(dn) != 3 or len(ratio) != 3:
+        raise ValueError("depth_num / interval_ratio need three stages")
+    write_blob(out_path, sd, depth_num=dn, interval_ratio=ratio, view_aggregation=va, base_channels=base)
+    return dict(tensors=len(sd), depth_num=dn, interval_ratio=ratio, view_aggregation=va, base_channels=base)
+
+
+def _main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(prog="python -m tandem_amd.weights",
+                                 description="Convert a CVA-MVSNet Lightning .ckpt / exported model.pt / state_dict to the TDMW blob DrMvsnet loads")
+    ap.add_argument("input")
+    ap.add_argument("output")
+    ap.add_argument("--depth-num", type=lambda s: tuple(int(v) for v in s.split(",")), default=None,
+                    help="e.g. 48,4,4 (the shipped tandem_512x320 model) -- needed for model.pt, which does not store it")
+    ap.add_argument("--interval-ratio", type=lambda s: tuple(float(v) for v in s.split(",")), default=None)
+    ap.add_argument("--view-aggregation", type=int, choices=(0, 1), default=None)
+    a = ap.parse_args(argv)
+    info = convert(a.input, a.output, a.depth_num, a.interval_ratio, a.view_aggregation)
+    print("wrote %s: %d tensors, depth_num %s, interval ratio %s, view aggregation %s, base channels %d"
+          % (a.output, info["tensors"], info["depth_num"], info["interval_ratio"], info["view_aggregation"], info["base_channels"]))
+
+
+if __name__ == "__main__":
+    _main()

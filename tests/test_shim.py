@@ -64,3 +64,47 @@ def test_tracker_shim_end_to_end(tmp_path):
     r = subprocess.run([build_tracker(tmp_path)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "tracker: E=" in r.stdout
+
+
+REF_TEST = os.path.join(ROOT, "oracle", "_ref", "dr_mvsnet_test")
+REF_SRC = "/root/reference/tandem/libdr/dr_mvsnet/src/dr_mvsnet_test.cpp"
+
+
+@pytest.mark.skipif(not os.path.isfile(REF_SRC), reason="reference checkout not present")
+def test_reference_test_program_compiles_unchanged_against_the_shim(tmp_path):
+    """ref:tandem/libdr/dr_mvsnet/src/dr_mvsnet_test.cpp, as it is, with tandem_amd/libdr/dr_mvsnet.h in place of the
+    reference header (oracle/Makefile.ref builds the copy that travels to the GPU box)."""
+    exe = str(tmp_path / "dr_mvsnet_test")
+    subprocess.check_call(["g++", "-std=c++14", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tandem_amd", "libdr"),
+                           REF_SRC, "-o", exe, "-L" + os.path.join(ROOT, "tandem_amd"), "-ldr_mi355x",
+                           "-Wl,-rpath," + os.path.join(ROOT, "tandem_amd")])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode != 0 and "usage: ./dr_mvsnet_test" in r.stderr
+
+
+@pytest.mark.gpu
+def test_reference_test_program_runs(tmp_path, trained_blob):
+    """The reference's own dr_mvsnet_test (built here from the reference source, unchanged) on the GPU: model load,
+    5 warm-up + 3 timed CallAsync / Ready / GetResult rounds against a stored window at the shape TANDEM ships
+    (320 x 512, 7 views, planes (48,4,4)), the reference's < 1e-2 criterion, and the out_folder dump."""
+    import sys
+    if not os.path.isfile(REF_TEST):
+        pytest.skip("oracle/_ref/dr_mvsnet_test not built (needs the reference checkout at build time)")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from export_fixture import write_tdms
+    from tandem_amd import weights as Wt
+    g = np.load(os.path.join(ROOT, "tests/golden/mvsnet_v7_320x512_shipped.npz"))
+    _, tens = Wt.read_blob(trained_blob)
+    blob = str(tmp_path / "shipped.tdmw")
+    Wt.write_blob(blob, tens, depth_num=tuple(int(v) for v in g["planes"]))
+    sample = str(tmp_path / "sample.tdms")
+    write_tdms(sample, g["bgrs"], g["K"], g["c2ws"], g["ref_index"], g["depth_min"], g["depth_max"], g["discard"],
+               g["ref_s3_depth"], g["ref_s3_confidence"])
+    out_dir = str(tmp_path) + "/"
+    r = subprocess.run([REF_TEST, blob, sample, "3", out_dir], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "All looks good!" in r.stdout and "Loading Model" in r.stdout and "GetResult" in r.stdout
+    pred = np.load(out_dir + "pred_outputs.npy")
+    assert pred.shape == g["ref_s3_depth"].shape
+    same = (pred == 0) == (g["ref_s3_depth"] == 0)
+    assert same.mean() > 0.998 and np.abs(pred - g["ref_s3_depth"])[same].mean() < 1e-4

@@ -132,3 +132,29 @@ def test_two_process_bench_path_on_one_gpu(tmp_path):
     assert vs["n_gpus"] == 2 and vs["source_views_total"] == 6 and vs["source_views_this_rank"] == 3
     assert vs["ranks_agree"] is True
     assert abs(vs["allreduce_mb_per_depth_map"] - 4e-6 * (48 * 120 * 160 * 32 + 32 * 240 * 320 * 16 + 8 * 480 * 640 * 8)) < 1e-3
+
+
+def test_engine_collective_single_rank(trained_blob):
+    """drm_comm_init / in-stream ncclAllReduce: with one rank that holds every source view the sharded forward (divisor
+    = all source views, all-reduce over a 1-rank communicator after every cost volume, no host step) must reproduce the
+    ordinary forward bit for bit; the communicator can be destroyed and re-created."""
+    from oracle import scene
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    H, W, V = 64, 96, 5
+    win = scene.make_window(H, W, V, seed=8)
+    args = (H, W, V, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), win["depth_min"], win["depth_max"], 10.0)
+    a = DrMvsnet(trained_blob)
+    a.upload(*args)
+    a.forward(1)
+    ref = a.download()
+    b = DrMvsnet(trained_blob)
+    for _ in range(2):
+        b.comm_init(0, 1, DrMvsnet.comm_unique_id())
+        b.set_view_shard(V - 1)
+        b.upload(*args)
+        b.forward(2)
+        out = b.download()
+        for x, y in ((ref.depth, out.depth), (ref.confidence, out.confidence), (ref.depth_dense, out.depth_dense)):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+        b.comm_destroy()
+    a.close(); b.close()
