@@ -15,6 +15,7 @@ value = depth maps of all ranks / max-over-ranks time.  Rank 0 prints ONE JSON l
               dr_mvsnet.cpp:540-545): host u8 images in, four float maps out -- PCIe-inclusive, never `value`;
   "tsdf"      BASELINE configs[3]: 1000 distinct depth maps of a camera loop through an analytic room fused into a 5 mm
               hashed voxel grid, integrate + ray-cast per frame, map growing (dr_debug_example.cpp:78-162);
+  "shipped_model"  the 320x512 (48,4,4) model TANDEM ships (published 4.96 FPS), latency and 3-engine throughput;
   "tandem_loop"  BASELINE configs[4] stand-in: TandemBackend's call order (depth network of keyframe k beside fusion +
               ray-cast of k-1) through the C++ shim on one GPU, keyframes/s;
   "tracker", "view_sharded" (N > 1).
@@ -171,6 +172,46 @@ def mvsnet_cpu_baseline(win, blob):
     return dict(value=1.0 / med, unit="depth-maps/s", cores=torch.get_num_threads(), physical_cores=phys, logical_cpus=logical, kind=kind,
                 sample="%d timed forwards of the same 640x480x7-view (48,32,8) window after 1 warm-up, torch CPU fp32, %d threads; median %.2f s, best %.2f s"
                        % (len(times), torch.get_num_threads(), med, min(times)))
+
+
+def shipped_leg(args, dev):
+    """The model TANDEM actually ships and runs (tandem/exported/tandem_512x320: 320 x 512, 7 views, planes (48,4,4) =
+    configs/abl04_fewer_depth_planes.yaml; published: 4.96 FPS on an unstated GPU incl. data loading, pretrained/ablation/
+    abl04_fewer_depth_planes.txt:5), same weights, resident window: single-engine latency and 3-engine throughput."""
+    import tempfile
+    import threading
+    from oracle import scene
+    from tandem_amd import weights as Wt
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    h, w, planes = 320, 512, (48, 4, 4)
+    _, tens = Wt.read_blob(os.path.join(ROOT, "weights", "tandem_va.tdmw"))
+    with tempfile.TemporaryDirectory() as td:
+        blob = os.path.join(td, "shipped.tdmw")
+        Wt.write_blob(blob, tens, depth_num=planes)
+        engines = []
+        for e in range(3):
+            win = scene.make_window(h, w, V, seed=60 + e)
+            m = DrMvsnet(blob, device=dev)
+            m.upload(h, w, V, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), win["depth_min"], win["depth_max"], DISCARD)
+            m.forward(5)
+            engines.append(m)
+        n1 = max(20, min(200, args.steps))
+        lat = engines[0].forward(n1) / n1
+        per = max(20, min(100, args.steps // 3))
+        threads = [threading.Thread(target=lambda m=m: m.forward(per)) for m in engines]
+        t0 = time.perf_counter()
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        dt = time.perf_counter() - t0
+        flops, nbytes = engines[0].work()
+        for m in engines:
+            m.close()
+    return dict(workload="320x512 ref+6-src window, planes (48,4,4) (the shipped tandem_512x320 model), fp32, resident in HBM",
+                single_engine=dict(ms_per_depth_map=lat, depth_maps_per_s=1e3 / lat, forwards=n1),
+                engines_3=dict(depth_maps_per_s=3 * per / dt, windows=3 * per),
+                gflop_per_depth_map=flops / 1e9, reference_published_fps=4.96)
 
 
 def boundary_leg(args, dev):
@@ -472,6 +513,7 @@ def main():
     tr = tracker_leg(args, local_rank) if (rank == 0 and not args.no_tsdf) else None
     bd = boundary_leg(args, local_rank) if (rank == 0 and world == 1 and not args.no_boundary) else None
     lp = tandem_loop_leg(args, local_rank) if (rank == 0 and world == 1 and not args.no_loop) else None
+    sh = shipped_leg(args, local_rank) if (rank == 0 and world == 1 and not args.no_boundary) else None
     vs = None
     if world > 1 and not args.no_view_shard:
         vs = view_shard_leg(args, rank, local_rank, world)
@@ -496,6 +538,8 @@ def main():
             out["tsdf"] = ts
         if bd is not None:
             out["boundary"] = bd
+        if sh is not None:
+            out["shipped_model"] = sh
         if lp is not None:
             out["tandem_loop"] = lp
         if tr is not None:

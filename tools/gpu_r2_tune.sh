@@ -1,0 +1,6 @@
+#!/bin/bash
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+bash tools/tune_conv.sh 320 512 48,4,4 > gpurun_out/conv_tuned_320x512.h 2> gpurun_out/tune_320.err
+bash tools/tune_conv.sh > gpurun_out/conv_tuned_480x640.h 2> gpurun_out/tune_480.err
+wc -l gpurun_out/conv_tuned_*.h; tail -3 gpurun_out/tune_320.err
