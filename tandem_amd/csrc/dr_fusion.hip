@@ -664,6 +664,23 @@ __device__ inline int find_block_xyz(const FusionDev &d, int x, int y, int z, bo
   return -1;
 }
 
+// A voxel is 8 bytes at an 8-byte-aligned address, but `Voxel` itself only promises the alignment of its float: read as a
+// struct it becomes a dword load plus a byte load per field (18 gathers per ray-cast sample).  One 64-bit load instead,
+// and one 128-bit load for two voxels that are neighbours in z.
+struct alignas(8) Voxel8 { unsigned lo, hi; };
+struct __attribute__((packed, aligned(8))) Voxel16 { unsigned a, b, c, d; };
+__device__ inline Voxel unpack_voxel(unsigned lo, unsigned hi) {
+  Voxel v;
+  v.sdf = __uint_as_float(lo);
+  v.c[0] = (unsigned char)(hi & 255u); v.c[1] = (unsigned char)((hi >> 8) & 255u); v.c[2] = (unsigned char)((hi >> 16) & 255u);
+  v.weight = (unsigned char)(hi >> 24);
+  return v;
+}
+__device__ inline Voxel load_voxel(const Voxel *p) {
+  const Voxel8 t = *reinterpret_cast<const Voxel8 *>(p);
+  return unpack_voxel(t.lo, t.hi);
+}
+
 template <bool FAST, bool COLOUR>
 __device__ inline Voxel interp_voxel(const FusionDev &d, F3 pos, bool far_blocks, bool &bail) {  // == get_interpolated_voxel(d, pos), tsdf_volume.cu:161-289
   const float vs = d.o.voxel_size, hv = vs / 2.0f, y = d.vs_rcp;
@@ -674,7 +691,7 @@ __device__ inline Voxel interp_voxel(const FusionDev &d, F3 pos, bool far_blocks
   const int c0x = g0x >> 3, c0y = g0y >> 3, c0z = g0z >> 3;
   const int b0 = find_block_xyz(d, c0x, c0y, c0z, far_blocks, bail);
   Voxel v0 = zero;
-  if (b0 >= 0) v0 = d.vox[(size_t)b0 * 512 + (((g0x & 7) << 6) | ((g0y & 7) << 3) | (g0z & 7))];
+  if (b0 >= 0) v0 = load_voxel(d.vox + (size_t)b0 * 512 + (((g0x & 7) << 6) | ((g0y & 7) << 3) | (g0z & 7)));
   if (v0.weight == 0) return v0;
   const float pdx = pos.x - hv, pdy = pos.y - hv, pdz = pos.z - hv;
   const float wx = qx - floorf(qx), wy = qy - floorf(qy), wz = qz - floorf(qz);  // voxel_position = position / voxel_size is q
@@ -699,11 +716,25 @@ __device__ inline Voxel interp_voxel(const FusionDev &d, F3 pos, bool far_blocks
   P[6] = bz1 == bz0 ? P[2] : (by1 == by0 ? P[4] : look(bx0, by1, bz1));
   P[7] = bz1 == bz0 ? P[3] : (bx1 == bx0 ? P[6] : (by1 == by0 ? P[5] : look(bx1, by1, bz1)));
   Voxel cv[8];
+  // The two z-corners of an (x, y) pair are neighbours in memory (z is the fastest voxel index) whenever they lie in the
+  // same block: one 16-byte load then brings both -- 4 gathers per sample instead of 8 for 7 lanes in 8.
+  if (bz1 == bz0 && gz[1] == gz[0] + 1) {
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const int local = ((gx[c & 1] & 7) << 6) | ((gy[(c >> 1) & 1] & 7) << 3) | (gz[(c >> 2) & 1] & 7);
-    cv[c] = zero;
-    if (P[c] >= 0) cv[c] = d.vox[(size_t)P[c] * 512 + local];
+    for (int c = 0; c < 4; ++c) {
+      const int local = ((gx[c & 1] & 7) << 6) | ((gy[(c >> 1) & 1] & 7) << 3) | (gz[0] & 7);
+      cv[c] = zero; cv[c | 4] = zero;
+      if (P[c] >= 0) {
+        const Voxel16 t = *reinterpret_cast<const Voxel16 *>(d.vox + (size_t)P[c] * 512 + local);
+        cv[c] = unpack_voxel(t.a, t.b); cv[c | 4] = unpack_voxel(t.c, t.d);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int local = ((gx[c & 1] & 7) << 6) | ((gy[(c >> 1) & 1] & 7) << 3) | (gz[(c >> 2) & 1] & 7);
+      cv[c] = zero;
+      if (P[c] >= 0) cv[c] = load_voxel(d.vox + (size_t)P[c] * 512 + local);
+    }
   }
   float dist = 0.0f, cx = 0.0f, cy = 0.0f, cz = 0.0f;
   const int order[8] = {0, 1, 2, 4, 3, 6, 5, 7};  // the reference's corner order: 000 100 010 001 110 011 101 111
