@@ -108,8 +108,8 @@ struct DevTensor {
 };
 
 struct Op {
-  enum Kind { PREPROCESS, CONV, PROB, COSTVOL, REGRESS, EDGE, HIST, SCAN, APPLY } kind;
-  const float *p0 = nullptr, *p1 = nullptr;
+  enum Kind { PREPROCESS, CONV, SKIPUP, PROB, COSTVOL, REGRESS, EDGE, HIST, SCAN, APPLY } kind;
+  const float *p0 = nullptr, *p1 = nullptr, *p3 = nullptr, *p4 = nullptr;
   float *p2 = nullptr;
   int d0 = 0, d1 = 0, d2 = 0;
   std::string name;
@@ -385,6 +385,7 @@ class MvsEngine {
       else if (o.kind == Op::PROB) snprintf(kn, sizeof kn, "k_prob");
       else if (o.kind == Op::REGRESS) snprintf(kn, sizeof kn, "k_regress");
       else if (o.kind == Op::PREPROCESS) snprintf(kn, sizeof kn, "k_preprocess");
+      else if (o.kind == Op::SKIPUP) snprintf(kn, sizeof kn, "k_skip_up<%d>", o.stage);
       else snprintf(kn, sizeof kn, "k_filter");
       char line[256];
       snprintf(line, sizeof line, "%s\t%s\t%.6e\t%.6e\n", o.name.c_str(), kn, o.flops, o.bytes);
@@ -469,6 +470,23 @@ class MvsEngine {
       sc[c] = (float)s;
       bi[c] = (float)((double)b[c] - (double)m[c] * s);
     }
+  }
+  // FeatureNet's skip connection (1x1 conv + bias + nearest-upsampled coarser level) on the streaming kernel k_skip_up;
+  // DR_SKIP_ON_CONV=1 keeps it on the MFMA convolution kernel (A/B hook, and the path for other channel counts).
+  DevTensor &add_skip(const std::string &opname, const std::string &wname, const DevTensor &in, const std::string &outname, const DevTensor &coarse) {
+    const HostTensor &w = blob_.at(wname + ".weight");
+    // (measured at 640x480x7: stage 3, Cin = 8: 0.141 -> 0.108 ms; stage 2, Cin = 16, a quarter of the pixels and twice the
+    // weights per lane: 0.038 -> 0.073 ms, so that one stays where it was)
+    if (getenv("DR_SKIP_ON_CONV") || w.dims[0] != 32 || w.dims[1] != in.C || in.C != 8 || coarse.C != 32 ||
+        coarse.H * 2 != in.H || coarse.W * 2 != in.W)
+      return add_conv(opname, wname, "", true, false, in, outname, 1, 1, 1, 1, 1, 1, false, CONV_NORMAL, &coarse, 2);
+    DevTensor &out = alloc(outname, in.D, in.H, in.W, 32);
+    Op o; o.kind = Op::SKIPUP; o.name = opname;
+    o.p0 = in.d; o.p1 = plan_arena_->upload(w.data); o.p2 = out.d; o.d0 = in.D; o.d1 = in.H; o.d2 = in.W; o.stage = in.C;
+    o.p3 = plan_arena_->upload(blob_.at(wname + ".bias").data); o.p4 = coarse.d;
+    o.flops = 2.0 * in.C * 32 * in.n() / in.C; o.bytes = 4.0 * (in.n() + coarse.n() + out.n());
+    ops_.push_back(o);
+    return out;
   }
   // Adds one convolution layer (possibly several launches) to the plan; returns the output tensor.
   DevTensor &add_conv(const std::string &opname, const std::string &wname, const std::string &bnname, bool conv_bias, bool relu,
@@ -576,10 +594,10 @@ class MvsEngine {
     DevTensor &c1 = cbr2("fn.conv2.2", fn + "conv2.2", c1b, 3, 1, CONV_NORMAL);
     add_conv("fn.out1", fn + "out.stage1", "", false, false, c1, "feat1", 1, 1, 1, 1, 1, 1, false, CONV_NORMAL, nullptr, 0);
     fork_lo_ = ops_.size();
-    DevTensor &i2 = add_conv("fn.skip2", fn + "skip.stage2", "", true, false, c2, "inter2", 1, 1, 1, 1, 1, 1, false, CONV_NORMAL, &c1, 2);
+    DevTensor &i2 = add_skip("fn.skip2", fn + "skip.stage2", c2, "inter2", c1);
     add_conv("fn.out2", fn + "out.stage2", "", false, false, i2, "feat2", 1, 3, 3, 1, 1, 1, false, CONV_NORMAL, nullptr, 0);
     feat2_op_ = ops_.size() - 1;
-    DevTensor &i3 = add_conv("fn.skip3", fn + "skip.stage3", "", true, false, c3, "inter3", 1, 1, 1, 1, 1, 1, false, CONV_NORMAL, &i2, 2);
+    DevTensor &i3 = add_skip("fn.skip3", fn + "skip.stage3", c3, "inter3", i2);
     add_conv("fn.out3", fn + "out.stage3", "", false, false, i3, "feat3", 1, 3, 3, 1, 1, 1, false, CONV_XPAIR, nullptr, 0);
     fork_hi_ = ops_.size();
 
@@ -747,6 +765,12 @@ class MvsEngine {
           if (on_side && i - 1 == feat2_op_) DR_HIP(hipEventRecord(ev_feat2_, side_));
           if (on_side && i - 1 == fork_hi_ - 1) DR_HIP(hipEventRecord(ev_feat3_, side_));
           break;
+        case Op::SKIPUP: {
+          const size_t npix = (size_t)o.d0 * o.d1 * o.d2;
+          const dim3 grid((unsigned)std::min<size_t>((npix + 31) / 32, 8192));
+          hipLaunchKernelGGL(k_skip_up<8>, grid, dim3(256), 0, stream_, o.p0, o.p1, o.p3, o.p4, o.p2, o.d0, o.d1, o.d2);
+          break;
+        }
         case Op::PROB:
         {
           // z-march chunk: long chunks amortise the 2 halo planes, but the launch needs ~1000 waves to fill the chip

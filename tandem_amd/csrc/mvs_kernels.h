@@ -26,6 +26,48 @@ __global__ void k_preprocess(const uint8_t *__restrict__ bgr, float4 *__restrict
   img[i] = make_float4(lut[p[2]], lut[p[1]], lut[p[0]], 0.f);
 }
 
+// ------------------------------------------------------------------ FeatureNet skip connection
+// inter = nearest_up2(coarser) + conv1x1(x) + bias   (module.py:518-531: `F.interpolate(..., scale_factor=2) + skip(...)`).
+// Cin = 8 or 16 inputs, 32 outputs per pixel: 512-1024 flop against 128 B written, 128 B re-read -- a streaming
+// operation.  On the MFMA convolution kernel (tile staging through LDS, K = 8 padded to a 16-wide chunk) it ran at
+// 2.3 TB/s; here one lane owns 4 output channels of a pixel (8 lanes = one 128-byte pixel record, a wave = 1 KiB of
+// contiguous output), its 4 x Cin weights live in registers, and the products are accumulated in the order the MFMA
+// kernel accumulated them (k = 4g + s: s outer, g inner), so the result is the same fmaf chain.
+template <int CIN>
+__global__ __launch_bounds__(256) void k_skip_up(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                                                 const float *__restrict__ coarse, float *__restrict__ out, int V, int H, int W) {
+  constexpr int CO = 32;
+  const int q = threadIdx.x & 7;  // output channels 4q .. 4q+3
+  float wr[4][CIN];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) wr[r][c] = w[(4 * q + r) * CIN + c];
+  const float4 b = *reinterpret_cast<const float4 *>(bias + 4 * q);
+  const size_t npix = (size_t)V * H * W, stride = (size_t)gridDim.x * (blockDim.x >> 3);
+  const int Hc = H >> 1, Wc = W >> 1;
+  for (size_t p = (size_t)blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3); p < npix; p += stride) {
+    const int xx = (int)(p % W), yy = (int)((p / W) % H), v = (int)(p / ((size_t)W * H));
+    float xi[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; c += 4) {
+      const float4 t = *reinterpret_cast<const float4 *>(x + p * CIN + c);
+      xi[c] = t.x; xi[c + 1] = t.y; xi[c + 2] = t.z; xi[c + 3] = t.w;
+    }
+    const float4 up = *reinterpret_cast<const float4 *>(coarse + (((size_t)v * Hc + (yy >> 1)) * Wc + (xx >> 1)) * CO + 4 * q);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int g = 0; g < CIN / 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(wr[r][4 * g + s], xi[4 * g + s], acc[r]);
+    float4 o;
+    o.x = (acc[0] + b.x) + up.x; o.y = (acc[1] + b.y) + up.y; o.z = (acc[2] + b.z) + up.z; o.w = (acc[3] + b.w) + up.w;
+    *reinterpret_cast<float4 *>(out + p * CO + 4 * q) = o;
+  }
+}
+
 // ------------------------------------------------------------------ depth hypotheses
 struct PlaneArgs {
   const float *prev;  // previous stage depth (hp x wp) or nullptr for the uniform stage

@@ -104,8 +104,11 @@ def test_protocol_and_argument_errors(trained_blob):
     with pytest.raises(_lib.DrError) as e:  # dr_mvsnet.cpp:153-160
         m.CallAsync(64, 96, 3, win["ref_index"], aliased, win["K"], list(win["c2ws"]), 0.5, 5.0, 2.5)
     assert e.value.code == 1
-    with pytest.raises(_lib.DrError):
+    with pytest.raises(ValueError):  # images of another size than announced: caught by the Python mirror's size check
         m.CallAsync(60, 96, 3, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), 0.5, 5.0, 2.5)
+    odd = [np.ascontiguousarray(b[:62]) for b in win["bgrs"]]
+    with pytest.raises(_lib.DrError):  # a height the 3-stage pyramid cannot hold: rejected by the engine
+        m.CallAsync(62, 96, 3, win["ref_index"], odd, win["K"], list(win["c2ws"]), 0.5, 5.0, 2.5)
     m.CallAsync(*args)  # still usable afterwards
     out = m.GetResult()
     assert np.isfinite(out.depth_dense).all()
