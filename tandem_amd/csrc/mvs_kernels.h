@@ -125,12 +125,13 @@ struct CostVolArgs {
 
 __device__ inline float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
-// One lane owns CPL = 8 channels (4 when C == 8... see LPV) of one pixel and walks the depth planes of its chunk.
+// One lane owns CPL channels of one pixel (4: the C / 4 lanes of a pixel read its whole channels-last record with one
+// instruction -- the kernel is bound by the L1's one tag look-up per cycle, PMC: 0.8 line accesses per cycle per CU with
+// CPL = 8) and walks the depth planes of its chunk.
 // Per (plane, view): 3 FMAs + one v_rcp (1 ulp; the reference divides, the coordinate differs by <1e-4 px) give the
 // source position; taps are fetched branch-free (clamped address, zeroed weight == grid_sample's zero padding).
-template <int C>
+template <int C, int CPL>               // CPL = channels per lane (4 or 8)
 __global__ __launch_bounds__(256) void k_costvol(const CostVolArgs a) {
-  constexpr int CPL = C >= 16 ? 8 : 4;  // channels per lane
   constexpr int NV = CPL / 4;           // float4 per lane
   constexpr int LPV = C / CPL;          // lanes per pixel
   constexpr int PXB = 256 / LPV;        // pixels per block
