@@ -249,15 +249,18 @@ __global__ __launch_bounds__(256) void k_costvol(const CostVolArgs a) {
 // Each lane owns the column (y, x0..x0+3) of a z-chunk and MARCHES along z: one input plane (3 rows x 6 positions
 // x 8 channels) is loaded once and feeds the three output planes it touches, so L1 traffic is a third of a
 // plane-at-a-time stencil.
+template <int XO>  // x outputs per lane (4: fewest L1 accesses per output; 2: twice the waves to hide their latency)
 __global__ __launch_bounds__(256) void k_prob(const float *__restrict__ x, const float *__restrict__ wt /*[27][8]*/,
                                               float *__restrict__ out, int D, int h, int w, int zchunk) {
-  const int wq = w >> 2;
+  const int wq = w / XO;
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= h * wq) return;
-  const int xq = n % wq, y = n / wq, x0 = xq * 4;
+  const int xq = n % wq, y = n / wq, x0 = xq * XO;
   const int z0 = blockIdx.y * zchunk, z1 = min(D, z0 + zchunk);
   // acc[j][o]: output plane (zz - 1 + j) while input plane zz is being consumed
-  float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+  float a0[XO], a1[XO], a2[XO];
+#pragma unroll
+  for (int o = 0; o < XO; ++o) a0[o] = a1[o] = a2[o] = 0.f;
   for (int zz = z0 - 1; zz <= z1; ++zz) {
     if (zz >= 0 && zz < D) {
 #pragma unroll
@@ -265,9 +268,9 @@ __global__ __launch_bounds__(256) void k_prob(const float *__restrict__ x, const
         const int yy = y + kh - 1;
         if (yy < 0 || yy >= h) continue;
         const float *row = x + ((size_t)zz * h + yy) * w * 8;
-        float4 lo[6], hi[6];
+        float4 lo[XO + 2], hi[XO + 2];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < XO + 2; ++i) {
           const int xx = x0 - 1 + i;
           if (xx >= 0 && xx < w) { lo[i] = ld4(row + (size_t)xx * 8); hi[i] = ld4(row + (size_t)xx * 8 + 4); }
           else { lo[i] = make_float4(0.f, 0.f, 0.f, 0.f); hi[i] = lo[i]; }
@@ -278,15 +281,20 @@ __global__ __launch_bounds__(256) void k_prob(const float *__restrict__ x, const
           // input plane zz is tap kd = 2 of output zz-1, kd = 1 of output zz, kd = 0 of output zz+1
           const float *w2 = wt + ((2 * 3 + kh) * 3 + kw) * 8, *w1 = wt + ((1 * 3 + kh) * 3 + kw) * 8, *w0 = wt + ((0 * 3 + kh) * 3 + kw) * 8;
 #pragma unroll
-          for (int o = 0; o < 4; ++o) { DR_DOT8(a0[o], kw + o, w2); DR_DOT8(a1[o], kw + o, w1); DR_DOT8(a2[o], kw + o, w0); }
+          for (int o = 0; o < XO; ++o) { DR_DOT8(a0[o], kw + o, w2); DR_DOT8(a1[o], kw + o, w1); DR_DOT8(a2[o], kw + o, w0); }
         }
 #undef DR_DOT8
       }
     }
     const int zo = zz - 1;  // complete once input plane zz has been consumed
-    if (zo >= z0 && zo < z1) *reinterpret_cast<float4 *>(out + ((size_t)zo * h + y) * w + x0) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+    if (zo >= z0 && zo < z1) {
+      float *dst = out + ((size_t)zo * h + y) * w + x0;
+      if (XO == 4) *reinterpret_cast<float4 *>(dst) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+      else if (XO == 2) *reinterpret_cast<float2 *>(dst) = make_float2(a0[0], a0[1]);
+      else dst[0] = a0[0];
+    }
 #pragma unroll
-    for (int o = 0; o < 4; ++o) { a0[o] = a1[o]; a1[o] = a2[o]; a2[o] = 0.f; }
+    for (int o = 0; o < XO; ++o) { a0[o] = a1[o]; a1[o] = a2[o]; a2[o] = 0.f; }
   }
 }
 
