@@ -57,15 +57,30 @@ struct ConvArgs {
   unsigned magicX, magicY;  // ceil(2^32 / TXI), ceil(2^32 / TYI): exact division of tile positions (< 2^16)
   int nuMax;                // max K chunks per pass over the classes (sizes the LDS weight area)
   int tilesD, tilesH, tilesW;
+  // FZ instances: the input tensor is never materialised -- the staging step computes it from FeatureNet's skip pair,
+  // in[v][y][x][c] = (W1 . fz_x[v][y][x][0..FZ) + fz_b)[c] + fz_coarse[v][y/2][x/2][c]   (module.py:517-529)
+  const float *fz_x, *fz_w, *fz_b, *fz_coarse;
+  // k_conv_a (persistent, LDS-DMA staged) only:
+  const float *zero16;  // 16 zero bytes: the source of every staged element outside the tensor
+  int a_slots;          // 16-byte LDS slots per tile buffer (multiple of 512)
+  int a_wbufs;          // weight buffers: 1 (single pass: loaded once per workgroup) or 2 (one per pass in flight)
 };
 
 constexpr int kConvThreads = 256;
 constexpr size_t kConvMaxLds = 160 * 1024;  // gfx950: 160 KiB LDS per CU, one workgroup may take all of it
 
 // ---- epilogue: folded BN, ReLU, residual / upsample add, one float4 (4 channels) per lane ----
+template <int CT>
+__device__ inline void conv_load_affine(const ConvArgs &a, int g, int ct0, float4 (&sc)[CT], float4 (&bi)[CT]) {
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {  // scale / bias are padded to whole 16-row tiles on the host
+    sc[ct] = *reinterpret_cast<const float4 *>(a.scale + (ct0 + ct) * 16 + 4 * g);
+    bi[ct] = *reinterpret_cast<const float4 *>(a.bias + (ct0 + ct) * 16 + 4 * g);
+  }
+}
 template <int CT, int PT>
-__device__ inline void conv_epilogue(const ConvArgs &a, const ConvClass &cls, floatx4 (&acc)[CT][PT], int wave, int j, int g, int ct0,
-                                     int pz0, int py0, int px0) {
+__device__ inline void conv_epilogue(const ConvArgs &a, const ConvClass &cls, floatx4 (&acc)[CT][PT], const float4 (&scv)[CT], const float4 (&biv)[CT],
+                                     int wave, int j, int g, int ct0, int pz0, int py0, int px0) {
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
     const int tau = wave * PT + pt;
@@ -85,8 +100,7 @@ __device__ inline void conv_epilogue(const ConvArgs &a, const ConvClass &cls, fl
       const size_t obase = (((size_t)oz * a.outH + oy) * a.outW + ox) * a.outC + ch;
       size_t abase = obase;
       if (a.add_mode == 2) abase = (((size_t)oz * a.addH + (oy >> 1)) * a.addW + (ox >> 1)) * a.outC + ch;
-      const float4 sc = *reinterpret_cast<const float4 *>(a.scale + c0);
-      const float4 bi = *reinterpret_cast<const float4 *>(a.bias + c0);
+      const float4 sc = scv[ct], bi = biv[ct];
       float4 v;
       v.x = acc[ct][pt][0] * sc.x + bi.x;
       v.y = acc[ct][pt][1] * sc.y + bi.y;
@@ -174,7 +188,10 @@ __device__ inline void conv_kloop(const float *lds, const float4 *wl, const int 
 }
 
 // grid = (tiles, parity classes, output-row groups).  PT = position tiles (16 positions each) per wave.
-template <int CI, int CT, int PT>
+// FZ > 0: fused FeatureNet skip -- the staged tile is computed (1x1 conv of an FZ-channel tensor + bias + nearest
+// upsample of the coarser level) instead of copied; the arithmetic is k_skip_up's, so the result is bit-identical to
+// running that kernel first and this one on its output.
+template <int CI, int CT, int PT, int FZ = 0>
 __global__ __launch_bounds__(kConvThreads) void k_conv(const ConvArgs a) {
   extern __shared__ float4 lds4[];
   float *lds = reinterpret_cast<float *>(lds4);
@@ -228,6 +245,61 @@ __global__ __launch_bounds__(kConvThreads) void k_conv(const ConvArgs a) {
     // ---- stage CI channels of the input halo tile into LDS (zero outside the tensor).  Loads are issued in
     // batches of kStageBatch per lane BEFORE the first LDS write so their HBM/L2 latencies overlap. ----
     constexpr int kStageBatch = CT >= 4 ? 6 : 12;  // normally the whole stage: one exposed HBM/L2 latency per pass
+    if constexpr (FZ > 0) {
+      static_assert(FZ == 0 || (C4 == kConvThreads / 64 && FZ % 4 == 0), "one wave per 4-channel group of the pass");
+      // wave w produces channels p*CI + 4w .. +3 of every staged position: its 4 x FZ weights are wave-uniform (scalar
+      // registers), a lane reads 4*FZ contiguous bytes of x (64 lanes = one contiguous run) and writes one float4.
+      const int q = __builtin_amdgcn_readfirstlane(p * C4 + wave);
+      float wr[4][FZ];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < FZ; ++c) wr[r][c] = a.fz_w[(4 * q + r) * FZ + c];
+      const float4 fb = *reinterpret_cast<const float4 *>(a.fz_b + 4 * q);
+#ifndef DR_FZ_BATCH
+#define DR_FZ_BATCH 4
+#endif
+      constexpr int kFB = DR_FZ_BATCH;
+      const int Hc = a.inH >> 1, Wc = a.inW >> 1;
+      for (int p0 = 0; p0 < NP; p0 += 64 * kFB) {
+        float4 xv[kFB][FZ / 4], up[kFB];
+        int dst[kFB];
+        bool in[kFB];
+#pragma unroll
+        for (int k = 0; k < kFB; ++k) {
+          const unsigned pos = p0 + k * 64 + lane;
+          const unsigned t = a.magicX ? __umulhi(pos, a.magicX) : pos, x = pos - t * a.TXI;
+          const unsigned z = a.magicY ? __umulhi(t, a.magicY) : t, y = t - z * a.TYI;
+          const int gz = iz0 + (int)z, gy = iy0 + (int)y, gx = ix0 + (int)x;
+          dst[k] = (int)pos < NP ? (int)(pos * CIS + wave * 4) : -1;
+          in[k] = (int)pos < NP && gz >= 0 && gz < a.inD && gy >= 0 && gy < a.inH && gx >= 0 && gx < a.inW;
+          up[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int c = 0; c < FZ / 4; ++c) xv[k][c] = up[k];
+          if (in[k]) {
+            const float *xp = a.fz_x + (((size_t)gz * a.inH + gy) * a.inW + gx) * FZ;
+#pragma unroll
+            for (int c = 0; c < FZ / 4; ++c) xv[k][c] = *reinterpret_cast<const float4 *>(xp + 4 * c);
+            up[k] = *reinterpret_cast<const float4 *>(a.fz_coarse + (((size_t)gz * Hc + (gy >> 1)) * Wc + (gx >> 1)) * a.inC + 4 * q);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < kFB; ++k) {
+          float acc4[4] = {0.f, 0.f, 0.f, 0.f}, xi[FZ];
+#pragma unroll
+          for (int c = 0; c < FZ / 4; ++c) { xi[4 * c] = xv[k][c].x; xi[4 * c + 1] = xv[k][c].y; xi[4 * c + 2] = xv[k][c].z; xi[4 * c + 3] = xv[k][c].w; }
+#pragma unroll
+          for (int sft = 0; sft < 4; ++sft)
+#pragma unroll
+            for (int gq = 0; gq < FZ / 4; ++gq)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc4[r] = __builtin_fmaf(wr[r][4 * gq + sft], xi[4 * gq + sft], acc4[r]);
+          float4 o = make_float4(0.f, 0.f, 0.f, 0.f);  // outside the tensor: the 3x3 layer's zero padding
+          if (in[k]) { o.x = (acc4[0] + fb.x) + up[k].x; o.y = (acc4[1] + fb.y) + up[k].y; o.z = (acc4[2] + fb.z) + up[k].z; o.w = (acc4[3] + fb.w) + up[k].w; }
+          if (dst[k] >= 0) *reinterpret_cast<float4 *>(lds + dst[k]) = o;
+        }
+      }
+    } else
 #ifdef DR_ABL_NO_STAGE
     if (a.npass < 0)  // ablation build: no staging at all (results are garbage)
 #endif
@@ -281,7 +353,195 @@ __global__ __launch_bounds__(kConvThreads) void k_conv(const ConvArgs a) {
     __syncthreads();
   }
 
-  conv_epilogue<CT, PT>(a, cls, acc, wave, j, g, ct0, pz0, py0, px0);
+  float4 scv[CT], biv[CT];
+  conv_load_affine<CT>(a, g, ct0, scv, biv);
+  conv_epilogue<CT, PT>(a, cls, acc, scv, biv, wave, j, g, ct0, pz0, py0, px0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_conv_a: the same implicit GEMM as a PERSISTENT workgroup whose staging is asynchronous.
+//
+// k_conv's phases are additive (r2 ablation at s2.conv0: K loop 61 %, staging 24 %, epilogue + launch 11 %; two
+// co-resident workgroups run in phase, so they do not hide each other's staging).  Here a workgroup of 8 waves walks a
+// list of (tile, channel pass) units; while the MFMAs of unit i run out of LDS buffer i & 1, the halo tile (and, for
+// multi-pass layers, the packed weights) of unit i + 1 stream into the other buffer with global_load_lds_dwordx4 --
+// no staging registers, no ds_write pass, one barrier per unit.  The LDS-DMA destination is wave-uniform base +
+// lane * 16, so the tile is stored unpadded; bank conflicts of the operand reads are avoided by a slot permutation
+// applied on the SOURCE side (each lane fetches the element that belongs in its slot) and on the read side
+// (tools/ubench/glds_probe.hip: conflict-free for position strides 1 and 2, which is what the layers use).
+constexpr int kConvAThreads = 512;
+
+template <int CI>
+__device__ inline int conv_a_unit(int pos, int c4) {  // (position, channel group) -> 16-byte slot
+  if constexpr (CI == 4) return pos;
+  else if constexpr (CI == 8) return ((pos ^ ((pos >> 3) & 1)) << 1) | c4;
+  else return ((pos ^ ((pos >> 3) & 1)) << 2) | (c4 ^ ((pos >> 1) & 3));
+}
+template <int CI>
+__device__ inline void conv_a_slot(int s, int &pos, int &c4) {  // inverse of conv_a_unit (both xors are involutions)
+  if constexpr (CI == 4) { pos = s; c4 = 0; }
+  else if constexpr (CI == 8) { const int pp = s >> 1; pos = pp ^ ((pp >> 3) & 1); c4 = s & 1; }
+  else { const int pp = s >> 2; pos = pp ^ ((pp >> 3) & 1); c4 = (s & 3) ^ ((pos >> 1) & 3); }
+}
+
+// One LDS-DMA piece: every lane fetches 16 bytes from its own global address, the wave's 1 KiB lands at LDS byte address
+// `lds_dst` (wave-uniform) + lane * 16.  Issued from inline asm on purpose: given the builtin, hipcc orders every later
+// LDS read behind the DMA with s_waitcnt vmcnt(0) -- directly in front of the K loop, which serialises the very overlap
+// this kernel exists for.  The asm statement is invisible to hipcc's counters; k_conv_a waits for it itself
+// (conv_a_wait_dma) before the barrier that publishes the buffer.  M0 is saved and restored around the instruction.
+__device__ inline void conv_a_dma16(const void *gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ inline void conv_a_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ inline unsigned conv_a_lds_addr(const void *p) {
+  return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char *)p;
+}
+
+template <int CI, int CT>
+__device__ inline void conv_a_issue(const ConvArgs &a, float4 *tile, float4 *wbuf, bool with_weights, int NP, int NU, int p, int ct0, int w_base,
+                                    int iz0, int iy0, int ix0, int wave, int lane) {
+  for (int s0 = wave * 64; s0 < a.a_slots; s0 += kConvAThreads) {  // s0 is wave-uniform
+    int pos, c4;
+    conv_a_slot<CI>(s0 + lane, pos, c4);
+    const unsigned t = a.magicX ? __umulhi((unsigned)pos, a.magicX) : (unsigned)pos, x = pos - t * a.TXI;
+    const unsigned z = a.magicY ? __umulhi(t, a.magicY) : t, y = t - z * a.TYI;
+    const int gz = iz0 + (int)z, gy = iy0 + (int)y, gx = ix0 + (int)x;
+    const float *src = a.zero16;
+    if (pos < NP && gz >= 0 && gz < a.inD && gy >= 0 && gy < a.inH && gx >= 0 && gx < a.inW)
+      src = a.in + (((size_t)gz * a.inH + gy) * a.inW + gx) * a.inC + p * CI + c4 * 4;
+    conv_a_dma16(src, __builtin_amdgcn_readfirstlane(conv_a_lds_addr(tile + s0)));
+  }
+  if (with_weights) {  // packed weights of this pass and row group: [u][CT][64] float4, lane-linear as they are in memory
+    const float4 *wsrc = a.wpk + w_base + ((size_t)p * NU * a.ctTot + ct0) * 64;
+    for (int e0 = wave * 64; e0 < NU * CT * 64; e0 += kConvAThreads) {
+      const int u = e0 / (CT * 64), r = e0 - u * (CT * 64);
+      conv_a_dma16(wsrc + (size_t)u * a.ctTot * 64 + r + lane, __builtin_amdgcn_readfirstlane(conv_a_lds_addr(wbuf + e0)));
+    }
+  }
+}
+
+template <int CI, int CT, int PT>
+__device__ inline void conv_a_load(const float4 *tile, const float4 *wp, int toff, int u, int c4, const int (&bpos)[PT], float4 (&av)[CT], float4 (&bv)[PT]) {
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) av[ct] = wp[(u * CT + ct) * 64];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) bv[pt] = tile[conv_a_unit<CI>(bpos[pt] + toff, c4)];
+}
+template <int CI, int CT, int PT>
+__device__ inline void conv_a_kloop(const float4 *tile, const float4 *wl, const int *tp, int TPC, int NU, int lane, int c4, const int (&bpos)[PT],
+                                    floatx4 (&acc)[CT][PT]) {
+  const float4 *wp = wl + lane;
+  float4 a0[CT], b0[PT], a1[CT], b1[PT];
+  int tA = tp[0], tB = tp[min(1, NU - 1) * TPC];
+  conv_a_load<CI, CT, PT>(tile, wp, tA, 0, c4, bpos, a0, b0);
+  int u = 0;
+  for (; u + 1 < NU; u += 2) {
+    conv_a_load<CI, CT, PT>(tile, wp, tB, u + 1, c4, bpos, a1, b1);
+    tA = tp[min(u + 2, NU - 1) * TPC];
+    __builtin_amdgcn_sched_barrier(0);
+    conv_chunk_mfma<CT, PT>(a0, b0, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    conv_chunk_anchor<CT, PT>(a1, b1, tA);
+    conv_a_load<CI, CT, PT>(tile, wp, tA, min(u + 2, NU - 1), c4, bpos, a0, b0);
+    tB = tp[min(u + 3, NU - 1) * TPC];
+    __builtin_amdgcn_sched_barrier(0);
+    conv_chunk_mfma<CT, PT>(a1, b1, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    conv_chunk_anchor<CT, PT>(a0, b0, tB);
+  }
+  if (u < NU) conv_chunk_mfma<CT, PT>(a0, b0, acc);
+}
+
+// grid = (persistent workgroups (multiple of 8), 1, output-row groups); 8 waves, PT position tiles per wave.
+template <int CI, int CT, int PT>
+__global__ __launch_bounds__(kConvAThreads) void k_conv_a(const ConvArgs a) {
+  extern __shared__ float4 lds4[];
+  constexpr int TPC = 16 / CI;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, g = lane >> 4;
+  const ConvClass cls = a.cls[0];
+  const int ct0 = blockIdx.z * CT;
+  const int NP = a.TZI * a.TYI * a.TXI, NU = cls.NU, n_w = NU * CT * 64;
+
+  // LDS: [tile 0][tile 1][weights 0][weights 1 (multi-pass layers)][tap table]
+  float4 *tile0 = lds4, *tile1 = lds4 + a.a_slots;
+  float4 *wb0 = lds4 + 2 * (size_t)a.a_slots, *wb1 = a.a_wbufs > 1 ? wb0 + n_w : wb0;
+  int *tapl = reinterpret_cast<int *>(wb0 + (size_t)a.a_wbufs * n_w);
+  for (int i = tid; i < NU * TPC; i += kConvAThreads) tapl[i] = a.tapoff[cls.tap_base + i];
+  const int *tp = tapl + (4 * g) / CI;
+  const int c4 = ((4 * g) % CI) / 4;
+
+  int bpos[PT];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const int tau = wave * PT + pt;
+    const int xt = tau % a.TXT, yt = (tau / a.TXT) % a.TY, zt = tau / (a.TXT * a.TY);
+    bpos[pt] = ((zt * a.sz) * a.TYI + yt * a.sy) * a.TXI + (xt * 16 + j) * a.sx;
+  }
+
+  // this workgroup's tiles: XCD k (= blockIdx.x % 8, own L2) owns the k-th contiguous range of tiles; its workgroups
+  // take them round-robin, so at any time an XCD works on neighbouring tiles whose halos overlap in its L2
+  const int ntiles = a.tilesD * a.tilesH * a.tilesW, per_xcd = (ntiles + 7) >> 3;
+  const int xcd = blockIdx.x & 7, wi = blockIdx.x >> 3, nw = gridDim.x >> 3;
+  const int t_lo = xcd * per_xcd, t_hi = min(ntiles, t_lo + per_xcd);
+  const int my_tiles = t_lo + wi < t_hi ? (t_hi - t_lo - wi + nw - 1) / nw : 0;
+  const int n_units = my_tiles * a.npass;
+  auto tile_origin = [&](int k, int &pz0, int &py0, int &px0) {
+    int b = t_lo + wi + k * nw;
+    const int tw = b % a.tilesW;
+    b /= a.tilesW;
+    pz0 = (b / a.tilesH) * a.TZ; py0 = (b % a.tilesH) * a.TY; px0 = tw * a.TXT * 16;
+  };
+  auto issue = [&](int unit) {
+    const int k = unit / a.npass, p = unit - k * a.npass;
+    int pz0, py0, px0;
+    tile_origin(k, pz0, py0, px0);
+    // weight buffer = pass % buffers: with one or two passes every pass keeps its own buffer and is fetched once
+    conv_a_issue<CI, CT>(a, (unit & 1) ? tile1 : tile0, (p & 1) ? wb1 : wb0, unit < a.npass || a.npass > a.a_wbufs, NP, NU, p, ct0, cls.w_base,
+                         pz0 * a.sz - a.pz, py0 * a.sy - a.py, px0 * a.sx - a.px, wave, lane);
+  };
+
+  floatx4 acc[CT][PT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  float4 scv[CT], biv[CT];  // folded BatchNorm of this lane's rows: fetched once, not per tile
+  conv_load_affine<CT>(a, g, ct0, scv, biv);
+  if (n_units > 0) issue(0);
+  int done_tile = -1;  // tile whose accumulators are complete and not yet written
+  for (int i = 0; i < n_units; ++i) {
+    conv_a_wait_dma();  // this wave's pieces of unit i have landed ...
+    __syncthreads();    // ... and so have everybody else's; every wave is done reading the other buffer
+#ifdef DR_ABL_NO_EPI
+    if (done_tile >= 0 && a.npass < 0) {
+#else
+    if (done_tile >= 0) {  // epilogue of the previous tile: its stores retire under the K loop below
+#endif
+      int pz0, py0, px0;
+      tile_origin(done_tile, pz0, py0, px0);
+      conv_epilogue<CT, PT>(a, cls, acc, scv, biv, wave, j, g, ct0, pz0, py0, px0);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
+      done_tile = -1;
+    }
+#ifndef DR_ABL_NO_STAGE
+    if (i + 1 < n_units) issue(i + 1);
+#endif
+#ifndef DR_ABL_NO_KLOOP
+    conv_a_kloop<CI, CT, PT>((i & 1) ? tile1 : tile0, ((i % a.npass) & 1) ? wb1 : wb0, tp, TPC, NU, lane, c4, bpos, acc);
+#endif
+    if ((i + 1) % a.npass == 0) done_tile = i / a.npass;
+  }
+  if (done_tile >= 0) {
+    int pz0, py0, px0;
+    tile_origin(done_tile, pz0, py0, px0);
+    conv_epilogue<CT, PT>(a, cls, acc, scv, biv, wave, j, g, ct0, pz0, py0, px0);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -299,9 +559,15 @@ struct ConvLayer {  // logical description (torch semantics)
   bool relu = false;
 };
 
+struct ConvFuse {  // FeatureNet skip pair fused into the staging step of the layer that consumes it (device pointers)
+  const float *x, *w, *b, *coarse;
+  int cin;  // channels of x (8)
+};
+
 struct ConvLaunch {
   ConvArgs args;
-  int ci, ct, pt;
+  int ci, ct, pt, fz = 0;
+  int async = 0;  // 1: k_conv_a (persistent, LDS-DMA staged, 512 threads)
   dim3 grid;
   size_t lds_bytes;
   double flops;  // useful (algorithmic) flops of this launch
@@ -365,15 +631,26 @@ struct DeviceArena {  // owns small device buffers created while planning (weigh
 struct ConvTuned {
   int Cin, Cout, kd, kh, kw, sd, sh, sw, transposed, mode, inD, inH, inW;  // layer signature
   int ci, ct, pt, tz, ty, txt;                                              // plan: channel pass, row tiles, position tiles per wave, tile shape (txt in 16s)
+  int async_;                                                               // 1: the persistent LDS-DMA kernel (k_conv_a)
 };
 #include "conv_tuned.h"
 
 inline bool conv_instance_exists(int ci, int ct) {
   return (ci == 4 && ct == 1) || ((ci == 8 || ci == 16) && (ct == 1 || ct == 2 || ct == 4));
 }
+inline bool conv_a_instance_exists(int ci, int ct, int pt) {
+  return (pt == 2 || pt == 4) && ((ci == 4 && ct == 1) || ((ci == 8 || ci == 16) && (ct == 1 || ct == 2)));
+}
+inline size_t conv_a_slots(int np, int ci) { return (size_t)cdiv(((np + 1) & ~1) * (ci / 4), 512) * 512; }
+// which kernel family the planner may use: 0 = k_conv only, 1 = k_conv_a only (falls back to k_conv when no async plan
+// fits), 2 = both, ranked together.  DR_CONV_ASYNC overrides (A/B hook).
+inline int conv_async_policy() {
+  if (const char *e = getenv("DR_CONV_ASYNC")) return atoi(e);
+  return 2;
+}
 
 inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in, int inD, int inH, int inW, int inC,
-                             float *out, const float *add, int add_mode, DeviceArena &arena, int rank = 0) {
+                             float *out, const float *add, int add_mode, DeviceArena &arena, int rank = 0, const ConvFuse *fz = nullptr) {
   // rank: which candidate of the cost model's ranking to build (0 = its choice); used by the engine's autotuner
   if (L.Cin % 4 != 0 || inC < L.Cin) fail(DR_ERR_ARG, "plan_conv: Cin=%d must be a multiple of 4 (tensor C=%d)", L.Cin, inC);
   auto cz = axis_classes(L.kd, L.sd, L.transposed, inD);
@@ -432,11 +709,45 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
                                   {2, 4, 2}, {2, 8, 1}, {4, 1, 4}, {4, 2, 2}, {4, 4, 1}, {8, 1, 2}, {8, 2, 1}, {16, 1, 1}};
   static const int cand4[][3] = {{1, 1, 4}, {1, 2, 2}, {1, 4, 1}, {2, 1, 2}, {2, 2, 1}, {4, 1, 1}};
   [[maybe_unused]] double best = 1e300;
-  int CI = 0, PT = 0, CT = 0, TZ = 0, TY = 0, TXT = 0, TZI = 0, TYI = 0, TXI = 0;
-  struct Cand { double cost; int ci, pt, ct, tz, ty, txt, tzi, tyi, txi; };
+  int CI = 0, PT = 0, CT = 0, TZ = 0, TY = 0, TXT = 0, TZI = 0, TYI = 0, TXI = 0, ASYNC = 0;
+  struct Cand { double cost; int ci, pt, ct, tz, ty, txt, tzi, tyi, txi, async; };
   std::vector<Cand> cands;
+  const int policy = fz ? 0 : conv_async_policy();
+  if (policy >= 1 && ncls == 1) {  // k_conv_a: 8 waves, 8*pt position tiles per workgroup, two tile buffers
+    for (int ci : {16, 8, 4}) {
+      if (L.Cin % ci || (ci == 4 && L.Cin != 4)) continue;
+      const int npass = L.Cin / ci, tpc = 16 / ci, nu = cdiv(classes[0].ntaps, tpc);
+      if (npass > 2 && (npass & 1)) continue;  // weight buffers alternate with the pass parity
+      for (int pt : {2, 4})
+        for (int tz = 1; tz <= 8 * pt; tz *= 2)
+          for (int ty = 1; tz * ty <= 8 * pt; ty *= 2) {
+            const int txt = 8 * pt / (tz * ty);
+            if ((tz > 1 && tz / 2 >= nPD) || (ty > 1 && ty / 2 >= nPH) || (txt > 1 && (txt / 2) * 16 >= nPW)) continue;  // more than half of the tile outside
+            const int tzi = (tz - 1) * SZ + exz, tyi = (ty - 1) * SY + exy, txi = (txt * 16 - 1) * SX + exx;
+            if ((size_t)tzi * tyi * txi >= 65536) continue;
+            const double tiles = (double)cdiv(nPD, tz) * cdiv(nPH, ty) * cdiv(nPW, txt * 16);
+            for (int ct : {2, 1}) {
+              if (CTtot % ct || !conv_a_instance_exists(ci, ct, pt)) continue;
+              const size_t slots = conv_a_slots(tzi * tyi * txi, ci);
+              const size_t bytes = 2 * slots * 16 + (size_t)(npass > 1 ? 2 : 1) * nu * ct * 1024 + (size_t)nu * tpc * 4 + 64;
+              if (bytes > kConvMaxLds) continue;
+              const double wpc = bytes * 2 <= kConvMaxLds ? 2.0 : 1.0, split = CTtot / ct;
+              const double mfma_unit = nu * 4.0 * ct * pt * 32.0 * 2.0;  // cycles per SIMD: two waves of the workgroup share it
+              const double stage_unit = slots / 4.0;                    // ~64 B/clk/CU from L2
+              const double unit = wpc * std::max(mfma_unit, stage_unit) + 700.0;
+              // x 1.1: the two families' cost models are not calibrated against each other; an untuned shape only
+              // moves to the persistent kernel when its model says so with some margin
+              const double cost = 1.1 * std::ceil(tiles * split / (256.0 * wpc)) * npass * unit;
+              cands.push_back({cost, ci, pt, ct, tz, ty, txt, tzi, tyi, txi, 1});
+            }
+          }
+    }
+  }
+  const bool sync_too = policy != 1 || cands.empty();
   for (int ci : {16, 8, 4}) {
+    if (!sync_too) break;
     if (L.Cin % ci || (ci == 4 && L.Cin != 4)) continue;
+    if (fz && ci != 16) continue;  // fused-skip instances exist for 16-channel passes, one row tile
     const int npass = L.Cin / ci, tpc = 16 / ci;
     double chunks = 0;  // K chunks per pass summed over classes
     for (auto &c : classes) chunks += cdiv(c.ntaps, tpc);
@@ -450,7 +761,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
         for (auto &cc : classes) nu_max = std::max(nu_max, cdiv(cc.ntaps, tpc));
         const double tiles = (double)cdiv(nPD, c[0]) * cdiv(nPH, c[1]) * cdiv(nPW, c[2] * 16);
         for (int ct : {4, 2, 1}) {
-          if (CTtot % ct || !conv_instance_exists(ci, ct)) continue;
+          if (CTtot % ct || !conv_instance_exists(ci, ct) || (fz && ct != 1)) continue;
           const size_t bytes = (size_t)tzi * tyi * txi * (ci + 4) * 4 + (size_t)nu_max * ct * 1024 + (size_t)nu_max * tpc * 4 + 64;
           if (bytes > kConvMaxLds) continue;
           const int split = CTtot / ct;
@@ -464,7 +775,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
           const double waves = std::ceil(n_wg * ncls / (256.0 * wg_per_cu));
           const double thr = (mfma_total + stage_total) / 256.0 / (wg_per_cu >= 2 ? 0.8 : 0.5);
           const double cost = std::max(thr, waves * lat_wg);
-          cands.push_back({cost, ci, pt, ct, c[0], c[1], c[2], tzi, tyi, txi});
+          cands.push_back({cost, ci, pt, ct, c[0], c[1], c[2], tzi, tyi, txi, 0});
         }
       }
     }
@@ -477,13 +788,13 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
             t.transposed != (L.transposed ? 1 : 0) || t.mode != (int)mode || t.inD != inD || t.inH != inH || t.inW != inW) continue;
         for (size_t i = 0; i < cands.size(); ++i) {
           const Cand &k = cands[i];
-          if (k.ci == t.ci && k.ct == t.ct && k.pt == t.pt && k.tz == t.tz && k.ty == t.ty && k.txt == t.txt) { std::swap(cands[0], cands[i]); break; }
+          if (k.ci == t.ci && k.ct == t.ct && k.pt == t.pt && k.tz == t.tz && k.ty == t.ty && k.txt == t.txt && k.async == t.async_) { std::swap(cands[0], cands[i]); break; }
         }
         break;
       }
     }
     const Cand &k = cands[std::min<size_t>(rank < 0 ? 0 : rank, cands.size() - 1)];
-    best = k.cost; CI = k.ci; PT = k.pt; CT = k.ct; TZ = k.tz; TY = k.ty; TXT = k.txt; TZI = k.tzi; TYI = k.tyi; TXI = k.txi;
+    best = k.cost; CI = k.ci; PT = k.pt; CT = k.ct; TZ = k.tz; TY = k.ty; TXT = k.txt; TZI = k.tzi; TYI = k.tyi; TXI = k.txi; ASYNC = k.async;
     R.ncand = (int)cands.size();
   }
   if (!CI) fail(DR_ERR_ARG, "plan_conv: no kernel instance / tile shape for Cin=%d Cout=%d", L.Cin, L.Cout);
@@ -574,11 +885,28 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   a.addH = R.outH / 2; a.addW = (mode == CONV_NORMAL ? R.outW : outWv) / 2;
   a.tilesD = cdiv(nPD, TZ); a.tilesH = cdiv(nPH, TY); a.tilesW = cdiv(nPW, TXT * 16);
   cl.ci = CI; cl.ct = CT; cl.pt = PT;
+  a.fz_x = a.fz_w = a.fz_b = a.fz_coarse = nullptr;
+  if (fz) {
+    if (fz->cin != 8 || L.transposed || SZ != 1 || SY != 1) fail(DR_ERR_ARG, "plan_conv: fused skip needs an 8-channel source and a stride-1 layer");
+    a.fz_x = fz->x; a.fz_w = fz->w; a.fz_b = fz->b; a.fz_coarse = fz->coarse; cl.fz = fz->cin;
+  }
   cl.grid = dim3(8 * cdiv(a.tilesD * a.tilesH * a.tilesW, 8), ncls, CTtot / CT);
   int nu_max = 0;
   for (auto &c : cls) nu_max = std::max(nu_max, c.NU);
   a.nuMax = nu_max;
   cl.lds_bytes = (size_t)TZI * TYI * TXI * CIS * 4 + (size_t)nu_max * CT * 1024 + (size_t)nu_max * TPC * 4 + 64;
+  a.zero16 = nullptr; a.a_slots = 0; a.a_wbufs = 1;
+  if (ASYNC) {
+    cl.async = 1;
+    a.zero16 = arena.upload(std::vector<float>(4, 0.f));
+    a.a_slots = (int)conv_a_slots(TZI * TYI * TXI, CI);
+    a.a_wbufs = npass > 1 ? 2 : 1;
+    cl.lds_bytes = 2 * (size_t)a.a_slots * 16 + (size_t)a.a_wbufs * nu_max * CT * 1024 + (size_t)nu_max * TPC * 4 + 64;
+    const int ntiles = a.tilesD * a.tilesH * a.tilesW, split = CTtot / CT;
+    const int wpc = cl.lds_bytes * 2 <= kConvMaxLds ? 2 : 1;
+    const int want = std::max(1, std::min(ntiles, 256 * wpc / split));
+    cl.grid = dim3(8 * cdiv(want, 8), 1, split);
+  }
   cl.flops = flops;
   R.launches.push_back(cl);
   return R;
@@ -594,13 +922,40 @@ inline void conv_allow_big_lds(const void *fn, std::atomic<unsigned long long> &
   DR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvMaxLds));
   done.fetch_or(bit, std::memory_order_release);
 }
-template <int CI, int CT, int PT>
+template <int CI, int CT, int PT, int FZ = 0>
 inline void launch_conv_inst(const ConvLaunch &c, hipStream_t st) {
   static std::atomic<unsigned long long> done{0};  // bit d: set on device d
-  conv_allow_big_lds(reinterpret_cast<const void *>(&k_conv<CI, CT, PT>), done, c.lds_bytes);
-  hipLaunchKernelGGL((k_conv<CI, CT, PT>), c.grid, dim3(kConvThreads), c.lds_bytes, st, c.args);
+  conv_allow_big_lds(reinterpret_cast<const void *>(&k_conv<CI, CT, PT, FZ>), done, c.lds_bytes);
+  hipLaunchKernelGGL((k_conv<CI, CT, PT, FZ>), c.grid, dim3(kConvThreads), c.lds_bytes, st, c.args);
+}
+template <int CI, int CT, int PT>
+inline void launch_conv_a_inst(const ConvLaunch &c, hipStream_t st) {
+  static std::atomic<unsigned long long> done{0};
+  conv_allow_big_lds(reinterpret_cast<const void *>(&k_conv_a<CI, CT, PT>), done, c.lds_bytes);
+  hipLaunchKernelGGL((k_conv_a<CI, CT, PT>), c.grid, dim3(kConvAThreads), c.lds_bytes, st, c.args);
 }
 inline void launch_conv(const ConvLaunch &c, hipStream_t st) {
+  if (c.async) {
+#define DR_CONV_A_CASE(CI_, CT_)                                                \
+  if (c.ci == CI_ && c.ct == CT_) {                                             \
+    if (c.pt == 4) launch_conv_a_inst<CI_, CT_, 4>(c, st);                      \
+    else launch_conv_a_inst<CI_, CT_, 2>(c, st);                                \
+    return;                                                                     \
+  }
+    DR_CONV_A_CASE(4, 1)
+    DR_CONV_A_CASE(8, 1)
+    DR_CONV_A_CASE(8, 2)
+    DR_CONV_A_CASE(16, 1)
+    DR_CONV_A_CASE(16, 2)
+#undef DR_CONV_A_CASE
+    fail(DR_ERR_ARG, "launch_conv: no async instance CI=%d CT=%d PT=%d", c.ci, c.ct, c.pt);
+  }
+  if (c.fz) {
+    if (c.fz != 8 || c.ci != 16 || c.ct != 1) fail(DR_ERR_ARG, "launch_conv: no fused-skip instance FZ=%d CI=%d CT=%d", c.fz, c.ci, c.ct);
+    if (c.pt == 4) launch_conv_inst<16, 1, 4, 8>(c, st);
+    else launch_conv_inst<16, 1, 1, 8>(c, st);
+    return;
+  }
 #define DR_CONV_CASE(CI_, CT_)                                                  \
   if (c.ci == CI_ && c.ct == CT_) {                                             \
     if (c.pt == 4) launch_conv_inst<CI_, CT_, 4>(c, st);                        \

@@ -263,8 +263,9 @@ class MvsEngine {
     };
     double t_before = 0, t_after = 0;
     const bool print = getenv("DR_CONV_PRINT") != nullptr;
+    const char *only = getenv("DR_AUTOTUNE_ONLY");  // tuning hook: restrict to layers whose name contains this
     for (Op &o : ops_) {
-      if (o.kind != Op::CONV || !o.replan) continue;
+      if (o.kind != Op::CONV || !o.replan || (only && o.name.find(only) == std::string::npos)) continue;
       const float t0 = time_launch(o.conv);
       float best = t0;
       int best_rank = 0;
@@ -272,13 +273,17 @@ class MvsEngine {
       for (int r = 1; r < std::min(k, o.ncand); ++r) {
         const ConvLaunch c = o.replan(r);
         const float t = time_launch(c);
+        if (print && atoi(getenv("DR_CONV_PRINT")) > 1)
+          fprintf(stderr, "  cand %-12s rank %2d %s<%d,%d,%d> tile %dx%dx%d lds %zu KB grid %u: %.4f ms\n", o.name.c_str(), r, c.async ? "async" : "", c.ci, c.ct, c.pt,
+                  c.args.TZ, c.args.TY, c.args.TXT * 16, c.lds_bytes >> 10, c.grid.x, t);
         if (t < best * 0.98f) { best = t; best_rank = r; best_c = c; }
       }
-      if (print) fprintf(stderr, "autotune %-12s model %.4f ms <%d,%d,%d> -> rank %d %.4f ms <%d,%d,%d> tile %dx%dx%d\n", o.name.c_str(), t0, o.conv.ci, o.conv.ct,
-                         o.conv.pt, best_rank, best, best_c.ci, best_c.ct, best_c.pt, best_c.args.TZ, best_c.args.TY, best_c.args.TXT * 16);
+      if (print) fprintf(stderr, "autotune %-12s model %.4f ms %s<%d,%d,%d> tile %dx%dx%d -> rank %d %.4f ms %s<%d,%d,%d> tile %dx%dx%d\n", o.name.c_str(), t0,
+                         o.conv.async ? "async" : "", o.conv.ci, o.conv.ct, o.conv.pt, o.conv.args.TZ, o.conv.args.TY, o.conv.args.TXT * 16, best_rank, best,
+                         best_c.async ? "async" : "", best_c.ci, best_c.ct, best_c.pt, best_c.args.TZ, best_c.args.TY, best_c.args.TXT * 16);
       if (print && best_rank != 0)
-        fprintf(stderr, "TUNED    {%s,   %d, %d, %d, %d, %d, %d},  // %s %.4f -> %.4f ms\n", o.sig.c_str(), best_c.ci, best_c.ct, best_c.pt, best_c.args.TZ,
-                best_c.args.TY, best_c.args.TXT, o.name.c_str(), t0, best);
+        fprintf(stderr, "TUNED    {%s,   %d, %d, %d, %d, %d, %d, %d},  // %s %.4f -> %.4f ms\n", o.sig.c_str(), best_c.ci, best_c.ct, best_c.pt, best_c.args.TZ,
+                best_c.args.TY, best_c.args.TXT, best_c.async, o.name.c_str(), t0, best);
       o.conv = best_c;
       t_before += t0; t_after += best;
     }
@@ -380,7 +385,9 @@ class MvsEngine {
       ms.push_back(t);
       const Op &o = ops_[i];
       char kn[64] = "misc";
-      if (o.kind == Op::CONV) snprintf(kn, sizeof kn, "k_conv<%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt);
+      if (o.kind == Op::CONV && o.conv.async) snprintf(kn, sizeof kn, "k_conv_a<%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt);
+      else if (o.kind == Op::CONV && o.conv.fz) snprintf(kn, sizeof kn, "k_conv<%d,%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt, o.conv.fz);
+      else if (o.kind == Op::CONV) snprintf(kn, sizeof kn, "k_conv<%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt);
       else if (o.kind == Op::COSTVOL) snprintf(kn, sizeof kn, "k_costvol<%d>", 32 >> (o.stage - 1));
       else if (o.kind == Op::PROB) snprintf(kn, sizeof kn, "k_prob");
       else if (o.kind == Op::REGRESS) snprintf(kn, sizeof kn, "k_regress");
@@ -491,7 +498,7 @@ class MvsEngine {
   // Adds one convolution layer (possibly several launches) to the plan; returns the output tensor.
   DevTensor &add_conv(const std::string &opname, const std::string &wname, const std::string &bnname, bool conv_bias, bool relu,
                       const DevTensor &in, const std::string &outname, int k3d, int kh, int kw, int sd, int sh, int sw,
-                      bool transposed, ConvMode mode, const DevTensor *add, int add_mode) {
+                      bool transposed, ConvMode mode, const DevTensor *add, int add_mode, const ConvFuse *fz = nullptr) {
     const HostTensor &w = blob_.at(wname + ".weight");
     ConvLayer L;
     L.transposed = transposed;
@@ -515,16 +522,19 @@ class MvsEngine {
       P0.outD = transposed ? in.D * sd : cz[0].npos; P0.outH = transposed ? in.H * sh : cy[0].npos; P0.outW = transposed ? in.W * sw : cx[0].npos;
     }
     DevTensor &out = alloc(outname, P0.outD, P0.outH, P0.outW, c_out);
-    ConvPlanOut P = plan_conv(L, mode, in.d, in.D, in.H, in.W, in.C, out.d, add ? add->d : nullptr, add_mode, *plan_arena_);
+    ConvFuse fzc{};
+    if (fz) fzc = *fz;
+    const bool fused = fz != nullptr;
+    ConvPlanOut P = plan_conv(L, mode, in.d, in.D, in.H, in.W, in.C, out.d, add ? add->d : nullptr, add_mode, *plan_arena_, 0, fz);
     // the autotuner re-plans this layer with another candidate of the cost model's ranking (weights are kept alive)
     auto keep = std::make_shared<std::vector<float>>(L.weight, L.weight + (size_t)L.Cout * L.Cin * k3d * kh * kw);
     ConvLayer Lc = L;
     const float *in_d = in.d, *add_d = add ? add->d : nullptr;
     float *out_d = out.d;
     const int iD = in.D, iH = in.H, iW = in.W, iC = in.C, ncand = P.ncand;
-    auto replan = [this, keep, Lc, mode, in_d, iD, iH, iW, iC, out_d, add_d, add_mode](int rank) mutable {
+    auto replan = [this, keep, Lc, mode, in_d, iD, iH, iW, iC, out_d, add_d, add_mode, fzc, fused](int rank) mutable {
       Lc.weight = keep->data();
-      return plan_conv(Lc, mode, in_d, iD, iH, iW, iC, out_d, add_d, add_mode, *plan_arena_, rank).launches.at(0);
+      return plan_conv(Lc, mode, in_d, iD, iH, iW, iC, out_d, add_d, add_mode, *plan_arena_, rank, fused ? &fzc : nullptr).launches.at(0);
     };
     int idx = 0;
     for (auto &cl : P.launches) {
@@ -532,11 +542,12 @@ class MvsEngine {
       if (P.launches.size() == 1) {
         o.replan = replan; o.ncand = ncand;
         char sig[160];
-        snprintf(sig, sizeof sig, "%d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d", L.Cin, L.Cout, k3d, kh, kw, sd, sh, sw, transposed ? 1 : 0, (int)mode, iD, iH, iW);
+        snprintf(sig, sizeof sig, "%d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d", L.Cin, L.Cout, k3d, kh, kw, sd, sh, sw, transposed ? 1 : 0, (int)mode + (fused ? 8 : 0), iD, iH, iW);
         o.sig = sig;
       }
       o.flops = cl.flops;
-      if (idx == 0) o.bytes = 4.0 * (in.n() + out.n() + (add ? (add_mode == 2 ? add->n() : out.n()) : 0));
+      if (idx == 0) o.bytes = 4.0 * ((fused ? in.n() / in.C * fzc.cin + in.n() / 4 : in.n()) + out.n() + (add ? (add_mode == 2 ? add->n() : out.n()) : 0));
+      if (fused) o.flops += 2.0 * fzc.cin * in.C * (in.n() / in.C);
       ops_.push_back(o);
       ++idx;
     }
@@ -597,8 +608,18 @@ class MvsEngine {
     DevTensor &i2 = add_skip("fn.skip2", fn + "skip.stage2", c2, "inter2", c1);
     add_conv("fn.out2", fn + "out.stage2", "", false, false, i2, "feat2", 1, 3, 3, 1, 1, 1, false, CONV_NORMAL, nullptr, 0);
     feat2_op_ = ops_.size() - 1;
-    DevTensor &i3 = add_skip("fn.skip3", fn + "skip.stage3", c3, "inter3", i2);
-    add_conv("fn.out3", fn + "out.stage3", "", false, false, i3, "feat3", 1, 3, 3, 1, 1, 1, false, CONV_XPAIR, nullptr, 0);
+    // stage 3: skip.stage3 (1x1, 8 -> 32, + upsampled inter2) is computed inside out.stage3's staging step -- the
+    // 32-channel full-resolution tensor between them (275 MB at 640x480x7) is never written or read.  DR_NO_SKIP_FUSION=1: the two-kernel path.
+    const HostTensor &w3 = blob_.at(fn + "skip.stage3.weight");
+    if (!getenv("DR_NO_SKIP_FUSION") && !getenv("DR_SKIP_ON_CONV") && w3.dims[0] == 32 && w3.dims[1] == 8 && c3.C == 8 && i2.C == 32 &&
+        i2.H * 2 == c3.H && i2.W * 2 == c3.W) {
+      ConvFuse fz{c3.d, plan_arena_->upload(w3.data), plan_arena_->upload(blob_.at(fn + "skip.stage3.bias").data), i2.d, 8};
+      DevTensor virt; virt.D = c3.D; virt.H = c3.H; virt.W = c3.W; virt.C = 32; virt.d = nullptr;  // inter3 exists in LDS only
+      add_conv("fn.out3", fn + "out.stage3", "", false, false, virt, "feat3", 1, 3, 3, 1, 1, 1, false, CONV_XPAIR, nullptr, 0, &fz);
+    } else {
+      DevTensor &i3 = add_skip("fn.skip3", fn + "skip.stage3", c3, "inter3", i2);
+      add_conv("fn.out3", fn + "out.stage3", "", false, false, i3, "feat3", 1, 3, 3, 1, 1, 1, false, CONV_XPAIR, nullptr, 0);
+    }
     fork_hi_ = ops_.size();
 
     for (int s = 1; s <= 3; ++s) {

@@ -275,3 +275,25 @@ def test_autotuned_plan_stays_within_tolerance(trained_blob):
     m.forward(1)
     compare(m.download(), ref, "autotuned")
     m.close()
+
+
+def test_fused_skip_equals_the_two_kernel_path(trained_blob, monkeypatch):
+    """FeatureNet stage 3 (module.py:524-529): skip.stage3 + upsample computed inside out.stage3's staging step gives
+    bit-for-bit what k_skip_up followed by the plain convolution gives (a second shape with partial tiles)."""
+    from oracle import scene
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    outs = []
+    for unfused in (False, True):
+        if unfused:
+            monkeypatch.setenv("DR_NO_SKIP_FUSION", "1")
+        m = DrMvsnet(trained_blob)
+        res = []
+        for (h, w, v) in ((64, 96, 3), (96, 160, 4)):
+            win = scene.make_window(h, w, v, seed=5)
+            m.CallAsync(h, w, v, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), 0.5, 5.0, 2.5)
+            res.append(m.GetResult())
+        outs.append(res)
+        m.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a.depth_dense, b.depth_dense) and np.array_equal(a.confidence_dense, b.confidence_dense)
+        assert np.array_equal(a.depth, b.depth) and np.array_equal(a.confidence, b.confidence)

@@ -2,7 +2,7 @@
 # mid-round check: whole -m gpu suite, smoke, the bench line (reduced sizes)
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider 2>&1 | tail -8 > gpurun_out/r2_gpu_tests.log; cat gpurun_out/r2_gpu_tests.log
+timeout 1500 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider --durations=8 > gpurun_out/r2_gpu_tests_full.log 2>&1; grep -E "passed|failed|^FAILED|^ERROR|s call" gpurun_out/r2_gpu_tests_full.log | tail -14
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 timeout 900 python bench.py --steps 150 --warmup 5 --tsdf-frames 400 --loop-keyframes 40 > gpurun_out/r2_bench_try.json 2> gpurun_out/r2_bench_try.err
 echo "bench rc=$?"; tail -3 gpurun_out/r2_bench_try.err
