@@ -67,7 +67,25 @@ def host_cores():
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA (== fp32 vector) peak
 PEAK_HBM_GBPS = 8000.0          # HBM3E spec peak (6.3 TB/s measured achievable)
 H, W, V = 480, 640, 7
+PLANES = (48, 32, 8)
 DISCARD = 10.0                  # TANDEM's mvsnet_discard_percentage default (settings.cpp:300)
+
+
+_BLOB = {}
+
+
+def model_blob():
+    """Weights blob of the configured model: the committed trained weights, with the hypothesis counts of --config."""
+    if PLANES not in _BLOB:
+        blob = os.path.join(ROOT, "weights", "tandem_va.tdmw")
+        if PLANES != (48, 32, 8):  # --config shipped: same weights, the shipped model's hypothesis counts
+            import tempfile
+            from tandem_amd import weights as Wt
+            _, tens = Wt.read_blob(blob)
+            blob = os.path.join(tempfile.mkdtemp(), "w_%d_%d_%d.tdmw" % PLANES)
+            Wt.write_blob(blob, tens, depth_num=PLANES)
+        _BLOB[PLANES] = blob
+    return _BLOB[PLANES]
 
 
 def mvsnet_leg(args, rank, dev, world):
@@ -76,7 +94,7 @@ def mvsnet_leg(args, rank, dev, world):
     from tandem_amd import replicas
     from tandem_amd.dr_mvsnet import DrMvsnet
     import threading
-    blob = os.path.join(ROOT, "weights", "tandem_va.tdmw")
+    blob = model_blob()
     # E independent DrMvsnet engines per GPU (each its own stream, worker and keyframe window): the launches of
     # different windows overlap, which fills the CUs during the many small kernels of the coarse UNet levels
     # (measured: 275 -> 338 -> 366 depth-maps/s for E = 1, 2, 3).  E = 1 is the single-window latency configuration.
@@ -154,7 +172,7 @@ def mvsnet_cpu_baseline(win, blob):
     if os.path.isdir("/root/reference/cva_mvsnet"):
         try:
             from oracle import mvsnet_oracle as O, ref_model
-            net, cva = ref_model.build((48, 32, 8), tens, view_aggregation=True)
+            net, cva = ref_model.build(PLANES, tens, view_aggregation=True)
             image, Ks, c2w = O.preprocess(win["bgrs"], win["K"], win["c2ws"], win["ref_index"])
             run = lambda: ref_model.run(net, cva, image, Ks, c2w, win["depth_min"], win["depth_max"], DISCARD)
             kind = "reference"
@@ -170,8 +188,8 @@ def mvsnet_cpu_baseline(win, blob):
         t0 = time.perf_counter(); run(); times.append(time.perf_counter() - t0)
     med = sorted(times)[len(times) // 2]
     return dict(value=1.0 / med, unit="depth-maps/s", cores=torch.get_num_threads(), physical_cores=phys, logical_cpus=logical, kind=kind,
-                sample="%d timed forwards of the same 640x480x7-view (48,32,8) window after 1 warm-up, torch CPU fp32, %d threads; median %.2f s, best %.2f s"
-                       % (len(times), torch.get_num_threads(), med, min(times)))
+                sample="%d timed forwards of the same %dx%dx7-view (%d,%d,%d) window after 1 warm-up, torch CPU fp32, %d threads; median %.2f s, best %.2f s"
+                       % ((len(times), W, H) + PLANES + (torch.get_num_threads(), med, min(times))))
 
 
 def shipped_leg(args, dev):
@@ -221,7 +239,7 @@ def boundary_leg(args, dev):
     import threading
     from oracle import scene
     from tandem_amd.dr_mvsnet import DrMvsnet
-    blob = os.path.join(ROOT, "weights", "tandem_va.tdmw")
+    blob = model_blob()
     out = {}
     per = max(10, min(60, args.steps // 3))
     for E in (1, 3):
@@ -414,7 +432,7 @@ def view_shard_leg(args, rank, dev, world):
     win = scene.make_window(H, W, V, seed=0)  # the SAME window on every rank
     window = dict(bgrs=win["bgrs"], K=win["K"], c2ws=list(win["c2ws"]), ref_index=win["ref_index"],
                   depth_min=win["depth_min"], depth_max=win["depth_max"], discard=DISCARD)
-    m = DrMvsnet(os.path.join(ROOT, "weights", "tandem_va.tdmw"), device=dev)
+    m = DrMvsnet(model_blob(), device=dev)
     mine = view_shard.upload(m, window, rank, world)
     one_dev = os.environ.get("DR_BENCH_ONE_DEVICE") == "1"  # test scaffold: RCCL refuses two ranks on one device
     if not one_dev:
@@ -489,7 +507,13 @@ def main():
     ap.add_argument("--engines", type=int, default=3, help="DrMvsnet engines (independent windows in flight) per GPU; 1 = latency configuration")
     ap.add_argument("--no-tsdf", action="store_true")
     ap.add_argument("--no-view-shard", action="store_true", help="N > 1 only: skip the view-sharded (configs[2]) leg")
+    ap.add_argument("--config", choices=["headline", "shipped"], default="headline",
+                    help="headline: BASELINE.json's metric configuration, 640x480x7 views, planes (48,32,8).  shipped: the model TANDEM exports and runs "
+                         "(tandem_512x320: 320x512x7 views, planes (48,4,4)); every leg of the line (value, roofline, cpu_baseline, boundary) is then on that shape")
     args = ap.parse_args()
+    if args.config == "shipped":
+        global H, W, PLANES
+        H, W, PLANES = 320, 512, (48, 4, 4)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn_under_torchrun(args)
@@ -519,14 +543,14 @@ def main():
         vs = view_shard_leg(args, rank, local_rank, world)
     if rank == 0:
         out = {
-            "metric": "depth-maps/sec @ 640x480x7-view x3-stage; TSDF voxels integrated/sec",
+            "metric": "depth-maps/sec @ %dx%dx7-view x3-stage; TSDF voxels integrated/sec" % (W, H),
             "value": mv["value"], "unit": "depth-maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": mv["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "640x480 ref+6-src keyframe window, 3-stage cascade (48/32/8 hypotheses), view aggregation, fp32; "
+            "config": {"workload": ("%dx%d ref+6-src keyframe window, 3-stage cascade (%d/%d/%d hypotheses), view aggregation, fp32; " % ((W, H) + PLANES)) +
                                    "independent windows, %d in flight per GPU (one DrMvsnet engine each) x %d GPU replica(s); trained weights recovered from the reference's exported "
                                    "tandem_512x320 model (same architecture), inputs resident in HBM" % (mv["engines_per_gpu"], world),
-                       "height": H, "width": W, "views": V, "planes": [48, 32, 8], "discard_percentage": DISCARD,
+                       "height": H, "width": W, "views": V, "planes": list(PLANES), "discard_percentage": DISCARD, "name": args.config,
                        "parallelism": "replicas x%d, %d engines per GPU" % (world, mv["engines_per_gpu"]),
                        "reference_published": "2.70 FPS (abl03, unstated GPU, incl. data loading) -- not the same clock, so vs_baseline is null"},
             "event_ms_per_step": mv["event_ms_per_step"],
