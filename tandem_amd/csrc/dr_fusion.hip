@@ -40,6 +40,8 @@ struct Voxel {  // tsdfvh/voxel.h:13-19 -- 8 bytes
 };
 static_assert(sizeof(Voxel) == 8, "voxel layout");
 
+struct PixRec { float dep, sd; unsigned col; };  // written by k_allocate (one lane per pixel), read by k_integrate
+
 struct FusionDev {  // everything the kernels need, passed by value
   drf_options_t o;
   unsigned long long *keys;  // [cap] packed block coordinate or kEmptyKey
@@ -51,6 +53,8 @@ struct FusionDev {  // everything the kernels need, passed by value
   int *err;                  // [0] pool exhausted, [1] coordinate out of packing range
   unsigned long long *cnt;   // [0] voxels updated by the current scan, [1] total, [2] round-trip mismatches
   float *sd;                 // [H*W] per-pixel surface distance |GetPoint3d(i, depth)| of the current scan
+  unsigned char *super[2];   // per level: 1 = some block of this superblock of the dense grid is allocated (ray-cast empty-space skip)
+  PixRec *pix;               // [H*W] {depth, surface distance, packed BGR} of the current scan: ONE gather per voxel in k_integrate
   unsigned *present;         // kPresentBits^3-bit map: bit set <=> that block is allocated (a cache of `grid`, no state)
   // Dense direct-mapped block index for the block coordinates [-256, 256)^3 (+-10 m at 5 mm voxels, +-20 m at 1 cm): one
   // int per cell, 512 MiB of the 288 GB -- 0 = absent, -1 = requested by the allocation pass of the current scan,
@@ -166,6 +170,17 @@ __device__ inline bool grid_index(I3 p, unsigned &idx) {  // dense region [-256,
   idx = (x << (2 * kGridBits)) | (y << kGridBits) | z;
   return true;
 }
+// Occupancy of the dense grid at two coarser levels, for the ray-caster's empty-space skip: a "superblock" of level L is
+// a cube of (1 << kSuperShift[L])^3 blocks; super[L][i] = 1 as soon as any block inside it is allocated.
+// Level 0: 32^3 blocks (1.28 m at 5 mm voxels, 4 KiB of flags), level 1: 8^3 blocks (0.32 m, 256 KiB).
+constexpr int kSuperLevels = 2;
+constexpr int kSuperShift[kSuperLevels] = {5, 3};
+template <int SH>
+__device__ inline unsigned super_index(unsigned idx) {
+  constexpr unsigned M = (1u << kGridBits) - 1;
+  const unsigned x = idx >> (2 * kGridBits), y = (idx >> kGridBits) & M, z = idx & M;
+  return ((x >> SH) << (2 * (kGridBits - SH))) | ((y >> SH) << (kGridBits - SH)) | (z >> SH);
+}
 __device__ inline int find_block_table(const FusionDev &d, I3 p) {  // blocks outside the dense region
   unsigned long long key;
   if (!pack_key(p, key)) return -1;
@@ -268,6 +283,8 @@ __global__ __launch_bounds__(256) void k_alloc_commit(const FusionDev d) {
     d.blk_key[p] = key;
     d.grid[idx] = p + 1;
     atomicOr(&d.present[idx >> 5], 1u << (idx & 31));
+    d.super[0][super_index<kSuperShift[0]>(idx)] = 1;  // plain stores: every writer writes the same value
+    d.super[1][super_index<kSuperShift[1]>(idx)] = 1;
   }
 }
 
@@ -290,7 +307,7 @@ __device__ inline void world_to_block_local(const drf_options_t &o, F3 p, I3 &bl
 }
 
 // ------------------------------------------------------------------ allocation
-__global__ __launch_bounds__(256) void k_allocate(const FusionDev d, const float *__restrict__ depth, const Mat T) {
+__global__ __launch_bounds__(256) void k_allocate(const FusionDev d, const unsigned char *__restrict__ bgr, const float *__restrict__ depth, const Mat T) {
   const drf_options_t &o = d.o;
   const int size = o.height * o.width;
   const float trunc = o.truncation_distance;
@@ -304,7 +321,13 @@ __global__ __launch_bounds__(256) void k_allocate(const FusionDev d, const float
     const float dep = live ? depth[i] : 0.0f;
     // IntegrateScanKernel recomputes distance(0, GetPoint3d(idx, depth[idx])) for every voxel that projects to
     // pixel idx (tsdf_volume.cu:485-486); it depends on the pixel only, so it is evaluated once here.
-    if (live) d.sd[i] = norm3(point3d(o, i, dep));
+    if (live) {
+      const float sdist = norm3(point3d(o, i, dep));
+      d.sd[i] = sdist;
+      PixRec r; r.dep = dep; r.sd = sdist;
+      r.col = (unsigned)bgr[3 * i] | ((unsigned)bgr[3 * i + 1] << 8) | ((unsigned)bgr[3 * i + 2] << 16);
+      d.pix[i] = r;
+    }
     if (dep < o.min_sensor_depth || dep > o.max_sensor_depth) live = false;
     const F3 point = xform(T, point3d(o, live ? i : 0, dep));
     if (point.x == 0 && point.y == 0 && point.z == 0) live = false;
@@ -433,22 +456,61 @@ __global__ __launch_bounds__(256) void k_cull(const FusionDev d, const Mat Ti) {
   }
 }
 
+// A voxel is 8 bytes at an 8-byte-aligned address, but `Voxel` itself only promises the alignment of its float: read as a
+// struct it becomes a dword load plus a byte load per field (18 gathers per ray-cast sample).  One 64-bit load instead,
+// and one 128-bit load for two voxels that are neighbours in z.
+struct alignas(8) Voxel8 { unsigned lo, hi; };
+struct __attribute__((packed, aligned(8))) Voxel16 { unsigned a, b, c, d; };
+__device__ inline Voxel unpack_voxel(unsigned lo, unsigned hi) {
+  Voxel v;
+  v.sdf = __uint_as_float(lo);
+  v.c[0] = (unsigned char)(hi & 255u); v.c[1] = (unsigned char)((hi >> 8) & 255u); v.c[2] = (unsigned char)((hi >> 16) & 255u);
+  v.weight = (unsigned char)(hi >> 24);
+  return v;
+}
+__device__ inline Voxel load_voxel(const Voxel *p) {
+  const Voxel8 t = *reinterpret_cast<const Voxel8 *>(p);
+  return unpack_voxel(t.lo, t.hi);
+}
+
 // One WAVE per VISIBLE block (k_cull's list).
-__global__ __launch_bounds__(256) void k_integrate(const FusionDev d, const unsigned char *__restrict__ bgr,
+#ifndef DR_INTEGRATE_WAVES
+#define DR_INTEGRATE_WAVES 1
+#endif
+__global__ __launch_bounds__(256, DR_INTEGRATE_WAVES) void k_integrate(const FusionDev d, const unsigned char *__restrict__ bgr,
                                                    const float *__restrict__ depth, const Mat T, const Mat Ti) {
   const drf_options_t &o = d.o;
   constexpr int bs = kBS;
   const float vs = o.voxel_size, trunc = o.truncation_distance, inv_vs = 1.0f / o.voxel_size;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int by = lane >> 3, bz = lane & 7;
   unsigned upd = 0;
   const int n_vis = *d.vis_count;
-  for (int iv = blockIdx.x * 4 + wave; iv < n_vis; iv += gridDim.x * 4) {
-    const int e = d.vis[iv];
-    const I3 P = unpack_key(d.blk_key[e]);
+  // The block of iteration i is named by two dependent look-ups (vis[] -> blk_key[]).  Both are wave-uniform (scalar
+  // loads) and fetched ahead -- the list entry two blocks ahead, the key one block ahead -- so that no iteration starts
+  // with a round trip to L2 before it can issue its voxel loads.
+  const int stride = gridDim.x * 4;
+  int iv = blockIdx.x * 4 + wave;
+  int e_next = iv < n_vis ? d.vis[iv] : 0;
+  int e_next2 = iv + stride < n_vis ? d.vis[iv + stride] : 0;
+  unsigned long long key_next = d.blk_key[e_next];
+  for (; iv < n_vis; iv += stride) {
+    const int e = e_next;
+    const I3 P = unpack_key(key_next);
+    e_next = e_next2;
+    key_next = d.blk_key[e_next];
+    e_next2 = iv + 2 * stride < n_vis ? d.vis[iv + 2 * stride] : 0;
     F3 position; position.x = P.x * vs * bs; position.y = P.y * vs * bs; position.z = P.z * vs * bs;
     const F3 pc = xform(Ti, position);
     Voxel *blk_vox = d.vox + (size_t)e * (bs * bs * bs);
+    // the block's 4 KB first: these are the loads that go to HBM, and nothing below depends on them until the combine --
+    // the corner test, 8 projections and 8 pixel gathers run under their latency (sched_barrier: hipcc otherwise sinks
+    // them behind the gathers).  Requesting the NEXT block's 4 KB here as well (two blocks per wave in flight, 121 VGPRs)
+    // measured 8 % slower: after the changes above the kernel is bound by vector-ALU issue, not by latency.
+    Voxel cur8[bs];
+#pragma unroll
+    for (int bx = 0; bx < bs; ++bx) cur8[bx] = load_voxel(blk_vox + bx * (bs * bs) + lane);
+    __builtin_amdgcn_sched_barrier(0);
     // UpdateVoxel's world -> cam -> world round trip (below) is, per voxel, the map  vp -> T*(Ti*vp)  = an affine map
     // plus fp32 rounding noise (< 1e-4 m for |coordinates| < 64 m).  An affine deviation is extremal at the corners of
     // the block's voxel lattice, so if its 8 corner voxels come back within 0.1 voxel of themselves, every voxel of the
@@ -471,7 +533,6 @@ __global__ __launch_bounds__(256) void k_integrate(const FusionDev d, const unsi
       F3 vpc[bs];
       int pix[bs];
       float dep8[bs], sd8[bs];
-      Voxel cur8[bs];
       unsigned col8[bs];
 #pragma unroll
       for (int bx = 0; bx < bs; ++bx) {
@@ -482,10 +543,8 @@ __global__ __launch_bounds__(256) void k_integrate(const FusionDev d, const unsi
         const bool inb = ix >= 0 && iy >= 0 && ix < o.width && iy < o.height;
         pix[bx] = inb ? iy * o.width + ix : -1;
         const int idx = inb ? pix[bx] : 0;
-        dep8[bx] = depth[idx];
-        sd8[bx] = d.sd[idx];
-        col8[bx] = (unsigned)bgr[3 * idx] | ((unsigned)bgr[3 * idx + 1] << 8) | ((unsigned)bgr[3 * idx + 2] << 16);
-        cur8[bx] = blk_vox[bx * (bs * bs) + lane];
+        const PixRec r = d.pix[idx];  // depth[idx], d.sd[idx], bgr[3 idx ..] in one 12-byte gather
+        dep8[bx] = r.dep; sd8[bx] = r.sd; col8[bx] = r.col;
       }
 #pragma unroll
       for (int bx = 0; bx < bs; ++bx) {
@@ -664,25 +723,8 @@ __device__ inline int find_block_xyz(const FusionDev &d, int x, int y, int z, bo
   return -1;
 }
 
-// A voxel is 8 bytes at an 8-byte-aligned address, but `Voxel` itself only promises the alignment of its float: read as a
-// struct it becomes a dword load plus a byte load per field (18 gathers per ray-cast sample).  One 64-bit load instead,
-// and one 128-bit load for two voxels that are neighbours in z.
-struct alignas(8) Voxel8 { unsigned lo, hi; };
-struct __attribute__((packed, aligned(8))) Voxel16 { unsigned a, b, c, d; };
-__device__ inline Voxel unpack_voxel(unsigned lo, unsigned hi) {
-  Voxel v;
-  v.sdf = __uint_as_float(lo);
-  v.c[0] = (unsigned char)(hi & 255u); v.c[1] = (unsigned char)((hi >> 8) & 255u); v.c[2] = (unsigned char)((hi >> 16) & 255u);
-  v.weight = (unsigned char)(hi >> 24);
-  return v;
-}
-__device__ inline Voxel load_voxel(const Voxel *p) {
-  const Voxel8 t = *reinterpret_cast<const Voxel8 *>(p);
-  return unpack_voxel(t.lo, t.hi);
-}
-
 template <bool FAST, bool COLOUR>
-__device__ inline Voxel interp_voxel(const FusionDev &d, F3 pos, bool far_blocks, bool &bail) {  // == get_interpolated_voxel(d, pos), tsdf_volume.cu:161-289
+__device__ inline Voxel interp_voxel(const FusionDev &d, F3 pos, bool far_blocks, bool &bail, int *empty_cell = nullptr) {  // == get_interpolated_voxel(d, pos), tsdf_volume.cu:161-289
   const float vs = d.o.voxel_size, hv = vs / 2.0f, y = d.vs_rcp;
   Voxel zero; zero.sdf = 0.f; zero.c[0] = zero.c[1] = zero.c[2] = 0; zero.weight = 0;
   // GetVoxel(position): WorldToGlobalVoxel (tsdf_volume.cu:109-113), then block = floor(g / 8), local = g mod 8
@@ -690,6 +732,11 @@ __device__ inline Voxel interp_voxel(const FusionDev &d, F3 pos, bool far_blocks
   const int g0x = f2i(qx + signf_(pos.x) * 0.5f), g0y = f2i(qy + signf_(pos.y) * 0.5f), g0z = f2i(qz + signf_(pos.z) * 0.5f);
   const int c0x = g0x >> 3, c0y = g0y >> 3, c0z = g0z >> 3;
   const int b0 = find_block_xyz(d, c0x, c0y, c0z, far_blocks, bail);
+  if (empty_cell) {  // dense-grid cell of the centre voxel's block when that block does not exist (else -1)
+    I3 c; c.x = c0x; c.y = c0y; c.z = c0z;
+    unsigned ci;
+    *empty_cell = (b0 < 0 && grid_index(c, ci)) ? (int)ci : -1;
+  }
   Voxel v0 = zero;
   if (b0 >= 0) v0 = load_voxel(d.vox + (size_t)b0 * 512 + (((g0x & 7) << 6) | ((g0y & 7) << 3) | (g0z & 7)));
   if (v0.weight == 0) return v0;
@@ -759,6 +806,23 @@ __device__ inline Voxel interp_voxel(const FusionDev &d, F3 pos, bool far_blocks
 }
 // Pixels are flagged for the literal pass (k_raycast_fix) with depth -1 when a sample leaves the range div_exact was
 // verified on, or needs a block outside the dense grid while the table is not empty.  Neither happens in a room-sized map.
+// How many further samples q + j * trunc * dir (j = 1..k) stay inside the superblock of `cell`, shrunk by one voxel on
+// every side.  Approximate float arithmetic on purpose: it only has to be conservative (the margin is 5 mm against
+// errors of ~1e-5 m), the samples' own positions are never used.
+template <int SH>
+__device__ inline int skip_steps(unsigned cell, F3 q, F3 dirw, F3 inv_dir, float vs, float inv_trunc) {
+  constexpr int H = 1 << (kGridBits - 1);
+  constexpr unsigned M = (1u << kGridBits) - 1, SM = ~((1u << SH) - 1u);
+  constexpr float hi_off = (float)(kBS << SH) - 1.5f;  // the superblock's n = 8 << SH voxels cover [(g - 0.5) vs, (g + n - 0.5) vs)
+  const float gx = (float)((int)(((cell >> (2 * kGridBits)) & SM) - H) * kBS);
+  const float gy = (float)((int)((((cell >> kGridBits) & M) & SM) - H) * kBS);
+  const float gz = (float)((int)(((cell & M) & SM) - H) * kBS);
+  float t = 1e30f;
+  if (dirw.x != 0.f) t = fminf(t, ((gx + (dirw.x > 0.f ? hi_off : 0.5f)) * vs - q.x) * inv_dir.x);
+  if (dirw.y != 0.f) t = fminf(t, ((gy + (dirw.y > 0.f ? hi_off : 0.5f)) * vs - q.y) * inv_dir.y);
+  if (dirw.z != 0.f) t = fminf(t, ((gz + (dirw.z > 0.f ? hi_off : 0.5f)) * vs - q.z) * inv_dir.z);
+  return (int)fminf(t * inv_trunc - 0.5f, 256.f);
+}
 template <bool FAST>
 __global__ __launch_bounds__(64) void k_raycast2(const FusionDev d, const Mat pose, unsigned char *__restrict__ bgr,
                                                  float *__restrict__ depth_out, int *__restrict__ n_flagged) {
@@ -793,11 +857,36 @@ __global__ __launch_bounds__(64) void k_raycast2(const FusionDev d, const Mat po
       if (FAST && !(in_fast_range(q.x) && in_fast_range(q.y) && in_fast_range(q.z) && in_fast_range(tx) && in_fast_range(ty))) bail = true;
       return q;
     };
+    // Empty-space skip.  A sample whose centre voxel lies in a block that does not exist returns weight 0 and the ray
+    // advances by the truncation distance (2 cm at TANDEM's settings: ~150 look-ups across a room).  d.super[] marks the
+    // superblocks (32^3 and 8^3 blocks) of the dense grid that hold any block at all; while the ray stays inside an empty one
+    // (shrunk by a voxel on every side: three orders of magnitude above the float error of the approximate ray used
+    // here) every sample is known to return weight 0, so `cur` takes the same sequence of float additions -- the
+    // result is bit-identical -- without transforming, dividing or loading anything.  DR_RAYCAST_NO_SKIP=1 turns it off.
+    F3 dirw, inv_dir;
+    {
+      const float lx = ucx / o.fx, ly = vcy / o.fy;
+      dirw.x = pose.m[0] * lx + pose.m[1] * ly + pose.m[2];
+      dirw.y = pose.m[4] * lx + pose.m[5] * ly + pose.m[6];
+      dirw.z = pose.m[8] * lx + pose.m[9] * ly + pose.m[10];
+      inv_dir.x = 1.0f / dirw.x; inv_dir.y = 1.0f / dirw.y; inv_dir.z = 1.0f / dirw.z;
+    }
+    const float inv_trunc = 1.0f / o.truncation_distance, vs = o.voxel_size;
     float cur = 0.f;
     while (cur < o.max_sensor_depth) {
-      const Voxel v = interp_voxel<FAST, false>(d, sample_pos(cur), far_blocks, bail);
+      const F3 q = sample_pos(cur);
+      int cell = -1;
+      const Voxel v = interp_voxel<FAST, false>(d, q, far_blocks, bail, d.super[0] ? &cell : nullptr);
       if (bail) break;
-      if (v.weight == 0) cur += o.truncation_distance; else cur += v.sdf;
+      if (v.weight == 0) {
+        cur += o.truncation_distance;
+        if (cell >= 0) {
+          int k = 0;
+          if (d.super[0][super_index<kSuperShift[0]>((unsigned)cell)] == 0) k = skip_steps<kSuperShift[0]>((unsigned)cell, q, dirw, inv_dir, vs, inv_trunc);
+          else if (d.super[1][super_index<kSuperShift[1]>((unsigned)cell)] == 0) k = skip_steps<kSuperShift[1]>((unsigned)cell, q, dirw, inv_dir, vs, inv_trunc);
+          for (; k > 0 && cur < o.max_sensor_depth; --k) cur += o.truncation_distance;
+        }
+      } else cur += v.sdf;
       if (v.weight != 0 && v.sdf < o.voxel_size) break;
     }
     if (!bail && cur < o.max_sensor_depth) {
@@ -908,10 +997,13 @@ class FusionEngine {
     d_.err = d_.n_alloc + 1;
     d_.cnt = dalloc<unsigned long long>(4);
     d_.sd = dalloc<float>(npix_);
+    d_.pix = dalloc<PixRec>(npix_);
+    for (int l = 0; l < kSuperLevels; ++l) d_.super[l] = dalloc<unsigned char>((size_t)1 << (3 * (kGridBits - kSuperShift[l])));
     d_.present = dalloc<unsigned>((size_t)1 << (3 * kPresentBits - 5));
     DR_HIP(hipMemsetAsync(d_.present, 0, (size_t)1 << (3 * kPresentBits - 3), int_stream_));
     d_.grid = dalloc<int>((size_t)1 << (3 * kGridBits));
     DR_HIP(hipMemsetAsync(d_.grid, 0, sizeof(int) << (3 * kGridBits), int_stream_));
+    for (int l = 0; l < kSuperLevels; ++l) DR_HIP(hipMemsetAsync(d_.super[l], 0, (size_t)1 << (3 * (kGridBits - kSuperShift[l])), int_stream_));
     d_.req = dalloc<unsigned>(o.num_blocks);
     d_.req_count = dalloc<int>(4);
     d_.vis_count = d_.req_count + 1;
@@ -953,7 +1045,7 @@ class FusionEngine {
     (void)hipSetDevice(device_);
     (void)hipDeviceSynchronize();
     (void)hipFree(d_.keys); (void)hipFree(d_.vals); (void)hipFree(d_.blk_key); (void)hipFree(d_.vox);
-    (void)hipFree(d_.n_alloc); (void)hipFree(d_.cnt); (void)hipFree(d_.sd); (void)hipFree(d_.present); (void)hipFree(d_.grid); (void)hipFree(d_.req); (void)hipFree(d_.req_count); (void)hipFree(d_.vis); (void)hipFree(d_.wg_upd); (void)hipFree(d_bgr_in_); (void)hipFree(d_depth_in_);
+    (void)hipFree(d_.n_alloc); (void)hipFree(d_.cnt); (void)hipFree(d_.sd); (void)hipFree(d_.pix); (void)hipFree(d_.super[0]); (void)hipFree(d_.super[1]); (void)hipFree(d_.present); (void)hipFree(d_.grid); (void)hipFree(d_.req); (void)hipFree(d_.req_count); (void)hipFree(d_.vis); (void)hipFree(d_.wg_upd); (void)hipFree(d_bgr_in_); (void)hipFree(d_depth_in_);
     (void)hipHostFree(h_bgr_in_); (void)hipHostFree(h_depth_in_);
     for (auto &r : renders_) {
       (void)hipFree(r.d_bgr); (void)hipFree(r.d_depth); (void)hipFree(r.d_flag);
@@ -987,8 +1079,10 @@ class FusionEngine {
     const dim3 grid(8 * cdiv(cdiv((int)npix_, 64), 8)), block(64);
     if (raycast_v1_) { hipLaunchKernelGGL(k_raycast, grid, block, 0, st, d_, P, d_bgr, d_depth); return; }
     hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(1), 0, st, d_flag);
-    if (d_.fast_div) hipLaunchKernelGGL(k_raycast2<true>, grid, block, 0, st, d_, P, d_bgr, d_depth, d_flag);
-    else hipLaunchKernelGGL(k_raycast2<false>, grid, block, 0, st, d_, P, d_bgr, d_depth, d_flag);
+    FusionDev dv = d_;
+    if (raycast_no_skip_) dv.super[0] = nullptr;  // DR_RAYCAST_NO_SKIP=1: every sample is looked up (A/B and parity hook)
+    if (d_.fast_div) hipLaunchKernelGGL(k_raycast2<true>, grid, block, 0, st, dv, P, d_bgr, d_depth, d_flag);
+    else hipLaunchKernelGGL(k_raycast2<false>, grid, block, 0, st, dv, P, d_bgr, d_depth, d_flag);
     hipLaunchKernelGGL(k_raycast_fix, dim3(512), dim3(64), 0, st, d_, P, d_bgr, d_depth, d_flag);
   }
   // tsdf_volume.cu:634-700
@@ -1210,7 +1304,7 @@ class FusionEngine {
     Mat T, Ti;
     memcpy(T.m, pose16, 64);
     inverse4_host(T.m, Ti.m);
-    hipLaunchKernelGGL(k_allocate, dim3(cdiv((int)npix_, 256)), dim3(256), 0, int_stream_, d_, d_depth, T);
+    hipLaunchKernelGGL(k_allocate, dim3(cdiv((int)npix_, 256)), dim3(256), 0, int_stream_, d_, d_bgr, d_depth, T);
     hipLaunchKernelGGL(k_alloc_commit, dim3(64), dim3(256), 0, int_stream_, d_);
     if (kernel_events_[0]) DR_HIP(hipEventRecord(kernel_events_[0], int_stream_));
     hipLaunchKernelGGL(k_cull, dim3(512), dim3(256), 0, int_stream_, d_, Ti);
@@ -1339,6 +1433,7 @@ class FusionEngine {
   int integrate_grid_ = 4096;
   unsigned long long fast_div_mismatches_ = 0;
   bool raycast_v1_ = getenv("DR_RAYCAST_V1") != nullptr;  // A/B hook: the literal first-generation ray-caster
+  bool raycast_no_skip_ = getenv("DR_RAYCAST_NO_SKIP") != nullptr;  // A/B hook: no empty-space skip in k_raycast2
   std::vector<Render> renders_;
   int free_slot_ = 0;
   Next next_ = kIntegrate;
