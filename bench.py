@@ -305,8 +305,8 @@ def tsdf_leg(args, rank, dev, world):
     res = dict(metric="TSDF voxels integrated/sec", value=units / tmax, unit="voxels/s", frames=n,
                ms_per_frame=1e3 * tmax / n, wall_ms_per_frame=1e3 * (t1 - t0) / n, frames_per_s=n * world / tmax,
                blocks=st["blocks"], voxels_per_frame=vox / n, mismatches=st["mismatches"],
-               kernel_ms_per_frame=dict(allocate=ms["allocate"] / n, integrate=ms["integrate"] / n, raycast=ms["raycast"] / n,
-                                        render_d2h=ms["d2h"] / n),
+               kernel_ms_per_frame=dict(allocate_commit_cull=ms["allocate"] / n, integrate=ms["integrate"] / n, raycast=ms["raycast"] / n,
+                                        render_d2h=ms["d2h"] / n),  # hipEvents on the engine's streams; `integrate` brackets k_integrate alone
                integrate_only_voxels_per_s=vox / (ms["integrate"] * 1e-3),
                config=dict(workload="%d distinct synthetic 640x480 depth maps (camera loop through a 6x4x3 m room with a sphere, 2.5 %% invalid "
                                     "pixels) fused into an initially empty 5 mm hashed voxel grid (truncation 20 mm, 2.5 M blocks = 10 GB): per frame "

@@ -9,6 +9,7 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out profiles
 export TMPDIR=/tmp
 S="--no-cpu --engines 1 --no-boundary --no-loop"
+if [ -z "$SKIP_PMC" ]; then
 export DR_MVS_NO_SIDE_STREAM=1
 rm -rf gpurun_out/pm1 gpurun_out/pm2 gpurun_out/pm3 gpurun_out/pm4 gpurun_out/prof
 A="--steps 3 --warmup 1 --tsdf-frames 60 $S"
@@ -20,6 +21,7 @@ for i in 1 2 3 4; do d=$(dirname $(find gpurun_out/pm$i -name "pmc_counter_colle
 python tools/pmc_to_json.py profiles/r02_pmc_traffic.json $(for i in 1 2 3; do dirname $(find gpurun_out/pm$i -name "pmc_counter_collection.csv" | head -1); done)
 cp profiles/r02_pmc_traffic.json gpurun_out/
 unset DR_MVS_NO_SIDE_STREAM
+fi  # SKIP_PMC=1: keep the committed profiles/r02_pmc_traffic.json (kernels unchanged since it was taken)
 timeout 1500 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider --durations=10 > gpurun_out/r02_gpu_tests.log 2>&1; grep -E "passed|failed|^FAILED|^ERROR" gpurun_out/r02_gpu_tests.log | tail -5
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee gpurun_out/r02_smoke.txt
 timeout 1500 python bench.py > gpurun_out/r02_bench.json 2> gpurun_out/r02_bench.err; echo "bench rc=$?"; tail -c 600 gpurun_out/r02_bench.json
