@@ -327,6 +327,16 @@ def tsdf_leg(args, rank, dev, world):
             k = min(n, 8)
             res["cpu_baseline"] = tsdf_cpu_baseline([(fr["bgr"][i].cpu().numpy(), fr["depth"][i].cpu().numpy(), poses[i]) for i in range(k)], opt)
     f.close()
+    if rank == 0:  # the reference's native setting (FullSystem.cpp:260,266: 1 cm voxels, 4 cm truncation), same frames
+        g = DrFusion(DrFusionOptions(**dict(opt, voxel_size=0.01, truncation_distance=0.04, num_blocks=600000)), device=dev)
+        ms10 = g.bench_sequence(fr["bgr"].data_ptr(), fr["depth"].data_ptr(), poses, render=True)
+        st10 = g.stats()
+        res["native_10mm"] = dict(value=st10["updated_total"] / (ms10["total"] * 1e-3), unit="voxels/s", ms_per_frame=ms10["total"] / n,
+                                  voxels_per_frame=st10["updated_total"] / n, blocks=st10["blocks"],
+                                  kernel_ms_per_frame=dict(allocate_commit_cull=ms10["allocate"] / n, integrate=ms10["integrate"] / n,
+                                                           raycast=ms10["raycast"] / n, render_d2h=ms10["d2h"] / n),
+                                  note="1 cm voxels, 4 cm truncation: TANDEM's own DrFusionOptions; same 1000 frames and loop")
+        g.close()
     del fr
     torch.cuda.empty_cache()
     return res
