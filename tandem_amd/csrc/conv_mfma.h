@@ -63,7 +63,7 @@ struct ConvArgs {
   // k_conv_a (persistent, LDS-DMA staged) only:
   const float *zero16;  // 16 zero bytes: the source of every staged element outside the tensor
   int a_slots;          // 16-byte LDS slots per tile buffer (multiple of 512)
-  int a_wbufs;          // weight buffers: 1 (single pass: loaded once per workgroup) or 2 (one per pass in flight)
+  int a_wbufs;          // weight buffers: npass when all passes fit (each fetched once per workgroup), else 2 (one per pass in flight)
 };
 
 constexpr int kConvThreads = 256;
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(kConvAThreads) void k_conv_a(const ConvArgs a) {
 
   // LDS: [tile 0][tile 1][weights 0][weights 1 (multi-pass layers)][tap table]
   float4 *tile0 = lds4, *tile1 = lds4 + a.a_slots;
-  float4 *wb0 = lds4 + 2 * (size_t)a.a_slots, *wb1 = a.a_wbufs > 1 ? wb0 + n_w : wb0;
+  float4 *wb0 = lds4 + 2 * (size_t)a.a_slots;  // weight buffer of pass p: wb0 + (p % a_wbufs) * n_w
   int *tapl = reinterpret_cast<int *>(wb0 + (size_t)a.a_wbufs * n_w);
   for (int i = tid; i < NU * TPC; i += kConvAThreads) tapl[i] = a.tapoff[cls.tap_base + i];
   const int *tp = tapl + (4 * g) / CI;
@@ -497,8 +497,8 @@ __global__ __launch_bounds__(kConvAThreads) void k_conv_a(const ConvArgs a) {
     const int k = unit / a.npass, p = unit - k * a.npass;
     int pz0, py0, px0;
     tile_origin(k, pz0, py0, px0);
-    // weight buffer = pass % buffers: with one or two passes every pass keeps its own buffer and is fetched once
-    conv_a_issue<CI, CT>(a, (unit & 1) ? tile1 : tile0, (p & 1) ? wb1 : wb0, unit < a.npass || a.npass > a.a_wbufs, NP, NU, p, ct0, cls.w_base,
+    // weight buffer = pass % buffers: when every pass has its own buffer it is fetched once per workgroup
+    conv_a_issue<CI, CT>(a, (unit & 1) ? tile1 : tile0, wb0 + (size_t)(p % a.a_wbufs) * n_w, unit < a.npass || a.npass > a.a_wbufs, NP, NU, p, ct0, cls.w_base,
                          pz0 * a.sz - a.pz, py0 * a.sy - a.py, px0 * a.sx - a.px, wave, lane);
   };
 
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(kConvAThreads) void k_conv_a(const ConvArgs a) {
     if (i + 1 < n_units) issue(i + 1);
 #endif
 #ifndef DR_ABL_NO_KLOOP
-    conv_a_kloop<CI, CT, PT>((i & 1) ? tile1 : tile0, ((i % a.npass) & 1) ? wb1 : wb0, tp, TPC, NU, lane, c4, bpos, acc);
+    conv_a_kloop<CI, CT, PT>((i & 1) ? tile1 : tile0, wb0 + (size_t)((i % a.npass) % a.a_wbufs) * n_w, tp, TPC, NU, lane, c4, bpos, acc);
 #endif
     if ((i + 1) % a.npass == 0) done_tile = i / a.npass;
   }
@@ -729,7 +729,8 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
             for (int ct : {2, 1}) {
               if (CTtot % ct || !conv_a_instance_exists(ci, ct, pt)) continue;
               const size_t slots = conv_a_slots(tzi * tyi * txi, ci);
-              const size_t bytes = 2 * slots * 16 + (size_t)(npass > 1 ? 2 : 1) * nu * ct * 1024 + (size_t)nu * tpc * 4 + 64;
+              size_t bytes = 2 * slots * 16 + (size_t)npass * nu * ct * 1024 + (size_t)nu * tpc * 4 + 64;  // all passes' weights resident ...
+              if (bytes > kConvMaxLds) bytes = 2 * slots * 16 + (size_t)std::min(npass, 2) * nu * ct * 1024 + (size_t)nu * tpc * 4 + 64;  // ... or two in flight
               if (bytes > kConvMaxLds) continue;
               const double wpc = bytes * 2 <= kConvMaxLds ? 2.0 : 1.0, split = CTtot / ct;
               const double mfma_unit = nu * 4.0 * ct * pt * 32.0 * 2.0;  // cycles per SIMD: two waves of the workgroup share it
@@ -900,8 +901,12 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
     cl.async = 1;
     a.zero16 = arena.upload(std::vector<float>(4, 0.f));
     a.a_slots = (int)conv_a_slots(TZI * TYI * TXI, CI);
-    a.a_wbufs = npass > 1 ? 2 : 1;
+    a.a_wbufs = npass;
     cl.lds_bytes = 2 * (size_t)a.a_slots * 16 + (size_t)a.a_wbufs * nu_max * CT * 1024 + (size_t)nu_max * TPC * 4 + 64;
+    if (cl.lds_bytes > kConvMaxLds) {  // the passes' weights do not all fit next to the two tile buffers: two buffers, re-fetched per pass
+      a.a_wbufs = std::min(npass, 2);
+      cl.lds_bytes = 2 * (size_t)a.a_slots * 16 + (size_t)a.a_wbufs * nu_max * CT * 1024 + (size_t)nu_max * TPC * 4 + 64;
+    }
     const int ntiles = a.tilesD * a.tilesH * a.tilesW, split = CTtot / CT;
     const int wpc = cl.lds_bytes * 2 <= kConvMaxLds ? 2 : 1;
     const int want = std::max(1, std::min(ntiles, 256 * wpc / split));
