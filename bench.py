@@ -327,7 +327,7 @@ def tsdf_leg(args, rank, dev, world):
             k = min(n, 8)
             res["cpu_baseline"] = tsdf_cpu_baseline([(fr["bgr"][i].cpu().numpy(), fr["depth"][i].cpu().numpy(), poses[i]) for i in range(k)], opt)
     f.close()
-    if rank == 0:  # the reference's native setting (FullSystem.cpp:260,266: 1 cm voxels, 4 cm truncation), same frames
+    if rank == 0 and not args.no_tsdf_native:  # the reference's native setting (FullSystem.cpp:260,266: 1 cm voxels, 4 cm truncation), same frames
         g = DrFusion(DrFusionOptions(**dict(opt, voxel_size=0.01, truncation_distance=0.04, num_blocks=600000)), device=dev)
         ms10 = g.bench_sequence(fr["bgr"].data_ptr(), fr["depth"].data_ptr(), poses, render=True)
         st10 = g.stats()
@@ -516,6 +516,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
     ap.add_argument("--engines", type=int, default=3, help="DrMvsnet engines (independent windows in flight) per GPU; 1 = latency configuration")
     ap.add_argument("--no-tsdf", action="store_true")
+    ap.add_argument("--no-tsdf-native", action="store_true", help="skip the extra TSDF run at the reference's native 1 cm / 4 cm setting (profiling runs: keeps "
+                                                                   "per-kernel averages to the 5 mm loop the roofline is quoted on)")
     ap.add_argument("--no-view-shard", action="store_true", help="N > 1 only: skip the view-sharded (configs[2]) leg")
     ap.add_argument("--config", choices=["headline", "shipped"], default="headline",
                     help="headline: BASELINE.json's metric configuration, 640x480x7 views, planes (48,32,8).  shipped: the model TANDEM exports and runs "

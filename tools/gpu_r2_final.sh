@@ -8,7 +8,7 @@
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out profiles
 export TMPDIR=/tmp
-S="--no-cpu --engines 1 --no-boundary --no-loop"
+S="--no-cpu --engines 1 --no-boundary --no-loop --no-tsdf-native"
 if [ -z "$SKIP_PMC" ]; then
 export DR_MVS_NO_SIDE_STREAM=1
 rm -rf gpurun_out/pm1 gpurun_out/pm2 gpurun_out/pm3 gpurun_out/pm4 gpurun_out/prof
@@ -22,10 +22,12 @@ python tools/pmc_to_json.py profiles/r02_pmc_traffic.json $(for i in 1 2 3; do d
 cp profiles/r02_pmc_traffic.json gpurun_out/
 unset DR_MVS_NO_SIDE_STREAM
 fi  # SKIP_PMC=1: keep the committed profiles/r02_pmc_traffic.json (kernels unchanged since it was taken)
+if [ -z "$ONLY_PROFILES" ]; then
 timeout 1500 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider --durations=10 > gpurun_out/r02_gpu_tests.log 2>&1; grep -E "passed|failed|^FAILED|^ERROR" gpurun_out/r02_gpu_tests.log | tail -5
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee gpurun_out/r02_smoke.txt
 timeout 1500 python bench.py > gpurun_out/r02_bench.json 2> gpurun_out/r02_bench.err; echo "bench rc=$?"; tail -c 600 gpurun_out/r02_bench.json
 timeout 600 python bench.py --config shipped --steps 240 --no-tsdf --no-loop > gpurun_out/r02_bench_shipped.json 2> gpurun_out/r02_bench_shipped.err; echo "shipped rc=$?"; head -c 300 gpurun_out/r02_bench_shipped.json; echo
+fi  # ONLY_PROFILES=1: PMC passes and kernel stats only
 DR_MVS_NO_SIDE_STREAM=1 timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o bench -- python bench.py --steps 20 --warmup 3 --tsdf-frames 200 $S > gpurun_out/r02_bench_prof.json 2> gpurun_out/prof.err
 python tools/rocprof_summary.py $(find gpurun_out/prof -name "*_results.db" | head -1) > gpurun_out/r02_bench_kernel_stats.txt 2>&1; head -12 gpurun_out/r02_bench_kernel_stats.txt
 rm -rf gpurun_out/pm1 gpurun_out/pm2 gpurun_out/pm3 gpurun_out/pm4 gpurun_out/prof
