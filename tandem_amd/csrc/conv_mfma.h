@@ -1,5 +1,10 @@
-// conv_mfma.h -- the one convolution kernel of the depth pipeline: a tap-table implicit GEMM on
-// the fp32 matrix cores of gfx950 (v_mfma_f32_16x16x4_f32, exact fp32 == an fmaf chain).
+// conv_mfma.h -- the convolution kernels of the depth pipeline: a tap-table implicit GEMM on
+// the fp32 matrix cores of gfx950 (v_mfma_f32_16x16x4_f32, exact fp32 == an fmaf chain), in two launch forms that
+// share operand mapping, packed weights, tap tables and epilogue:
+//   k_conv<CI,CT,PT,FZ>  4 waves, one tile per workgroup, register-staged halo tile (FZ = 8: the staging step computes
+//                        FeatureNet's skip.stage3 + upsample instead of copying a tensor);
+//   k_conv_a<CI,CT,PT>   8 waves, persistent over (tile, channel pass) units, halo tiles streamed into a second LDS
+//                        buffer by LDS-DMA (global_load_lds_dwordx4) under the K loop of the current unit.
 //
 // It replaces every dense contraction the reference hands to cuDNN through ATen
 // (FeatureNet.forward cva_mvsnet/models/module.py:496-531, CostRegNet.forward module.py:577-600):

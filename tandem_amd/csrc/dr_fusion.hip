@@ -1,12 +1,20 @@
 // dr_fusion.hip -- MI355X engine behind the DrFusion operator API (C ABI: include/dr_mi355x.h).
 //
 // Replaces tandem/libdr/dr_fusion/src (CUDA, managed memory, try-lock hash inserts):
-//   HashTable / Heap        tsdfvh/hash_table.cu, heap.cu  -> lock-free open-addressing table keyed by the
-//                                                           packed block coordinate (64-bit CAS), bump pool
-//   AllocateFromDepthKernel tsdfvh/tsdf_volume.cu:317-434 -> k_allocate   (one lane per pixel, DDA)
-//   IntegrateScanKernel     tsdfvh/tsdf_volume.cu:436-513 -> k_integrate  (one 64-lane wave per ALLOCATED block,
-//                                                           8 voxels per lane, coalesced 4 KB block read-modify-write)
-//   GenerateRgbDepthKernel  tsdfvh/tsdf_volume.cu:600-632 -> k_raycast    (one lane per pixel, sphere tracing)
+//   HashTable / Heap        tsdfvh/hash_table.cu, heap.cu  -> dense direct-mapped block grid (512^3 cells, one load per
+//                                                           look-up) + presence bitmap + request list for block
+//                                                           coordinates in [-256, 256)^3; a lock-free open-addressing
+//                                                           table (64-bit CAS) outside it; bump pool
+//   AllocateFromDepthKernel tsdfvh/tsdf_volume.cu:317-434 -> k_allocate   (one lane per pixel, DDA; new blocks are requested
+//                                                           once per wave) + k_alloc_commit (pool slots, bitmap, superblock flags)
+//   IntegrateScanKernel     tsdfvh/tsdf_volume.cu:436-513 -> k_cull (allocated blocks whose centre projects into the image)
+//                                                           + k_integrate (one 64-lane wave per VISIBLE block, 8 voxels
+//                                                           per lane, coalesced 4 KB block read-modify-write, one 12-byte
+//                                                           pixel record per voxel) + k_fold_counter
+//   GenerateRgbDepthKernel  tsdfvh/tsdf_volume.cu:600-632 -> k_raycast2 (one lane per pixel, sphere tracing; exact 3-instruction
+//                                                           division verified against IEEE for all dividends, shared
+//                                                           corner coordinates, empty-superblock skip) + k_raycast_fix;
+//                                                           k_raycast = the literal form (DR_RAYCAST_V1, parity hook)
 //   TsdfVolume::{IntegrateScanAsync,RenderAsync,GetRenderResult}  tsdf_volume.cu:515-737 -> FusionEngine
 //   MeshExtractor / ExtractMeshAsync / GetMeshSync  marching_cubes/mesh_extractor.cu, tsdf_volume.cu:739-838
 //                                                         -> mesh_kernels.h (per allocated block, LDS neighbourhood)

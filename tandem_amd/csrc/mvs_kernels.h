@@ -6,7 +6,9 @@
 //   k_regress    : softmax over D, depth expectation, 4-neighbour confidence (module.py:1116-1133)
 //   k_edge / k_hist / k_scan / k_apply : 5x5 order-statistic edge filter with an exact
 //                  radix-select quantile                            (module.py:1320-1361)
-//   k_prob       : CostRegNet's Cout = 1 head on the vector pipe, marching along z  (module.py:575)
+//   k_prob       : CostRegNet's Cout = 1 head on the vector pipe, one output column per lane marching along z  (module.py:575)
+//   k_skip_up    : FeatureNet skip (1x1 conv + bias + nearest x2 of the coarser level) as a streaming kernel; the same
+//                  arithmetic runs inside k_conv's fused staging (conv_mfma.h) for stage 3
 // Coalesced float4 channels-last accesses, no re-materialised intermediates (the reference writes and re-reads a
 // (C,D,h,w) volume ~7 times per source view); k_costvol walks the image in XCD-aware bands so that its gathers hit L2.
 #pragma once
