@@ -445,9 +445,8 @@ def view_shard_leg(args, rank, dev, world):
     m = DrMvsnet(model_blob(), device=dev)
     mine = view_shard.upload(m, window, rank, world)
     one_dev = os.environ.get("DR_BENCH_ONE_DEVICE") == "1"  # test scaffold: RCCL refuses two ranks on one device
-    if not one_dev:
+    if not one_dev and view_shard.init_engine_collective(m, rank, world):
         # the engine's own collective: ncclAllReduce of each cost volume on the engine stream, no host step per phase
-        view_shard.init_engine_collective(m, rank, world)
         step = lambda n: m.forward(n)
         mode = "in-engine RCCL all-reduce of the fp32 cost volume after each stage's cost-volume kernel, stream-ordered"
         nbytes = sum(m.device_tensor("volume%d" % s)[1] for s in (1, 2, 3)) * 4
@@ -458,7 +457,7 @@ def view_shard_leg(args, rank, dev, world):
         def step(n):
             for _ in range(n):
                 view_shard.forward(m, ar)
-        mode = "host-driven phases with torch.distributed all-reduce (one-device test scaffold)"
+        mode = "host-driven phases with torch.distributed all-reduce (%s)" % ("one-device test scaffold" if one_dev else "engine could not bind RCCL")
         nbytes = sum(m.device_tensor("volume%d" % s)[1] for s in (1, 2, 3)) * 4
     step(warmup)
     replicas.barrier(dev)
@@ -550,9 +549,24 @@ def main():
     bd = boundary_leg(args, local_rank) if (rank == 0 and world == 1 and not args.no_boundary) else None
     lp = tandem_loop_leg(args, local_rank) if (rank == 0 and world == 1 and not args.no_loop) else None
     sh = shipped_leg(args, local_rank) if (rank == 0 and world == 1 and not args.no_boundary) else None
-    vs = None
+    vs, vs_hung = None, False
     if world > 1 and not args.no_view_shard:
-        vs = view_shard_leg(args, rank, local_rank, world)
+        # The sharded leg is the only part of this program with a data-path collective.  It runs under a watchdog: if a
+        # rank gets stuck in it (a collective that never completes cannot be cancelled from Python) the headline line
+        # above is still printed and every rank leaves with os._exit instead of hanging the launcher.
+        import threading
+        box = {}
+
+        def run_vs():
+            try:
+                box["r"] = view_shard_leg(args, rank, local_rank, world)
+            except Exception as e:  # reported in the line, never fatal for the headline measurement
+                box["r"] = dict(error="%s: %s" % (type(e).__name__, e))
+        th = threading.Thread(target=run_vs, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("DR_BENCH_VS_TIMEOUT", "240")))
+        vs_hung = th.is_alive()
+        vs = dict(error="view-sharded leg did not finish within the watchdog time") if vs_hung else box.get("r")
     if rank == 0:
         out = {
             "metric": "depth-maps/sec @ %dx%dx7-view x3-stage; TSDF voxels integrated/sec" % (W, H),
@@ -582,7 +596,9 @@ def main():
             out["tracker"] = tr
         if vs is not None:
             out["view_sharded"] = vs
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if vs_hung:
+        os._exit(0)
     import torch.distributed as dist
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -77,13 +77,22 @@ def forward(model, allreduce):
 
 def init_engine_collective(model, rank, world):
     """Give `model` an RCCL communicator of its own (drm_comm_init): rank 0 draws the id, torch.distributed carries the 128
-    bytes to the other ranks.  Afterwards `model.forward(n)` / CallAsync run a sharded window without any host step."""
-    import torch
+    bytes to the other ranks.  Afterwards `model.forward(n)` / CallAsync run a sharded window without any host step.
+    Returns False (on every rank alike) when rank 0 could not bind RCCL; the caller then uses the host-driven phases."""
+    import sys
     import torch.distributed as dist
-    uid = [model.comm_unique_id() if rank == 0 else None]
+    uid = [None]
+    if rank == 0:
+        try:
+            uid = [model.comm_unique_id()]
+        except Exception as e:  # no librccl.so.1 to bind: every rank learns it from the broadcast and falls back together
+            print("view_shard: engine collective unavailable (%s); using torch.distributed" % e, file=sys.stderr)
     if world > 1:
         dist.broadcast_object_list(uid, src=0)
+    if uid[0] is None:
+        return False
     model.comm_init(rank, world, uid[0])
+    return True
 
 
 def run(model, window, rank, world, allreduce):
