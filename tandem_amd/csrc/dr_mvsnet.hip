@@ -644,7 +644,11 @@ class MvsEngine {
       DevTensor &x7 = dbr3(pre + "conv7", cr + "conv7", k6, four ? 1 : 2, k4);
       DevTensor &x9 = dbr3(pre + "conv9", cr + "conv9", x7, 2, k2);
       DevTensor &x11 = dbr3(pre + "conv11", cr + "conv11", x9, 2, c0);
-      {
+      if (getenv("DR_PROB_ON_CONV") && w % 8 == 0) {
+        // A/B hook: the Cout = 1 head as 8 x-shifts per column on the MFMA kernel (CONV_X8, 50 % of the rows carry work);
+        // measured against k_prob in profiles/r02_experiments.txt
+        add_conv(pre + "prob", cr + "prob", "", false, false, x11, "logits" + S, 3, 3, 3, 1, 1, 1, false, CONV_X8, nullptr, 0);
+      } else {
         const HostTensor &pw = blob_.at(cr + "prob.weight");  // (1,8,3,3,3) -> [tap][cin]
         std::vector<float> wt(27 * 8);
         for (int ci = 0; ci < 8; ++ci) for (int t = 0; t < 27; ++t) wt[t * 8 + ci] = pw.data[ci * 27 + t];
