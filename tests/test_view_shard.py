@@ -109,3 +109,30 @@ def test_two_rank_gloo_view_shard(tmp_path):
         # tolerance: fp32 summation order of 4 views split 2 + 2 -- same bar as the HIP path vs the oracle
         assert o["err"] < 1e-4 and o["flips"] < 1e-3, o  # measured: 3.6e-6 m, 0 flips
     assert a["checksum"] == b["checksum"]  # every rank ends with the same depth map (no broadcast needed)
+
+
+def test_engine_collective_falls_back_when_rccl_cannot_be_bound():
+    """init_engine_collective must not raise when the engine cannot draw an RCCL id (no librccl.so.1): it reports False --
+    on every rank alike, the id travels by broadcast -- and bench.py's sharded leg then uses the host-driven phases."""
+    from tandem_amd import view_shard
+
+    class NoRccl:
+        def comm_unique_id(self):
+            raise RuntimeError("librccl.so.1: cannot open shared object file")
+
+        def comm_init(self, rank, world, uid):
+            raise AssertionError("must not be reached without an id")
+
+    class WithRccl:
+        def __init__(self):
+            self.got = None
+
+        def comm_unique_id(self):
+            return b"\x01" * 128
+
+        def comm_init(self, rank, world, uid):
+            self.got = (rank, world, uid)
+
+    assert view_shard.init_engine_collective(NoRccl(), 0, 1) is False
+    m = WithRccl()
+    assert view_shard.init_engine_collective(m, 0, 1) is True and m.got == (0, 1, b"\x01" * 128)
