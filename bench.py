@@ -569,7 +569,9 @@ def main():
         vs = dict(error="view-sharded leg did not finish within the watchdog time") if vs_hung else box.get("r")
     if rank == 0:
         out = {
-            "metric": "depth-maps/sec @ %dx%dx7-view x3-stage; TSDF voxels integrated/sec" % (W, H),
+            # BASELINE.json's metric string, verbatim, for the configuration it is quoted on
+            "metric": ("depth-maps/sec @ 640\u00d7480\u00d77-view\u00d73-stage; TSDF voxels integrated/sec" if args.config == "headline"
+                       else "depth-maps/sec @ %d\u00d7%d\u00d77-view\u00d73-stage; TSDF voxels integrated/sec" % (W, H)),
             "value": mv["value"], "unit": "depth-maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": mv["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
