@@ -1,0 +1,311 @@
+// conv_march.h -- k_conv_m: the stride-1 3x3 / 3x3x3 convolutions as a MARCHING, producer/consumer-specialised kernel.
+//
+// Same implicit GEMM as conv_mfma.h (operand mapping, packed weights, swizzled LDS-DMA image, epilogue), different engine:
+//   * a persistent workgroup = 8 CONSUMER waves (two per SIMD: ds_read_b128 + v_mfma_f32_16x16x4_f32 and nothing else in
+//     the K loop) + 2 PRODUCER waves that issue every LDS-DMA (global_load_lds_dwordx4) from a per-lane offset table built
+//     once per workgroup -- no address decode, no vmcnt wait and no barrier in the MFMA waves;
+//   * the workgroup owns a contiguous range of steps (march_plan.h) and MARCHES along z: a ring of R input planes stays
+//     in LDS, a step computes one output plane of the tile from the three planes around it and only ONE new plane is
+//     fetched per step (k_conv_a re-fetched a 6-plane halo per 4 output planes, in two half-record passes);
+//   * no s_barrier after start-up.  Producer -> consumers: a monotone `ready` word per producer wave, written after the
+//     wave's s_waitcnt vmcnt(0) (its DMA pieces have landed).  Consumers -> producer: one monotone `released` word per
+//     consumer wave, written after the last ds_read of a ring slot.  A wave's LDS operations execute in order, so a
+//     reader that has seen the word sees the data, and a slot is overwritten only after every reader is done with it.
+//     The consumer waves therefore drift apart instead of draining the MFMA pipe at a barrier once per unit;
+//   * sections whose input plane lies outside the volume (z padding) are skipped, not fed zeros;
+//   * channel passes that do not fit (Cin = 32 with a 3x3x3 kernel: 72 KB of weights) run as an OUTER loop over the whole
+//     range: pass 0 leaves raw fp32 partial sums in the output tensor, the last pass adds them before the BN/ReLU
+//     epilogue (the same lane wrote them).
+// Every wait is bounded: a wave that gives up raises the workgroup's abort word and *err and leaves; nothing can hang.
+#pragma once
+#include "march_plan.h"
+
+namespace dr {
+
+struct MarchArgs {
+  const int *tap2d;    // [NUP * TPC] in-plane tap offsets (positions of the staged plane)
+  MarchGeom geo;
+  int NPO;             // channel passes around the whole range (1 or 2)
+  int ncols, colsH, colsW;
+  int R, PS;           // ring slots, 16-byte LDS slots per ring slot (multiple of 128: an even number of 1 KiB DMA pieces)
+  int NP;              // staged positions per plane (TYI * TXI)
+  int nit;             // DMA pieces of a plane per producer wave (PS / 128)
+  int wsec;            // float4 per weight section (NUP * CT * 64)
+  int NU;              // K chunks per channel pass in the packed weight array (KZ * NUP)
+  int steps;           // ncols * Dc
+  int *err;            // raised when a wait gave up (nullptr: not reported)
+};
+
+constexpr int kMarchConsumers = 8, kMarchProducers = 2;
+constexpr int kMarchThreads = 64 * (kMarchConsumers + kMarchProducers);
+constexpr int kMarchMaxIt = 24;          // DMA pieces per producer wave per plane (planes up to 48 KB)
+constexpr int kMarchSpinLimit = 1 << 18; // polls before a wait gives up (tens of milliseconds)
+// flag words (ints) behind the weights: [0..1] ready (one per producer wave), [4..11] released (one per consumer wave), [12] abort
+constexpr int kMarchFlagInts = 16;
+
+// the flag words are read and written with LDS instructions (ds_read / ds_write), never through flat addressing
+typedef __attribute__((address_space(3))) volatile int march_flag_t;
+
+__device__ inline int march_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// ---- index arithmetic shared with the host emulation (tests/cpp/march_emul.hip), which checks it against a direct convolution ----
+// staged position of output position j of position tile (wave, pt)
+DR_HD inline int march_bpos(const ConvArgs &a, int wave, int pt, int PT, int j) {
+  const int tau = wave * PT + pt, xt = tau % a.TXT, yt = tau / a.TXT;
+  return yt * a.TXI + (xt * 16 + j) * a.sx;
+}
+// column -> tile origin (output positions) and, for 2-D layers, the image the column belongs to
+DR_HD inline void march_tile_origin(const ConvArgs &a, const MarchArgs &m, int col, int &zc, int &py0, int &px0) {
+  zc = col / (m.colsH * m.colsW);
+  const int tl = col - zc * (m.colsH * m.colsW);
+  py0 = (tl / m.colsW) * a.TY; px0 = (tl % m.colsW) * a.TXT * 16;
+}
+// DMA piece (producer wave pw, iteration it), lane -> element offset inside the plane relative to the tile origin, packed (y, x)
+template <int CI>
+DR_HD inline void march_piece_entry(const ConvArgs &a, const MarchArgs &m, int pw, int it, int lane, int &rel, unsigned &yx) {
+  int pos, c4;
+  conv_a_slot<CI>((it * kMarchProducers + pw) * 64 + lane, pos, c4);
+  const unsigned y = (unsigned)pos / (unsigned)a.TXI, x = (unsigned)pos - y * a.TXI;
+  const bool ok = it < m.nit && pos < m.NP;
+  rel = ok ? (int)((y * a.inW + x) * a.inC + c4 * 4) : 0;
+  yx = ok ? ((y << 16) | x) : 0x7fff7fffu;  // a position no tile origin can bring inside the tensor
+}
+DR_HD inline bool march_piece_inside(const ConvArgs &a, unsigned yx, int iy0, int ix0) {
+  const unsigned gy = (unsigned)(iy0 + (int)(yx >> 16)), gx = (unsigned)(ix0 + (int)(yx & 0xffffu));
+  return gy < (unsigned)a.inH && gx < (unsigned)a.inW;
+}
+// element offset of the tile origin of input plane gz, channel slice `pass` (may be negative: the halo starts outside the tensor)
+DR_HD inline long long march_plane_offset(const ConvArgs &a, int gz, int iy0, int ix0, int pass, int CI) {
+  return (((long long)gz * a.inH + iy0) * a.inW + ix0) * a.inC + (long long)pass * CI;
+}
+// weight piece e = (sec * NUP + u) * CT + ct of outer pass po -> float4 index (lane 0) in the packed weight array
+DR_HD inline size_t march_weight_src(const ConvArgs &a, const MarchArgs &m, int po, int e, int NUP, int CT, int ct0) {
+  const int ct = e % CT, su = e / CT, u = su % NUP, sec = su / NUP;
+  const int dz = sec / m.geo.NPI, pi = sec - dz * m.geo.NPI;
+  return ((size_t)((po * m.geo.NPI + pi) * m.NU + dz * NUP + u) * a.ctTot + ct0 + ct) * 64;
+}
+DR_HD inline size_t march_out_index(const ConvArgs &a, int qz, int qy, int qx, int c0) {
+  return (((size_t)qz * a.outH + qy) * a.outW + qx) * a.outC + c0;
+}
+
+// Consumer side: wait until load `idx` has landed.  `cached` remembers the last value seen (the producers normally run
+// ahead, so most sections need no LDS read at all).
+__device__ inline bool march_wait_ready(march_flag_t *flags, int idx, int &cached, int *err, int lane) {
+  if (cached > idx) return true;
+  for (int spin = 0; spin < kMarchSpinLimit; ++spin) {
+    const int r0 = flags[0], r1 = flags[1];
+    cached = march_uniform(r0 < r1 ? r0 : r1);
+    if (cached > idx) return true;
+    if (march_uniform(flags[12])) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  if (lane == 0) { flags[12] = 1; if (err) *err = 1; }
+  return false;
+}
+// Producer side: wait until every consumer wave has released `need` loads.
+__device__ inline bool march_wait_released(march_flag_t *flags, int need, int *err, int lane) {
+  for (int spin = 0; spin < kMarchSpinLimit; ++spin) {
+    int v = flags[4];
+#pragma unroll
+    for (int w = 1; w < kMarchConsumers; ++w) { const int t = flags[4 + w]; v = t < v ? t : v; }
+    if (march_uniform(v) >= need) return true;
+    if (march_uniform(flags[12])) break;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  if (lane == 0) { flags[12] = 1; if (err) *err = 2; }
+  return false;
+}
+
+// ---- K loop of one section: NUP chunks, fully unrolled, every LDS address known before the loop ----
+template <int NUP, int CT, int PT>
+__device__ inline void march_load(const float4 *tile, const float4 *wp, const int (&sw)[NUP][PT], int u, float4 (&av)[CT], float4 (&bv)[PT]) {
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) av[ct] = wp[(u * CT + ct) * 64];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) bv[pt] = tile[sw[u][pt]];
+}
+template <int CT, int PT>
+__device__ inline void march_anchor(const float4 (&av)[CT], const float4 (&bv)[PT]) {
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) asm volatile("" ::"v"(av[ct].x), "v"(av[ct].y), "v"(av[ct].z), "v"(av[ct].w));
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) asm volatile("" ::"v"(bv[pt].x), "v"(bv[pt].y), "v"(bv[pt].z), "v"(bv[pt].w));
+}
+template <int NUP, int CT, int PT>
+__device__ inline void march_kloop(const float4 *tile, const float4 *wp, const int (&sw)[NUP][PT], floatx4 (&acc)[CT][PT]) {
+  float4 a0[CT], b0[PT], a1[CT], b1[PT];
+  march_load<NUP, CT, PT>(tile, wp, sw, 0, a0, b0);
+#pragma unroll
+  for (int u = 0; u + 1 < NUP; u += 2) {
+    march_load<NUP, CT, PT>(tile, wp, sw, u + 1, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    conv_chunk_mfma<CT, PT>(a0, b0, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    march_anchor<CT, PT>(a1, b1);
+    if (u + 2 < NUP) march_load<NUP, CT, PT>(tile, wp, sw, u + 2, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    conv_chunk_mfma<CT, PT>(a1, b1, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    if (u + 2 < NUP) march_anchor<CT, PT>(a0, b0);
+  }
+  if (NUP & 1) conv_chunk_mfma<CT, PT>(a0, b0, acc);
+}
+
+// ---- epilogue of one step; raw: 0 = final, 1 = store raw partial sums, 2 = add the stored partial sums, then final ----
+template <int CT, int PT>
+__device__ inline void march_epilogue(const ConvArgs &a, floatx4 (&acc)[CT][PT], const float4 (&scv)[CT], const float4 (&biv)[CT], int raw,
+                                      int wave, int j, int g, int ct0, int qz, int py0, int px0) {
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const int tau = wave * PT + pt;
+    const int xt = tau % a.TXT, yt = tau / a.TXT;
+    const int qy = py0 + yt, qx = px0 + xt * 16 + j;
+    if (qy >= a.nPH || qx >= a.nPW) continue;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int c0 = (ct0 + ct) * 16 + 4 * g;
+      if (c0 >= a.rows_valid) continue;
+      const size_t obase = march_out_index(a, qz, qy, qx, c0);
+      float4 v = make_float4(acc[ct][pt][0], acc[ct][pt][1], acc[ct][pt][2], acc[ct][pt][3]);
+      if (raw == 2) {
+        const float4 r = *reinterpret_cast<const float4 *>(a.out + obase);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      if (raw != 1) {
+        const float4 sc = scv[ct], bi = biv[ct];
+        v.x = v.x * sc.x + bi.x; v.y = v.y * sc.y + bi.y; v.z = v.z * sc.z + bi.z; v.w = v.w * sc.w + bi.w;
+        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (a.add_mode) {
+          size_t abase = obase;
+          if (a.add_mode == 2) abase = (((size_t)qz * a.addH + (qy >> 1)) * a.addW + (qx >> 1)) * a.outC + c0;
+          const float4 r = *reinterpret_cast<const float4 *>(a.add + abase);
+          v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+      }
+      *reinterpret_cast<float4 *>(a.out + obase) = v;
+    }
+  }
+}
+
+template <int CI, int NUP, int CT, int PT>
+__device__ inline void march_consumer(const ConvArgs &a, const MarchArgs &m, float4 *lds4, march_flag_t *flags, const float4 *wl, int wave, int lane,
+                                      int s0, int s1) {
+  constexpr int TPC = 16 / CI;
+  const int j = lane & 15, g = lane >> 4;
+  const int sub = (4 * g) / CI, c4 = ((4 * g) % CI) / 4, ct0 = blockIdx.z * CT;
+  const int NS = m.geo.KZ * m.geo.NPI;
+  // swizzled 16-byte slot of this lane's operand for every chunk of a plane and every position tile of the wave
+  int sw[NUP][PT];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const int bpos = march_bpos(a, wave, pt, PT, j);
+#pragma unroll
+    for (int u = 0; u < NUP; ++u) {
+      sw[u][pt] = conv_a_unit<CI>(bpos + m.tap2d[u * TPC + sub], c4);
+      asm volatile("" : "+v"(sw[u][pt]));  // one register per address: hipcc otherwise keeps the position and channel parts apart (2 x NUP x PT registers)
+    }
+  }
+  float4 scv[CT], biv[CT];
+  conv_load_affine<CT>(a, g, ct0, scv, biv);
+  const float4 *wp = wl + lane;
+  int cached = 0, L = 0;
+  for (int po = 0; po < m.NPO; ++po) {
+    const int raw = m.NPO == 1 ? 0 : (po == 0 ? 1 : 2);  // the planner produces NPO <= 2
+    for (int s = s0; s < s1;) {
+      const MarchSeg sg = march_segment(m.geo, s, s1);
+      int zc, py0, px0;
+      march_tile_origin(a, m, sg.col, zc, py0, px0);
+      for (int z = sg.za; z < sg.zb; ++z) {
+        floatx4 acc[CT][PT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+          for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int sec = 0; sec < NS; ++sec) {
+          const int rel = march_section_load(m.geo, sg, z, sec);
+          if (rel < 0) continue;
+          const int idx = L + rel;
+          if (!march_wait_ready(flags, idx, cached, m.err, lane)) return;
+          asm volatile("" ::: "memory");
+          march_kloop<NUP, CT, PT>(lds4 + (size_t)(idx % m.R) * m.PS, wp + (size_t)sec * m.wsec, sw, acc);
+          if (march_section_releases(m.geo, sg, z, sec)) {
+            asm volatile("" ::: "memory");
+            if (lane == 0) flags[4 + wave] = idx + 1;
+          }
+        }
+        const int qz = m.geo.KZ == 3 ? z : zc;
+        march_epilogue<CT, PT>(a, acc, scv, biv, raw, wave, j, g, ct0, qz, py0, px0);
+      }
+      L += sg.nl;
+      s += sg.zb - sg.za;
+    }
+  }
+}
+
+// Producer wave pw of kMarchProducers: takes DMA pieces pw, pw + 2, ... of every plane and of the weights.
+template <int CI>
+__device__ inline void march_producer(const ConvArgs &a, const MarchArgs &m, float4 *lds4, march_flag_t *flags, float4 *wl, int pw, int lane, int s0,
+                                      int s1, int NUP, int CT) {
+  const int ct0 = blockIdx.z * CT, NS = m.geo.KZ * m.geo.NPI;
+  // per-lane table of this wave's pieces of a plane: element offset inside the plane (relative to the tile origin) and
+  // the (y, x) of the position inside the tile for the bounds test.  Built once; a piece then costs a compare and an add.
+  int rel[kMarchMaxIt];
+  unsigned yx[kMarchMaxIt];
+#pragma unroll
+  for (int it = 0; it < kMarchMaxIt; ++it) march_piece_entry<CI>(a, m, pw, it, lane, rel[it], yx[it]);
+  int L = 0;
+  for (int po = 0; po < m.NPO; ++po) {
+    if (po > 0 && !march_wait_released(flags, L, m.err, lane)) return;  // nobody reads the previous pass's weights any more
+    // packed weights of this outer pass: section (dz, pi) = chunks dz*NUP .. of channel pass po*NPI + pi
+    for (int e = pw; e < NS * NUP * CT; e += kMarchProducers)  // piece e = (sec * NUP + u) * CT + ct
+      conv_a_dma16(a.wpk + march_weight_src(a, m, po, e, NUP, CT, ct0) + lane, march_uniform(conv_a_lds_addr(wl + (size_t)e * 64)));
+    for (int s = s0; s < s1;) {
+      const MarchSeg sg = march_segment(m.geo, s, s1);
+      int zc, py0, px0;
+      march_tile_origin(a, m, sg.col, zc, py0, px0);
+      const int iy0 = py0 * a.sy - a.py, ix0 = px0 * a.sx - a.px;
+      for (int l = 0; l < sg.nl; ++l) {
+        const int idx = L + l;
+        int plane, pi;
+        march_load_plane(m.geo, sg, l, plane, pi);
+        const int gz = m.geo.KZ == 3 ? plane : zc;
+        if (idx >= m.R && !march_wait_released(flags, idx - m.R + 1, m.err, lane)) return;
+        asm volatile("" ::: "memory");
+        const float *pbase = a.in + march_plane_offset(a, gz, iy0, ix0, po * m.geo.NPI + pi, CI);
+        float4 *dst = lds4 + (size_t)(idx % m.R) * m.PS;
+#pragma unroll
+        for (int it = 0; it < kMarchMaxIt; ++it) {
+          if (it < m.nit) {
+            const float *src = march_piece_inside(a, yx[it], iy0, ix0) ? pbase + rel[it] : a.zero16;
+            conv_a_dma16(src, march_uniform(conv_a_lds_addr(dst + (it * kMarchProducers + pw) * 64)));
+          }
+        }
+        conv_a_wait_dma();  // this wave's pieces of load idx (and, first time round, of the weights) have landed
+        if (lane == 0) flags[pw] = idx + 1;
+      }
+      L += sg.nl;
+      s += sg.zb - sg.za;
+    }
+  }
+}
+
+// grid = (persistent workgroups (multiple of 8), 1, output-row groups); 10 waves.
+template <int CI, int NUP, int CT, int PT>
+__global__ __launch_bounds__(kMarchThreads) void k_conv_m(const ConvArgs a, const MarchArgs m) {
+  extern __shared__ float4 lds4[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = march_uniform(tid >> 6);
+  float4 *wl = lds4 + (size_t)m.R * m.PS;
+  march_flag_t *flags = (march_flag_t *)(__attribute__((address_space(3))) char *)(wl + (size_t)m.geo.KZ * m.geo.NPI * m.wsec);
+  if (tid < kMarchFlagInts) flags[tid] = 0;
+  __syncthreads();  // the only barrier of the kernel
+  // XCD k (= blockIdx.x % 8, own L2) owns the k-th contiguous eighth of the step space: the workgroups of an XCD work on
+  // neighbouring columns, whose halos overlap in that L2
+  const int nwg = gridDim.x, id = (int)(blockIdx.x & 7u) * (nwg >> 3) + (int)(blockIdx.x >> 3);
+  int s0, s1;
+  march_range(m.steps, id, nwg, s0, s1);
+  if (s0 >= s1) return;
+  if (wave < kMarchConsumers) march_consumer<CI, NUP, CT, PT>(a, m, lds4, flags, wl, wave, lane, s0, s1);
+  else march_producer<CI>(a, m, lds4, flags, wl, wave - kMarchConsumers, lane, s0, s1, NUP, CT);
+}
+
+}  // namespace dr

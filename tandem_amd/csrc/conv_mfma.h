@@ -377,13 +377,13 @@ __global__ __launch_bounds__(kConvThreads) void k_conv(const ConvArgs a) {
 constexpr int kConvAThreads = 512;
 
 template <int CI>
-__device__ inline int conv_a_unit(int pos, int c4) {  // (position, channel group) -> 16-byte slot
+__host__ __device__ inline int conv_a_unit(int pos, int c4) {  // (position, channel group) -> 16-byte slot
   if constexpr (CI == 4) return pos;
   else if constexpr (CI == 8) return ((pos ^ ((pos >> 3) & 1)) << 1) | c4;
   else return ((pos ^ ((pos >> 3) & 1)) << 2) | (c4 ^ ((pos >> 1) & 3));
 }
 template <int CI>
-__device__ inline void conv_a_slot(int s, int &pos, int &c4) {  // inverse of conv_a_unit (both xors are involutions)
+__host__ __device__ inline void conv_a_slot(int s, int &pos, int &c4) {  // inverse of conv_a_unit (both xors are involutions)
   if constexpr (CI == 4) { pos = s; c4 = 0; }
   else if constexpr (CI == 8) { const int pp = s >> 1; pos = pp ^ ((pp >> 3) & 1); c4 = s & 1; }
   else { const int pp = s >> 2; pos = pp ^ ((pp >> 3) & 1); c4 = (s & 3) ^ ((pos >> 1) & 3); }
@@ -549,6 +549,10 @@ __global__ __launch_bounds__(kConvAThreads) void k_conv_a(const ConvArgs a) {
   }
 }
 
+}  // namespace dr
+#include "conv_march.h"  // k_conv_m: marching producer/consumer kernel for the stride-1 3x3 / 3x3x3 layers
+namespace dr {
+
 // ------------------------------------------------------------------------------------------------
 // Host side: logical layer description -> packed weights, tap table, tile plan, launches.
 
@@ -572,7 +576,9 @@ struct ConvFuse {  // FeatureNet skip pair fused into the staging step of the la
 struct ConvLaunch {
   ConvArgs args;
   int ci, ct, pt, fz = 0;
-  int async = 0;  // 1: k_conv_a (persistent, LDS-DMA staged, 512 threads)
+  int async = 0;  // 1: k_conv_a (persistent, LDS-DMA staged, 512 threads); 2: k_conv_m (marching, 8 consumer + 2 producer waves)
+  MarchArgs march{};
+  int nup = 0;    // k_conv_m: K chunks per input plane
   dim3 grid;
   size_t lds_bytes;
   double flops;  // useful (algorithmic) flops of this launch
@@ -622,14 +628,22 @@ struct ConvPlanOut {
 
 struct DeviceArena {  // owns small device buffers created while planning (weights, tables)
   std::vector<void *> ptrs;
+  int *err_flag = nullptr;  // where k_conv_m reports a wait that gave up (device-visible memory owned by the caller)
+  bool host_only = false;   // planning without a device (tests/cpp/march_emul.hip): the "uploads" stay in host memory
   template <class T>
   T *upload(const std::vector<T> &h) {
+    if (host_only) {
+      T *d = static_cast<T *>(malloc(std::max<size_t>(h.size() * sizeof(T), 16)));
+      memcpy(d, h.data(), h.size() * sizeof(T));
+      ptrs.push_back(d);
+      return d;
+    }
     T *d = dalloc<T>(h.size());
     DR_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     ptrs.push_back(d);
     return d;
   }
-  ~DeviceArena() { for (void *p : ptrs) (void)hipFree(p); }
+  ~DeviceArena() { for (void *p : ptrs) { if (host_only) free(p); else (void)hipFree(p); } }
 };
 
 // Measured-best plans for known layer shapes (tools/tune_conv.sh -> conv_tuned.h); anything else uses the cost model.
@@ -645,6 +659,49 @@ inline bool conv_instance_exists(int ci, int ct) {
 }
 inline bool conv_a_instance_exists(int ci, int ct, int pt) {
   return (pt == 2 || pt == 4) && ((ci == 4 && ct == 1) || ((ci == 8 || ci == 16) && (ct == 1 || ct == 2)));
+}
+inline bool conv_m_instance_exists(int ci, int nup, int ct, int pt) {
+  if (pt != 2 && pt != 4) return false;
+  if (ct == 2) return ci == 16 && nup == 9 && pt == 2;  // (CT = 2, PT = 4 needs more than the 168 registers three waves per SIMD leave)
+  return ct == 1 && ((ci == 8 && nup == 6) || (ci == 16 && (nup == 12 || nup == 9)));
+}
+// DR_CONV_MARCH: 0 = never plan k_conv_m, 1 = rank it with the other families (default), 2 = prefer it wherever it applies (A/B hook)
+inline int conv_march_policy() {
+  if (const char *e = getenv("DR_CONV_MARCH")) return atoi(e);
+  return 1;
+}
+struct MarchShape {  // derived geometry of a k_conv_m candidate
+  int nup, npi, npo, ns, tyi, txi, np, ps, r;
+  size_t wbytes, lds_bytes;
+  long long steps;
+  int grid;
+  bool ok;
+};
+inline MarchShape march_shape(int KZ, int ntp, int Cin, int ci, int ct, int pt, int ty, int txt, int SX, int exy, int exx, int nPD, int nPH, int nPW, int CTtot) {
+  MarchShape m{};
+  const int tpc = 16 / ci;
+  if (Cin % ci || ntp % tpc || CTtot % ct || ty * txt != kMarchConsumers * pt) return m;
+  m.nup = ntp / tpc;
+  if (!conv_m_instance_exists(ci, m.nup, ct, pt)) return m;
+  const int npass = Cin / ci;
+  if (npass > 2) return m;
+  m.npi = KZ == 1 ? npass : 1; m.npo = KZ == 1 ? 1 : npass; m.ns = KZ * m.npi;
+  m.tyi = ty - 1 + exy; m.txi = (txt * 16 - 1) * SX + exx; m.np = m.tyi * m.txi;
+  if (m.np >= 65536) return m;
+  m.ps = cdiv(((m.np + 15) & ~15) * (ci / 4), 128) * 128;
+  if (m.ps / 128 > kMarchMaxIt) return m;
+  m.wbytes = (size_t)m.ns * m.nup * ct * 1024;
+  const size_t fixed = m.wbytes + kMarchFlagInts * 4;
+  if (fixed >= kConvMaxLds) return m;
+  const int rmin = KZ == 3 ? 3 : m.npi + 1, rmax = KZ == 3 ? 4 : 2 * m.npi + 2;
+  m.r = (int)std::min<size_t>(rmax, (kConvMaxLds - fixed) / ((size_t)m.ps * 16));
+  if (m.r < rmin) return m;
+  m.lds_bytes = (size_t)m.r * m.ps * 16 + fixed;
+  m.steps = (long long)cdiv(nPH, ty) * cdiv(nPW, txt * 16) * nPD;
+  const int split = CTtot / ct;
+  m.grid = 8 * cdiv((int)std::min<long long>(m.steps, std::max(8, 256 / split)), 8);
+  m.ok = true;
+  return m;
 }
 inline size_t conv_a_slots(int np, int ci) { return (size_t)cdiv(((np + 1) & ~1) * (ci / 4), 512) * 512; }
 // which kernel family the planner may use: 0 = k_conv only, 1 = k_conv_a only (falls back to k_conv when no async plan
@@ -747,6 +804,31 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
               cands.push_back({cost, ci, pt, ct, tz, ty, txt, tzi, tyi, txi, 1});
             }
           }
+    }
+  }
+  // k_conv_m: the stride-1 3x3 / 3x3x3 layers on the marching producer/consumer kernel (conv_march.h)
+  const int march_policy = fz ? 0 : conv_march_policy();
+  const bool march_ok = march_policy >= 1 && ncls == 1 && !L.transposed && mode != CONV_X8 && L.kh == 3 && L.kw == 3 && (L.kd == 1 || L.kd == 3) &&
+                        SZ == 1 && SY == 1 && L.sw == 1;
+  const int march_ntp = march_ok ? 3 * (int)cx[0].t.size() : 0;  // taps per input plane
+  if (march_ok) {
+    for (int ci : {16, 8}) {
+      if (ci == 8 && L.Cin != 8) continue;
+      for (int pt : {2, 4})
+        for (int ty = 1; ty <= kMarchConsumers * pt; ty *= 2) {
+          const int txt = kMarchConsumers * pt / ty;
+          if ((ty > 1 && ty / 2 >= nPH) || (txt > 1 && (txt / 2) * 16 >= nPW)) continue;
+          for (int ct : {2, 1}) {
+            const MarchShape ms = march_shape(L.kd, march_ntp, L.Cin, ci, ct, pt, ty, txt, SX, exy, exx, nPD, nPH, nPW, CTtot);
+            if (!ms.ok) continue;
+            const double spw = std::ceil((double)ms.steps / ms.grid);
+            const double unit = ms.ns * ms.nup * 4.0 * ct * pt * 64.0;  // MFMA cycles of a step per SIMD (two consumer waves each)
+            const double startup = (double)ms.lds_bytes / 16.0 + 3000.0;
+            double cost = ms.npo * (spw * unit * 1.02 + startup);
+            if (march_policy >= 2) cost *= 1e-3;
+            cands.push_back({cost, ci, pt, ct, 1, ty, txt, L.kd, ms.tyi, ms.txi, 2});
+          }
+        }
     }
   }
   const bool sync_too = policy != 1 || cands.empty();
@@ -902,7 +984,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   a.nuMax = nu_max;
   cl.lds_bytes = (size_t)TZI * TYI * TXI * CIS * 4 + (size_t)nu_max * CT * 1024 + (size_t)nu_max * TPC * 4 + 64;
   a.zero16 = nullptr; a.a_slots = 0; a.a_wbufs = 1;
-  if (ASYNC) {
+  if (ASYNC == 1) {
     cl.async = 1;
     a.zero16 = arena.upload(std::vector<float>(4, 0.f));
     a.a_slots = (int)conv_a_slots(TZI * TYI * TXI, CI);
@@ -916,6 +998,31 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
     const int wpc = cl.lds_bytes * 2 <= kConvMaxLds ? 2 : 1;
     const int want = std::max(1, std::min(ntiles, 256 * wpc / split));
     cl.grid = dim3(8 * cdiv(want, 8), 1, split);
+  }
+  if (ASYNC == 2) {
+    const MarchShape ms = march_shape(L.kd, march_ntp, L.Cin, CI, CT, PT, TY, TXT, SX, exy, exx, nPD, nPH, nPW, CTtot);
+    if (!ms.ok) fail(DR_ERR_ARG, "plan_conv: inconsistent k_conv_m plan");
+    cl.async = 2; cl.nup = ms.nup;
+    a.zero16 = arena.upload(std::vector<float>(4, 0.f));
+    a.a_slots = 0; a.a_wbufs = 0;
+    MarchArgs &m = cl.march;
+    std::vector<int> tap2d((size_t)ms.nup * TPC, 0);
+    {
+      const DimTaps &Y = *classes[0].y, &X = *classes[0].x;
+      int n = 0;
+      for (size_t iy = 0; iy < Y.t.size(); ++iy) for (size_t ix = 0; ix < X.t.size(); ++ix, ++n) tap2d[n] = Y.off[iy] * TXI + X.off[ix];
+    }
+    m.tap2d = arena.upload(tap2d);
+    m.geo.KZ = L.kd; m.geo.NPI = ms.npi; m.geo.Dc = L.kd == 3 ? nPD : 1;
+    m.NPO = ms.npo;
+    m.colsH = cdiv(nPH, TY); m.colsW = cdiv(nPW, TXT * 16);
+    m.ncols = (L.kd == 3 ? 1 : nPD) * m.colsH * m.colsW;
+    m.R = ms.r; m.PS = ms.ps; m.NP = ms.np; m.nit = ms.ps / 128;
+    m.wsec = ms.nup * CT * 64; m.NU = L.kd * ms.nup;
+    m.steps = (int)ms.steps;
+    m.err = arena.err_flag;
+    cl.lds_bytes = ms.lds_bytes;
+    cl.grid = dim3(ms.grid, 1, CTtot / CT);
   }
   cl.flops = flops;
   R.launches.push_back(cl);
@@ -944,7 +1051,27 @@ inline void launch_conv_a_inst(const ConvLaunch &c, hipStream_t st) {
   conv_allow_big_lds(reinterpret_cast<const void *>(&k_conv_a<CI, CT, PT>), done, c.lds_bytes);
   hipLaunchKernelGGL((k_conv_a<CI, CT, PT>), c.grid, dim3(kConvAThreads), c.lds_bytes, st, c.args);
 }
+template <int CI, int NUP, int CT, int PT>
+inline void launch_conv_m_inst(const ConvLaunch &c, hipStream_t st) {
+  static std::atomic<unsigned long long> done{0};
+  conv_allow_big_lds(reinterpret_cast<const void *>(&k_conv_m<CI, NUP, CT, PT>), done, c.lds_bytes);
+  hipLaunchKernelGGL((k_conv_m<CI, NUP, CT, PT>), c.grid, dim3(kMarchThreads), c.lds_bytes, st, c.args, c.march);
+}
 inline void launch_conv(const ConvLaunch &c, hipStream_t st) {
+  if (c.async == 2) {
+#define DR_CONV_M_CASE(CI_, NUP_, CT_)                                          \
+  if (c.ci == CI_ && c.nup == NUP_ && c.ct == CT_) {                            \
+    if (c.pt == 4) launch_conv_m_inst<CI_, NUP_, CT_, 4>(c, st);                \
+    else launch_conv_m_inst<CI_, NUP_, CT_, 2>(c, st);                          \
+    return;                                                                     \
+  }
+    DR_CONV_M_CASE(8, 6, 1)
+    DR_CONV_M_CASE(16, 12, 1)
+    DR_CONV_M_CASE(16, 9, 1)
+#undef DR_CONV_M_CASE
+    if (c.ci == 16 && c.nup == 9 && c.ct == 2 && c.pt == 2) { launch_conv_m_inst<16, 9, 2, 2>(c, st); return; }
+    fail(DR_ERR_ARG, "launch_conv: no marching instance CI=%d NUP=%d CT=%d PT=%d", c.ci, c.nup, c.ct, c.pt);
+  }
   if (c.async) {
 #define DR_CONV_A_CASE(CI_, CT_)                                                \
   if (c.ci == CI_ && c.ct == CT_) {                                             \

@@ -168,6 +168,8 @@ class MvsEngine {
     std::vector<float> lut(256);
     for (int i = 0; i < 256; ++i) lut[i] = (float)((double)(float)i / 255.0);
     lut_ = consts_.upload(lut);
+    DR_HIP(hipHostMalloc((void **)&march_err_, sizeof(int), hipHostMallocDefault));  // pinned, device-visible: k_conv_m raises it when a ring wait gives up
+    *march_err_ = 0;
     worker_ = std::thread(&MvsEngine::loop, this);
   }
   ~MvsEngine() {
@@ -184,6 +186,7 @@ class MvsEngine {
     release();
     if (h_out_) (void)hipHostFree(h_out_);
     if (h_in_) (void)hipHostFree(h_in_);
+    if (march_err_) (void)hipHostFree(march_err_);
     (void)hipStreamSynchronize(side_);
     for (auto e : {ev_fork_, ev_feat2_, ev_feat3_}) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(side_);
@@ -239,6 +242,7 @@ class MvsEngine {
     float t = 0;
     DR_HIP(hipEventElapsedTime(&t, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    check_march();
     if (ms) *ms = t;
   }
   // Time the first `k` candidates of every convolution layer's plan ranking in place (hipEvents, layer alone on the
@@ -274,13 +278,13 @@ class MvsEngine {
         const ConvLaunch c = o.replan(r);
         const float t = time_launch(c);
         if (print && atoi(getenv("DR_CONV_PRINT")) > 1)
-          fprintf(stderr, "  cand %-12s rank %2d %s<%d,%d,%d> tile %dx%dx%d lds %zu KB grid %u: %.4f ms\n", o.name.c_str(), r, c.async ? "async" : "", c.ci, c.ct, c.pt,
+          fprintf(stderr, "  cand %-12s rank %2d %s<%d,%d,%d> tile %dx%dx%d lds %zu KB grid %u: %.4f ms\n", o.name.c_str(), r, c.async == 2 ? "march" : (c.async ? "async" : ""), c.ci, c.ct, c.pt,
                   c.args.TZ, c.args.TY, c.args.TXT * 16, c.lds_bytes >> 10, c.grid.x, t);
         if (t < best * 0.98f) { best = t; best_rank = r; best_c = c; }
       }
       if (print) fprintf(stderr, "autotune %-12s model %.4f ms %s<%d,%d,%d> tile %dx%dx%d -> rank %d %.4f ms %s<%d,%d,%d> tile %dx%dx%d\n", o.name.c_str(), t0,
-                         o.conv.async ? "async" : "", o.conv.ci, o.conv.ct, o.conv.pt, o.conv.args.TZ, o.conv.args.TY, o.conv.args.TXT * 16, best_rank, best,
-                         best_c.async ? "async" : "", best_c.ci, best_c.ct, best_c.pt, best_c.args.TZ, best_c.args.TY, best_c.args.TXT * 16);
+                         o.conv.async == 2 ? "march" : (o.conv.async ? "async" : ""), o.conv.ci, o.conv.ct, o.conv.pt, o.conv.args.TZ, o.conv.args.TY, o.conv.args.TXT * 16, best_rank, best,
+                         best_c.async == 2 ? "march" : (best_c.async ? "async" : ""), best_c.ci, best_c.ct, best_c.pt, best_c.args.TZ, best_c.args.TY, best_c.args.TXT * 16);
       if (print && best_rank != 0)
         fprintf(stderr, "TUNED    {%s,   %d, %d, %d, %d, %d, %d, %d},  // %s %.4f -> %.4f ms\n", o.sig.c_str(), best_c.ci, best_c.ct, best_c.pt, best_c.args.TZ,
                 best_c.args.TY, best_c.args.TXT, best_c.async, o.name.c_str(), t0, best);
@@ -337,6 +341,7 @@ class MvsEngine {
     try { forward(nullptr, cut[phase], cut[phase + 1]); } catch (...) { phase_mode_ = false; throw; }
     phase_mode_ = false;
     DR_HIP(hipStreamSynchronize(stream_));
+    check_march();
   }
   void device_tensor(const char *name, void **dptr, size_t *n) {
     std::unique_lock<std::mutex> lk(mu_);
@@ -385,7 +390,8 @@ class MvsEngine {
       ms.push_back(t);
       const Op &o = ops_[i];
       char kn[64] = "misc";
-      if (o.kind == Op::CONV && o.conv.async) snprintf(kn, sizeof kn, "k_conv_a<%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt);
+      if (o.kind == Op::CONV && o.conv.async == 2) snprintf(kn, sizeof kn, "k_conv_m<%d,%d,%d,%d>", o.conv.ci, o.conv.nup, o.conv.ct, o.conv.pt);
+      else if (o.kind == Op::CONV && o.conv.async) snprintf(kn, sizeof kn, "k_conv_a<%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt);
       else if (o.kind == Op::CONV && o.conv.fz) snprintf(kn, sizeof kn, "k_conv<%d,%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt, o.conv.fz);
       else if (o.kind == Op::CONV) snprintf(kn, sizeof kn, "k_conv<%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt);
       else if (o.kind == Op::COSTVOL) snprintf(kn, sizeof kn, "k_costvol<%d>", 32 >> (o.stage - 1));
@@ -438,6 +444,7 @@ class MvsEngine {
           DR_HIP(hipMemcpyAsync(h_out_ + 2 * (n / 4), T("depth3").d, n, hipMemcpyDeviceToHost, stream_));
           DR_HIP(hipMemcpyAsync(h_out_ + 3 * (n / 4), T("conf3").d, n, hipMemcpyDeviceToHost, stream_));
           DR_HIP(hipStreamSynchronize(stream_));
+          check_march();
           has_output_ = true;
         } catch (const std::exception &e) { worker_error_ = e.what(); }
         unprocessed_ = false;
@@ -583,6 +590,7 @@ class MvsEngine {
   }
   void build_plan(int H, int W, int V) {
     plan_arena_.reset(new DeviceArena());
+    plan_arena_->err_flag = march_err_;
     if (h_out_) { (void)hipHostFree(h_out_); h_out_ = nullptr; }
     if (h_in_) { (void)hipHostFree(h_in_); h_in_ = nullptr; }
     DR_HIP(hipHostMalloc((void **)&h_out_, (size_t)H * W * 16, hipHostMallocDefault));
@@ -868,6 +876,11 @@ class MvsEngine {
   size_t fork_lo_ = 0, fork_hi_ = 0, feat2_op_ = 0;  // ops [fork_lo_, fork_hi_) = fn.skip2 .. fn.out3
 
   int device_;
+  int *march_err_ = nullptr;
+  // called after a stream synchronise: a marching convolution that gave up a wait leaves garbage behind -- report it, never return it
+  void check_march() {
+    if (march_err_ && *march_err_) { const int c = *march_err_; *march_err_ = 0; fail(DR_ERR_DEVICE, "k_conv_m: a ring wait gave up (code %d): the LDS producer/consumer protocol stalled", c); }
+  }
   Blob blob_;
   hipStream_t stream_ = nullptr;
   DeviceArena consts_;
@@ -988,6 +1001,7 @@ int drm_debug_conv(int device, const float *in, int D, int H, int W, int Cin, co
     if (hipGetDeviceCount(&n) != hipSuccess || n <= device) fail(DR_ERR_DEVICE, "no HIP device %d", device);
     DR_HIP(hipSetDevice(device));
     DeviceArena arena;
+    arena.err_flag = arena.upload(std::vector<int>(1, 0));
     ConvLayer L;
     L.Cin = Cin; L.Cout = Cout; L.kd = kd; L.kh = kh; L.kw = kw; L.sd = sd; L.sh = sh; L.sw = sw;
     L.transposed = transposed != 0; L.weight = weight; L.relu = relu != 0;
@@ -1013,6 +1027,14 @@ int drm_debug_conv(int device, const float *in, int D, int H, int W, int Cin, co
     for (auto &cl : P.launches) launch_conv(cl, nullptr);
     DR_HIP(hipDeviceSynchronize());
     DR_HIP(hipGetLastError());
+    int march_err = 0;
+    DR_HIP(hipMemcpy(&march_err, arena.err_flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (march_err) fail(DR_ERR_DEVICE, "k_conv_m: a ring wait gave up (code %d)", march_err);
+    if (getenv("DR_CONV_PRINT")) {
+      const ConvLaunch &c = P.launches.at(0);
+      fprintf(stderr, "debug_conv: %s<%d,%d,%d> nup %d tile %dx%dx%d lds %zu grid %ux%u (%d candidates)\n", c.async == 2 ? "march" : (c.async ? "async" : "sync"), c.ci, c.ct, c.pt,
+              c.nup, c.args.TZ, c.args.TY, c.args.TXT * 16, c.lds_bytes, c.grid.x, c.grid.z, P.ncand);
+    }
     DR_HIP(hipMemcpy(out, d_out, on * 4, hipMemcpyDeviceToHost));
     if (out_dims) { out_dims[0] = oD; out_dims[1] = oH; out_dims[2] = oW; }
   });

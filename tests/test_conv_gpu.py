@@ -106,3 +106,27 @@ def test_every_plan_candidate_is_correct(case, monkeypatch):
         run_case(case)
         if rank > 160:  # beyond the candidate count the last one repeats
             break
+
+
+# ---- k_conv_m: the marching producer/consumer kernel (conv_march.h).  DR_CONV_MARCH=2 puts its candidates first in the
+# planner's ranking; the shapes are large enough for several steps per workgroup (ring wrap-around, column changes in
+# the middle of a range, both channel-pass structures).
+MARCH = [
+    ("march xpair 3x3x3 16->8", (20, 96, 160), 16, 8, (3, 3, 3), (1, 1, 1), False, True, "none"),
+    ("march xpair 3x3x3 32->8 (two outer passes)", (12, 64, 128), 32, 8, (3, 3, 3), (1, 1, 1), False, True, "none"),
+    ("march xpair 3x3x3 8->8", (8, 128, 256), 8, 8, (3, 3, 3), (1, 1, 1), False, True, "none"),
+    ("march 3x3x3 16->16", (16, 64, 96), 16, 16, (3, 3, 3), (1, 1, 1), False, True, "none"),
+    ("march xpair 3x3 8->8, 7 views", (7, 96, 192), 8, 8, (1, 3, 3), (1, 1, 1), False, True, "none"),
+    ("march 3x3 16->16 +skip, 7 views", (7, 80, 112), 16, 16, (1, 3, 3), (1, 1, 1), False, True, "same"),
+    ("march 3x3 32->32 (inner passes), 7 views", (7, 48, 80), 32, 32, (1, 3, 3), (1, 1, 1), False, True, "none"),
+    ("march 3x3 32->16, 7 views", (7, 64, 96), 32, 16, (1, 3, 3), (1, 1, 1), False, False, "none"),
+    ("march odd sizes 3x3x3 16->8", (5, 35, 70), 16, 8, (3, 3, 3), (1, 1, 1), False, True, "none"),
+]
+
+
+@pytest.mark.parametrize("case", MARCH, ids=[c[0] for c in MARCH])
+def test_marching_kernel_candidates(case, monkeypatch):
+    monkeypatch.setenv("DR_CONV_MARCH", "2")
+    for rank in range(8):  # the marching candidates (tile shapes, PT, CT) lead the ranking; later ranks repeat other families
+        monkeypatch.setenv("DR_CONV_RANK", str(rank))
+        run_case(case)

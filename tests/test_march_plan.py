@@ -1,0 +1,27 @@
+"""CPU: the marching convolution kernel's planner, index arithmetic and ring protocol (tandem_amd/csrc/conv_march.h,
+march_plan.h) executed on the host by tests/cpp/march_emul.hip -- every k_conv_m plan candidate of eight layer types
+(CostRegNet conv0 / conv2 module.py:546-552, FeatureNet's 3x3 layers module.py:461-494) against a direct convolution.
+No device code runs here; the GPU side is tests/test_conv_gpu.py."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="needs hipcc to compile the host emulation")
+def test_march_emulation_matches_direct_convolution(tmp_path):
+    exe = tmp_path / "march_emul"
+    subprocess.check_call([HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-Wno-unused-function",
+                           "-Wno-pass-failed", "-Wno-unused-result", os.path.join(ROOT, "tests", "cpp", "march_emul.hip"), "-o", str(exe)])
+    out = subprocess.run([str(exe), "40"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if " plan " in l]
+    assert len(lines) >= 30 and all(" ok " in l for l in lines), out.stdout[-4000:]
+    # every instance family and both pass structures were exercised
+    text = out.stdout
+    for needle in ("ci=8 nup=6", "ci=16 nup=12", "ci=16 nup=9", "ct=2", "pt=4", "NPI=2", "NPO=2"):
+        assert needle in text, needle
