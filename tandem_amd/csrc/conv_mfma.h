@@ -566,6 +566,7 @@ struct ConvLayer {  // logical description (torch semantics)
   const float *weight = nullptr;    // (Cout,Cin,kd,kh,kw) or transposed (Cin,Cout,kd,kh,kw)
   std::vector<float> scale, bias;   // per Cout (folded BN / conv bias); empty -> 1 / 0
   bool relu = false;
+  int out_pad = 0;                  // the output tensor carries a border of this many pixels in H and W (`out` points at its first interior pixel)
 };
 
 struct ConvFuse {  // FeatureNet skip pair fused into the staging step of the layer that consumes it (device pointers)
@@ -959,7 +960,11 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   a.scale = arena.upload(sc); a.bias = arena.upload(bi); a.add = add; a.tapoff = arena.upload(tapoff);
   a.cls = arena.upload(cls);
   a.inD = inD; a.inH = inH; a.inW = inW; a.inC = inC;
-  a.outD = R.outD; a.outH = R.outH; a.outW = outWv; a.outC = outCv;
+  a.outD = R.outD; a.outH = R.outH + 2 * L.out_pad; a.outW = outWv; a.outC = outCv;
+  if (L.out_pad) {  // bordered output: only the strides change (the x border is a whole number of XPAIR / X8 output groups or the mode is refused)
+    if ((2 * L.out_pad) % shifts) fail(DR_ERR_ARG, "plan_conv: an output border of %d pixels does not fit the %d-wide output groups", L.out_pad, shifts);
+    a.outW = outWv + 2 * L.out_pad / shifts;
+  }
   a.nPD = nPD; a.nPH = nPH; a.nPW = nPW;
   a.sz = SZ; a.sy = SY; a.sx = SX; a.pz = PZ; a.py = PY; a.px = PX;
   a.omz = cz[0].om; a.omy = cy[0].om; a.omx = cx[0].om;

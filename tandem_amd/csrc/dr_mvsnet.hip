@@ -104,7 +104,9 @@ static void world_to_pixel(const float *K9, const double *w2c, double *o) {
 struct DevTensor {
   float *d = nullptr;
   int D = 0, H = 0, W = 0, C = 0;
-  size_t n() const { return (size_t)D * H * W * C; }
+  int pad = 0;  // zero border (pixels) around every H x W plane in memory; H and W stay the logical size
+  size_t n() const { return (size_t)D * (H + 2 * pad) * (W + 2 * pad) * C; }         // floats in memory
+  float *interior() const { return d + ((size_t)pad * (W + 2 * pad) + pad) * C; }    // first logical pixel
 };
 
 struct Op {
@@ -366,12 +368,17 @@ class MvsEngine {
     require_config();
     DR_HIP(hipSetDevice(device_));
     const DevTensor &t = T(name);
-    if (n) *n = t.n();
+    const size_t logical = (size_t)t.D * t.H * t.W * t.C;
+    if (n) *n = logical;
     if (dims) { dims[0] = t.D; dims[1] = t.H; dims[2] = t.W; dims[3] = t.C; }
     if (out) {
-      if (t.n() > n_max) fail(DR_ERR_ARG, "get_tensor(%s): need %zu floats, have %zu", name, t.n(), n_max);
+      if (logical > n_max) fail(DR_ERR_ARG, "get_tensor(%s): need %zu floats, have %zu", name, logical, n_max);
       DR_HIP(hipStreamSynchronize(stream_));
-      DR_HIP(hipMemcpy(out, t.d, t.n() * 4, hipMemcpyDeviceToHost));
+      if (!t.pad) DR_HIP(hipMemcpy(out, t.d, logical * 4, hipMemcpyDeviceToHost));
+      else  // bordered tensor: the caller gets the logical (D, H, W, C) block
+        for (int z = 0; z < t.D; ++z)
+          DR_HIP(hipMemcpy2D(out + (size_t)z * t.H * t.W * t.C, (size_t)t.W * t.C * 4, t.interior() + (size_t)z * (t.H + 2 * t.pad) * (t.W + 2 * t.pad) * t.C,
+                             (size_t)(t.W + 2 * t.pad) * t.C * 4, (size_t)t.W * t.C * 4, t.H, hipMemcpyDeviceToHost));
     }
   }
   void profile(std::string &names, std::vector<float> &ms) {
@@ -459,9 +466,10 @@ class MvsEngine {
     if (it == tensors_.end()) fail(DR_ERR_ARG, "unknown tensor '%s'", name.c_str());
     return it->second;
   }
-  DevTensor &alloc(const std::string &name, int D, int H, int W, int C) {
-    DevTensor t; t.D = D; t.H = H; t.W = W; t.C = C;
+  DevTensor &alloc(const std::string &name, int D, int H, int W, int C, int pad = 0) {
+    DevTensor t; t.D = D; t.H = H; t.W = W; t.C = C; t.pad = pad;
     t.d = dalloc<float>(t.n());
+    if (pad) DR_HIP(hipMemset(t.d, 0, t.n() * 4));  // the border is written once, here; producers only touch the interior
     tensors_[name] = t;
     return tensors_[name];
   }
@@ -505,13 +513,13 @@ class MvsEngine {
   // Adds one convolution layer (possibly several launches) to the plan; returns the output tensor.
   DevTensor &add_conv(const std::string &opname, const std::string &wname, const std::string &bnname, bool conv_bias, bool relu,
                       const DevTensor &in, const std::string &outname, int k3d, int kh, int kw, int sd, int sh, int sw,
-                      bool transposed, ConvMode mode, const DevTensor *add, int add_mode, const ConvFuse *fz = nullptr) {
+                      bool transposed, ConvMode mode, const DevTensor *add, int add_mode, const ConvFuse *fz = nullptr, int out_pad = 0) {
     const HostTensor &w = blob_.at(wname + ".weight");
     ConvLayer L;
     L.transposed = transposed;
     const int c_out = transposed ? w.dims[1] : w.dims[0], c_in_real = transposed ? w.dims[0] : w.dims[1];
     L.Cout = c_out; L.Cin = in.C;
-    L.kd = k3d; L.kh = kh; L.kw = kw; L.sd = sd; L.sh = sh; L.sw = sw; L.relu = relu;
+    L.kd = k3d; L.kh = kh; L.kw = kw; L.sd = sd; L.sh = sh; L.sw = sw; L.relu = relu; L.out_pad = out_pad;
     std::vector<float> padded;
     if (c_in_real != in.C) {  // RGB -> RGB0: zero-pad the input-channel axis of the weights
       if (transposed || c_in_real > in.C) fail(DR_ERR_ARG, "%s: channel mismatch", opname.c_str());
@@ -528,16 +536,16 @@ class MvsEngine {
       auto cz = axis_classes(k3d, sd, transposed, in.D), cy = axis_classes(kh, sh, transposed, in.H), cx = axis_classes(kw, sw, transposed, in.W);
       P0.outD = transposed ? in.D * sd : cz[0].npos; P0.outH = transposed ? in.H * sh : cy[0].npos; P0.outW = transposed ? in.W * sw : cx[0].npos;
     }
-    DevTensor &out = alloc(outname, P0.outD, P0.outH, P0.outW, c_out);
+    DevTensor &out = alloc(outname, P0.outD, P0.outH, P0.outW, c_out, out_pad);
     ConvFuse fzc{};
     if (fz) fzc = *fz;
     const bool fused = fz != nullptr;
-    ConvPlanOut P = plan_conv(L, mode, in.d, in.D, in.H, in.W, in.C, out.d, add ? add->d : nullptr, add_mode, *plan_arena_, 0, fz);
+    ConvPlanOut P = plan_conv(L, mode, in.d, in.D, in.H, in.W, in.C, out.interior(), add ? add->d : nullptr, add_mode, *plan_arena_, 0, fz);
     // the autotuner re-plans this layer with another candidate of the cost model's ranking (weights are kept alive)
     auto keep = std::make_shared<std::vector<float>>(L.weight, L.weight + (size_t)L.Cout * L.Cin * k3d * kh * kw);
     ConvLayer Lc = L;
     const float *in_d = in.d, *add_d = add ? add->d : nullptr;
-    float *out_d = out.d;
+    float *out_d = out.interior();
     const int iD = in.D, iH = in.H, iW = in.W, iC = in.C, ncand = P.ncand;
     auto replan = [this, keep, Lc, mode, in_d, iD, iH, iW, iC, out_d, add_d, add_mode, fzc, fused](int rank) mutable {
       Lc.weight = keep->data();
@@ -611,10 +619,12 @@ class MvsEngine {
     DevTensor &c1a = cbr2("fn.conv2.0", fn + "conv2.0", c2, 5, 2, CONV_NORMAL);
     DevTensor &c1b = cbr2("fn.conv2.1", fn + "conv2.1", c1a, 3, 1, CONV_NORMAL);
     DevTensor &c1 = cbr2("fn.conv2.2", fn + "conv2.2", c1b, 3, 1, CONV_NORMAL);
-    add_conv("fn.out1", fn + "out.stage1", "", false, false, c1, "feat1", 1, 1, 1, 1, 1, 1, false, CONV_NORMAL, nullptr, 0);
+    // feature maps handed to the cost volume carry a one-pixel zero border (k_costvol2); DR_COSTVOL_V1=1: the unpadded layout + k_costvol
+    const int fpad = costvol_v1_ ? 0 : 1;
+    add_conv("fn.out1", fn + "out.stage1", "", false, false, c1, "feat1", 1, 1, 1, 1, 1, 1, false, CONV_NORMAL, nullptr, 0, nullptr, fpad);
     fork_lo_ = ops_.size();
     DevTensor &i2 = add_skip("fn.skip2", fn + "skip.stage2", c2, "inter2", c1);
-    add_conv("fn.out2", fn + "out.stage2", "", false, false, i2, "feat2", 1, 3, 3, 1, 1, 1, false, CONV_NORMAL, nullptr, 0);
+    add_conv("fn.out2", fn + "out.stage2", "", false, false, i2, "feat2", 1, 3, 3, 1, 1, 1, false, CONV_NORMAL, nullptr, 0, nullptr, fpad);
     feat2_op_ = ops_.size() - 1;
     // stage 3: skip.stage3 (1x1, 8 -> 32, + upsampled inter2) is computed inside out.stage3's staging step -- the
     // 32-channel full-resolution tensor between them (275 MB at 640x480x7) is never written or read.  DR_NO_SKIP_FUSION=1: the two-kernel path.
@@ -623,10 +633,10 @@ class MvsEngine {
         i2.H * 2 == c3.H && i2.W * 2 == c3.W) {
       ConvFuse fz{c3.d, plan_arena_->upload(w3.data), plan_arena_->upload(blob_.at(fn + "skip.stage3.bias").data), i2.d, 8};
       DevTensor virt; virt.D = c3.D; virt.H = c3.H; virt.W = c3.W; virt.C = 32; virt.d = nullptr;  // inter3 exists in LDS only
-      add_conv("fn.out3", fn + "out.stage3", "", false, false, virt, "feat3", 1, 3, 3, 1, 1, 1, false, CONV_XPAIR, nullptr, 0, &fz);
+      add_conv("fn.out3", fn + "out.stage3", "", false, false, virt, "feat3", 1, 3, 3, 1, 1, 1, false, CONV_XPAIR, nullptr, 0, &fz, fpad);
     } else {
       DevTensor &i3 = add_skip("fn.skip3", fn + "skip.stage3", c3, "inter3", i2);
-      add_conv("fn.out3", fn + "out.stage3", "", false, false, i3, "feat3", 1, 3, 3, 1, 1, 1, false, CONV_XPAIR, nullptr, 0);
+      add_conv("fn.out3", fn + "out.stage3", "", false, false, i3, "feat3", 1, 3, 3, 1, 1, 1, false, CONV_XPAIR, nullptr, 0, nullptr, fpad);
     }
     fork_hi_ = ops_.size();
 
@@ -711,6 +721,7 @@ class MvsEngine {
       CostVolArgs &a = cv_[s - 1];
       memset(&a, 0, sizeof a);
       a.feat = T("feat" + std::to_string(s)).d;
+      a.fpad = T("feat" + std::to_string(s)).pad;
       a.vol = T("volume" + std::to_string(s)).d;
       a.V = V; a.h = h; a.w = w;
       a.dchunk = s == 1 ? 4 : (D >= 16 ? 8 : D);  // enough workgroups to fill 256 CUs at every stage
@@ -814,10 +825,15 @@ class MvsEngine {
           int pb = 256, xo = 1;  // r2 sweep: one output column per lane (4x the waves) beats the 4-column variant 0.204 -> 0.124 ms over the three stages
           if (const char *e = getenv("DR_PROB_BLOCK")) pb = std::max(64, std::min(256, atoi(e) / 64 * 64));  // tuning hooks
           if (const char *e = getenv("DR_PROB_XO")) xo = atoi(e) == 2 ? 2 : (atoi(e) == 4 ? 4 : 1);
-          const dim3 grid(cdiv(o.d1 * (o.d2 / xo), pb), cdiv(o.d0, zchunk));
-          if (xo == 4) hipLaunchKernelGGL(k_prob<4>, grid, dim3(pb), 0, stream_, o.p0, o.p1, o.p2, o.d0, o.d1, o.d2, zchunk);
-          else if (xo == 2) hipLaunchKernelGGL(k_prob<2>, grid, dim3(pb), 0, stream_, o.p0, o.p1, o.p2, o.d0, o.d1, o.d2, zchunk);
-          else hipLaunchKernelGGL(k_prob<1>, grid, dim3(pb), 0, stream_, o.p0, o.p1, o.p2, o.d0, o.d1, o.d2, zchunk);
+          dim3 grid(cdiv(o.d1 * (o.d2 / xo), pb), cdiv(o.d0, zchunk));
+          int gz = 0, nwg = 0;
+          if (!getenv("DR_PROB_LAUNCH_ORDER")) {  // XCD-band workgroup order (A/B hook: the plain 2-D launch order)
+            gz = (int)grid.y; nwg = (int)(grid.x * grid.y);
+            grid = dim3(8 * cdiv(nwg, 8));
+          }
+          if (xo == 4) hipLaunchKernelGGL(k_prob<4>, grid, dim3(pb), 0, stream_, o.p0, o.p1, o.p2, o.d0, o.d1, o.d2, zchunk, gz, nwg);
+          else if (xo == 2) hipLaunchKernelGGL(k_prob<2>, grid, dim3(pb), 0, stream_, o.p0, o.p1, o.p2, o.d0, o.d1, o.d2, zchunk, gz, nwg);
+          else hipLaunchKernelGGL(k_prob<1>, grid, dim3(pb), 0, stream_, o.p0, o.p1, o.p2, o.d0, o.d1, o.d2, zchunk, gz, nwg);
         }
           break;
         case Op::COSTVOL: {
@@ -831,6 +847,13 @@ class MvsEngine {
           CostVolArgs b = a;
           b.gx = cdiv(a.w, pxb); b.gz = cdiv(a.planes.D, a.dchunk); b.nwg = b.gx * b.gz * a.h;
           dim3 grid(8 * cdiv(b.nwg, 8));
+          if (a.fpad) {  // bordered feature maps: 4 channels per lane, no per-tap validity logic
+            b.gx = cdiv(a.w, 1024 / C); b.nwg = b.gx * b.gz * a.h;
+            grid = dim3(8 * cdiv(b.nwg, 8));
+            if (C == 32) hipLaunchKernelGGL((k_costvol2<32>), grid, dim3(256), 0, stream_, b);
+            else if (C == 16) hipLaunchKernelGGL((k_costvol2<16>), grid, dim3(256), 0, stream_, b);
+            else hipLaunchKernelGGL((k_costvol2<8>), grid, dim3(256), 0, stream_, b);
+          } else
           if (C == 32 && cpl == 8) hipLaunchKernelGGL((k_costvol<32, 8>), grid, dim3(256), 0, stream_, b);
           else if (C == 32) hipLaunchKernelGGL((k_costvol<32, 4>), grid, dim3(256), 0, stream_, b);
           else if (C == 16 && cpl == 8) hipLaunchKernelGGL((k_costvol<16, 8>), grid, dim3(256), 0, stream_, b);
@@ -872,6 +895,7 @@ class MvsEngine {
   hipEvent_t ev_fork_ = nullptr, ev_feat2_ = nullptr, ev_feat3_ = nullptr;
   bool side_enabled_ = true;
   // channels per lane of k_costvol for C >= 16 (measured: stage 2 0.210 -> 0.194 ms, stage 1 0.146 -> 0.143 ms with 4)
+  bool costvol_v1_ = getenv("DR_COSTVOL_V1") != nullptr;
   int cpl_wide_ = getenv("DR_COSTVOL_CPL") ? (atoi(getenv("DR_COSTVOL_CPL")) == 8 ? 8 : 4) : 4;
   size_t fork_lo_ = 0, fork_hi_ = 0, feat2_op_ = 0;  // ops [fork_lo_, fork_hi_) = fn.skip2 .. fn.out3
 

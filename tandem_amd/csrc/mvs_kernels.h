@@ -123,6 +123,7 @@ struct CostVolArgs {
   float nsrc_f;          // float(V-1)
   int view_aggregation;
   int gx, gz, nwg;       // workgroup grid: x-blocks per row, depth chunks, total (rows = nwg / (gx * gz))
+  int fpad;              // k_costvol2: the feature maps carry a zero border of this many pixels (1)
 };
 
 __device__ inline float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -244,6 +245,123 @@ __global__ __launch_bounds__(256) void k_costvol(const CostVolArgs a) {
   }
 }
 
+// k_costvol2: the same arithmetic on feature maps stored with a ONE-PIXEL ZERO BORDER ((h+2) x (w+2) per view), as a
+// software-pipelined flat loop over (plane, view).
+//  * Zero border: grid_sample's zero padding needs no per-tap logic.  A sample that is outside altogether (or behind the
+//    camera) is moved to (-1, -1), where tap 00 is the border's zero with weight 1 and the other taps have weight 0; a
+//    sample whose footprint is partly outside reads border zeros for the missing taps.  Products and their order are
+//    k_costvol's (0 * w instead of t * 0 for a missing tap).  Gone per (plane, view): four tap-validity flags and weight
+//    selects, the x1 / y1 clamps and three of the four address computations (one VGPR offset against two per-view
+//    scalar bases: rows y0 and y0 + 1; +C floats for x0 + 1).
+//  * Pipelining: k_costvol issued the four gathers of a (plane, view) and waited for them before it touched the next
+//    view -- with four waves per SIMD each iteration exposed most of an L2 round trip (PMC round 2: 541 cycles per
+//    wave-iteration against ~210 cycles of instruction issue).  Here the gathers of iteration i + 1 are issued before the
+//    arithmetic of iteration i (two tap sets in registers, used alternately), across view and plane boundaries.
+//  * The view index is a run-time loop variable (its matrix comes from scalar loads), the per-view ray coefficients are
+//    recomputed (6 FMAs) instead of held in 21 registers; the gate's cross-lane channel sum uses DPP, not ds_bpermute.
+struct CvTaps {
+  float4 t00, t01, t10, t11;
+  float w00, w01, w10, w11;
+};
+__device__ inline float cv_dpp_add(float s, int ctrl) {  // s + s[dpp permutation of the row]
+  if (ctrl == 0) return s + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  if (ctrl == 1) return s + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  return s + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0x141, 0xF, 0xF, true));                // row_half_mirror: lane i <-> 7 - i
+}
+template <int C>
+__global__ __launch_bounds__(256) void k_costvol2(const CostVolArgs a) {
+  constexpr int LPV = C / 4;            // lanes per pixel, 4 channels each
+  constexpr int PXB = 256 / LPV;        // pixels per block
+  const int tid = threadIdx.x, q = tid % LPV;
+  const int per = (a.nwg + 7) >> 3;     // XCD-aware order, as k_costvol
+  const int nid = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+  if (nid >= a.nwg) return;
+  const int bz = nid % a.gz, bxy = nid / a.gz;
+  const int x = (bxy % a.gx) * PXB + tid / LPV, y = bxy / a.gx;
+  const int d0 = bz * a.dchunk, d1 = min(a.planes.D, d0 + a.dchunk);
+  const bool live = x < a.w;
+  const int xc = live ? x : a.w - 1;    // dead lanes keep running for the cross-lane gate sum
+  const int h = a.h, w = a.w, nsrc = a.V - 1, wp = w + 2;
+  const size_t vplane = (size_t)(h + 2) * wp * C;  // floats per padded view
+  const float fw = (float)w, fh = (float)h, xf = (float)xc, yf = (float)y;
+
+  const float4 ref = ld4(a.feat + ((size_t)(y + 1) * wp + xc + 1) * C + q * 4);
+  const float4 gw = make_float4(a.gw[q * 4], a.gw[q * 4 + 1], a.gw[q * 4 + 2], a.gw[q * 4 + 3]);
+  const PixelPlanes pp = make_planes(a.planes, y, xc);
+  const float inv_n = a.view_aggregation ? a.nsrc_f : a.nsrc_f + 1.f;
+  const float *f00 = a.feat + ((size_t)wp + 1) * C + q * 4;  // pixel (0, 0) of view 0, this lane's channels
+
+  auto issue = [&](int d, int v, CvTaps &T) {
+    const float *m = a.M[v];  // wave-uniform: scalar loads
+    const float depth = pp.at(a.planes, d);
+    const float rx = m[0] * xf + m[1] * yf + m[2], ry = m[4] * xf + m[5] * yf + m[6], rz = m[8] * xf + m[9] * yf + m[10];
+    const float px = rx * depth + m[3], py = ry * depth + m[7], pz = rz * depth + m[11];
+    const float rcp = __builtin_amdgcn_rcpf(pz);
+    const float u = px * rcp, vv = py * rcp;
+    const bool inside = pz >= 0.001f && u > -1.f && u < fw && vv > -1.f && vv < fh;  // module.py:861,887; NaN fails too
+    const float uc = inside ? u : -1.f, vc = inside ? vv : -1.f;
+    const float fx0 = floorf(uc), fy0 = floorf(vc);
+    const float ax = uc - fx0, ay = vc - fy0, bx = 1.f - ax, by = 1.f - ay;
+    T.w00 = bx * by; T.w01 = ax * by; T.w10 = bx * ay; T.w11 = ax * ay;
+    const int o = ((int)fy0 * wp + (int)fx0) * C;
+    const float *r0 = f00 + (size_t)(v + 1) * vplane, *r1 = r0 + (size_t)wp * C;  // wave-uniform bases: rows y0 and y0 + 1
+    T.t00 = ld4(r0 + o); T.t01 = ld4(r0 + o + C); T.t10 = ld4(r1 + o); T.t11 = ld4(r1 + o + C);
+  };
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), s1 = acc;
+  auto consume = [&](int d, int v, const CvTaps &T) {
+    if (v == 0) {
+      acc = a.view_aggregation ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(ref.x * ref.x, ref.y * ref.y, ref.z * ref.z, ref.w * ref.w);
+      s1 = ref;
+    }
+    float4 wv;
+    wv.x = T.t00.x * T.w00 + T.t01.x * T.w01 + T.t10.x * T.w10 + T.t11.x * T.w11;
+    wv.y = T.t00.y * T.w00 + T.t01.y * T.w01 + T.t10.y * T.w10 + T.t11.y * T.w11;
+    wv.z = T.t00.z * T.w00 + T.t01.z * T.w01 + T.t10.z * T.w10 + T.t11.z * T.w11;
+    wv.w = T.t00.w * T.w00 + T.t01.w * T.w01 + T.t10.w * T.w10 + T.t11.w * T.w11;
+    if (a.view_aggregation) {
+      const float4 df = make_float4(wv.x - ref.x, wv.y - ref.y, wv.z - ref.z, wv.w - ref.w);
+      const float4 d2 = make_float4(df.x * df.x, df.y * df.y, df.z * df.z, df.w * df.w);
+      float s = 0.f;
+      s += gw.x * d2.x + gw.y * d2.y + gw.z * d2.z + gw.w * d2.w;
+      if constexpr (LPV >= 2) s = cv_dpp_add(s, 0);
+      if constexpr (LPV >= 4) s = cv_dpp_add(s, 1);
+      if constexpr (LPV >= 8) s = cv_dpp_add(s, 2);
+      const float g1 = fmaxf(a.gA1 * s + a.gB1, 0.f);
+      const float g = fmaxf(a.gA2 * g1 + a.gB2, 0.f) + 1.f;
+      acc.x += g * d2.x; acc.y += g * d2.y; acc.z += g * d2.z; acc.w += g * d2.w;
+    } else {  // plain variance incl. the reference view (module.py:1074-1075,1094-1096,1110)
+      s1.x += wv.x; s1.y += wv.y; s1.z += wv.z; s1.w += wv.w;
+      acc.x += wv.x * wv.x; acc.y += wv.y * wv.y; acc.z += wv.z * wv.z; acc.w += wv.w * wv.w;
+    }
+    if (v == nsrc - 1) {
+      float4 o4 = make_float4(acc.x / inv_n, acc.y / inv_n, acc.z / inv_n, acc.w / inv_n);
+      if (!a.view_aggregation) {
+        const float4 mu = make_float4(s1.x / inv_n, s1.y / inv_n, s1.z / inv_n, s1.w / inv_n);
+        o4 = make_float4(o4.x - mu.x * mu.x, o4.y - mu.y * mu.y, o4.z - mu.z * mu.z, o4.w - mu.w * mu.w);
+      }
+      if (live) *reinterpret_cast<float4 *>(a.vol + ((size_t)d * h * w + (size_t)y * w + x) * C + q * 4) = o4;
+    }
+  };
+  const int n = (d1 - d0) * nsrc;
+  if (n <= 0) return;
+  CvTaps A, B;
+  int d = d0, v = 0;
+  issue(d, v, A);
+  for (int it = 0; it < n; it += 2) {  // two iterations per trip: the tap sets A and B alternate without copies
+    int dn = d, vn = v + 1;
+    if (vn == nsrc) { vn = 0; ++dn; }
+    issue(dn, vn, B);  // unconditional (past the end: a harmless extra gather): a branch here makes hipcc wait for ALL loads at the join
+    consume(d, v, A);
+    if (it + 1 >= n) break;
+    d = dn; v = vn;
+    dn = d; vn = v + 1;
+    if (vn == nsrc) { vn = 0; ++dn; }
+    issue(dn, vn, A);
+    consume(d, v, B);
+    d = dn; v = vn;
+  }
+}
+
 // ------------------------------------------------------------------ prob conv (Cout = 1)
 // CostRegNet.prob = Conv3d(8, 1, 3, padding=1, bias=False) (module.py:575): 216 MACs per voxel and a single output
 // channel -- no matrix shape to speak of, so it runs on the vector pipe: one lane = 4 consecutive x outputs,
@@ -251,14 +369,23 @@ __global__ __launch_bounds__(256) void k_costvol(const CostVolArgs a) {
 // Each lane owns the column (y, x0..x0+3) of a z-chunk and MARCHES along z: one input plane (3 rows x 6 positions
 // x 8 channels) is loaded once and feeds the three output planes it touches, so L1 traffic is a third of a
 // plane-at-a-time stencil.
+// Workgroup order (gz > 0): as in k_costvol, XCD k (= blockIdx.x % 8, own L2) walks the k-th band of rows, z chunks of a
+// pixel block innermost -- the three input rows an output row needs and the two halo planes of a z chunk are then
+// fetched into ONE L2 (launch order spread them over all eight: PMC showed 208 MB fetched per launch against 62 MB of input).
 template <int XO>  // x outputs per lane (4: fewest L1 accesses per output; 2: twice the waves to hide their latency)
 __global__ __launch_bounds__(256) void k_prob(const float *__restrict__ x, const float *__restrict__ wt /*[27][8]*/,
-                                              float *__restrict__ out, int D, int h, int w, int zchunk) {
+                                              float *__restrict__ out, int D, int h, int w, int zchunk, int gz, int nwg) {
   const int wq = w / XO;
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  int bx = blockIdx.x, bz = blockIdx.y;
+  if (gz > 0) {
+    const int per = (nwg + 7) >> 3, nid = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+    if (nid >= nwg) return;
+    bz = nid % gz; bx = nid / gz;
+  }
+  const int n = bx * blockDim.x + threadIdx.x;
   if (n >= h * wq) return;
   const int xq = n % wq, y = n / wq, x0 = xq * XO;
-  const int z0 = blockIdx.y * zchunk, z1 = min(D, z0 + zchunk);
+  const int z0 = bz * zchunk, z1 = min(D, z0 + zchunk);
   // acc[j][o]: output plane (zz - 1 + j) while input plane zz is being consumed
   float a0[XO], a1[XO], a2[XO];
 #pragma unroll

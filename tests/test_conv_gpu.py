@@ -56,9 +56,19 @@ def torch_ref(x, w, stride, transposed, scale, bias, relu, add, add_mode):
     return y[0].permute(1, 2, 3, 0).contiguous().numpy()
 
 
+_REF_CACHE = {}
+
+
 def run_case(case):
     from tandem_amd.dr_mvsnet import debug_conv
     name, dims, cin, cout, k, stride, transposed, relu, add_mode = case
+    if name in _REF_CACHE:  # plan sweeps re-run one case many times: inputs and the torch reference are computed once
+        x, w, scale, bias, add, ref = _REF_CACHE[name]
+        got = debug_conv(x, w, stride, transposed, scale, bias, relu, add, add_mode == "up2")
+        err = np.abs(got - ref).max()
+        tol = 2e-5 * max(1.0, np.abs(ref).max())
+        assert got.shape == ref.shape and err <= tol, f"{name}: max|err| {err:.3e} > {tol:.3e}"
+        return
     rng = np.random.RandomState(abs(hash(name)) % (2 ** 31))
     x = rng.randn(*dims, cin).astype(np.float32)
     wshape = (cin, cout) + k if transposed else (cout, cin) + k
@@ -76,6 +86,7 @@ def run_case(case):
         add = rng.randn(od[0], od[1] // 2, od[2] // 2, cout).astype(np.float32)
     got = debug_conv(x, w, stride, transposed, scale, bias, relu, add, add_mode == "up2")
     ref = torch_ref(x, w, stride, transposed, scale, bias, relu, add, add_mode)
+    _REF_CACHE[name] = (x, w, scale, bias, add, ref)
     assert got.shape == ref.shape
     err = np.abs(got - ref).max()
     tol = 2e-5 * max(1.0, np.abs(ref).max())  # fp32 reassociation only (MFMA fp32 == fmaf chain)
