@@ -40,7 +40,7 @@ constexpr int kMarchConsumers = 8, kMarchProducers = 2;
 constexpr int kMarchThreads = 64 * (kMarchConsumers + kMarchProducers);
 constexpr int kMarchMaxIt = 24;          // DMA pieces per producer wave per plane (planes up to 48 KB)
 constexpr int kMarchSpinLimit = 1 << 18; // polls before a wait gives up (tens of milliseconds)
-// flag words (ints) behind the weights: [0..1] ready (one per producer wave), [4..11] released (one per consumer wave), [12] abort
+// flag words (ints) behind the weights: [0..3] ready (one per producer wave), [4..11] released (one per consumer wave), [12] abort
 constexpr int kMarchFlagInts = 16;
 
 // the flag words are read and written with LDS instructions (ds_read / ds_write), never through flat addressing
@@ -90,11 +90,14 @@ DR_HD inline size_t march_out_index(const ConvArgs &a, int qz, int qy, int qx, i
 
 // Consumer side: wait until load `idx` has landed.  `cached` remembers the last value seen (the producers normally run
 // ahead, so most sections need no LDS read at all).
+template <int NPW>
 __device__ inline bool march_wait_ready(march_flag_t *flags, int idx, int &cached, int *err, int lane) {
   if (cached > idx) return true;
   for (int spin = 0; spin < kMarchSpinLimit; ++spin) {
-    const int r0 = flags[0], r1 = flags[1];
-    cached = march_uniform(r0 < r1 ? r0 : r1);
+    int r = flags[0];
+#pragma unroll
+    for (int p = 1; p < NPW; ++p) { const int t = flags[p]; r = t < r ? t : r; }
+    cached = march_uniform(r);
     if (cached > idx) return true;
     if (march_uniform(flags[12])) break;
     __builtin_amdgcn_s_sleep(1);
@@ -187,7 +190,7 @@ __device__ inline void march_epilogue(const ConvArgs &a, floatx4 (&acc)[CT][PT],
   }
 }
 
-template <int CI, int NUP, int CT, int PT>
+template <int CI, int NUP, int CT, int PT, int NPW>
 __device__ inline void march_consumer(const ConvArgs &a, const MarchArgs &m, float4 *lds4, march_flag_t *flags, const float4 *wl, int wave, int lane,
                                       int s0, int s1) {
   constexpr int TPC = 16 / CI;
@@ -225,15 +228,22 @@ __device__ inline void march_consumer(const ConvArgs &a, const MarchArgs &m, flo
           const int rel = march_section_load(m.geo, sg, z, sec);
           if (rel < 0) continue;
           const int idx = L + rel;
-          if (!march_wait_ready(flags, idx, cached, m.err, lane)) return;
+#if !defined(DR_MABL_NO_WAIT) && !defined(DR_MABL_FREE)  // (timing ablations, tools/gpu_r3_ablate.sh: results are wrong by design)
+          if (!march_wait_ready<NPW>(flags, idx, cached, m.err, lane)) return;
+#endif
           asm volatile("" ::: "memory");
+#ifndef DR_MABL_NO_KLOOP
           march_kloop<NUP, CT, PT>(lds4 + (size_t)(idx % m.R) * m.PS, wp + (size_t)sec * m.wsec, sw, acc);
+#endif
           if (march_section_releases(m.geo, sg, z, sec)) {
             asm volatile("" ::: "memory");
             if (lane == 0) flags[4 + wave] = idx + 1;
           }
         }
         const int qz = m.geo.KZ == 3 ? z : zc;
+#if defined(DR_MABL_NO_EPI) || defined(DR_MABL_FREE)
+        if (m.NPO > 7)  // never true: keeps the accumulators live
+#endif
         march_epilogue<CT, PT>(a, acc, scv, biv, raw, wave, j, g, ct0, qz, py0, px0);
       }
       L += sg.nl;
@@ -269,13 +279,19 @@ __device__ inline void march_producer(const ConvArgs &a, const MarchArgs &m, flo
         int plane, pi;
         march_load_plane(m.geo, sg, l, plane, pi);
         const int gz = m.geo.KZ == 3 ? plane : zc;
+#ifndef DR_MABL_FREE
         if (idx >= m.R && !march_wait_released(flags, idx - m.R + 1, m.err, lane)) return;
+#endif
         asm volatile("" ::: "memory");
         const float *pbase = a.in + march_plane_offset(a, gz, iy0, ix0, po * m.geo.NPI + pi, CI);
         float4 *dst = lds4 + (size_t)(idx % m.R) * m.PS;
 #pragma unroll
         for (int it = 0; it < kMarchMaxIt; ++it) {
+#if defined(DR_MABL_NO_DMA) || defined(DR_MABL_FREE)
+          if (it < m.nit && m.NPO > 7) {
+#else
           if (it < m.nit) {
+#endif
             const float *src = march_piece_inside(a, yx[it], iy0, ix0) ? pbase + rel[it] : a.zero16;
             conv_a_dma16(src, march_uniform(conv_a_lds_addr(dst + (it * kMarchProducers + pw) * 64)));
           }
@@ -289,9 +305,90 @@ __device__ inline void march_producer(const ConvArgs &a, const MarchArgs &m, flo
   }
 }
 
-// grid = (persistent workgroups (multiple of 8), 1, output-row groups); 10 waves.
-template <int CI, int NUP, int CT, int PT>
-__global__ __launch_bounds__(kMarchThreads) void k_conv_m(const ConvArgs a, const MarchArgs m) {
+// Fused-skip producer (FeatureNet out.stage3, module.py:517-529): the layer's 32-channel input `inter3 = W1 . c3 + b1 +
+// nearest_up2(inter2)` is never materialised -- producer wave pw computes channel group pw (4 channels) of the current
+// 16-channel pass for every staged position of the tile and writes it into the ring slot with ds_write_b128 (the image
+// the DMA would have produced: same slot permutation, zeros outside the tensor).  Its 4 x 8 weights are wave-uniform
+// (scalar registers); a lane reads 32 contiguous bytes of c3 and 16 bytes of inter2.  The arithmetic is k_skip_up's
+// (same fmaf chain, (acc + b) + up), so the result is bit-identical to the two-kernel path.
+constexpr int kMarchFzProducers = 4;
+template <int FZ>
+__device__ inline void march_producer_fz(const ConvArgs &a, const MarchArgs &m, float4 *lds4, march_flag_t *flags, float4 *wl, int pw, int lane, int s0,
+                                         int s1, int NUP, int CT) {
+  static_assert(FZ == 8, "8-channel skip source");
+  constexpr int kB = 5;  // positions per lane whose loads are in flight together
+  const int ct0 = blockIdx.z * CT, NS = m.geo.KZ * m.geo.NPI;
+  const int Hc = a.inH >> 1, Wc = a.inW >> 1;
+  for (int e = pw; e < NS * NUP * CT; e += kMarchFzProducers)
+    conv_a_dma16(a.wpk + march_weight_src(a, m, 0, e, NUP, CT, ct0) + lane, march_uniform(conv_a_lds_addr(wl + (size_t)e * 64)));
+  conv_a_wait_dma();
+  int L = 0;
+  for (int s = s0; s < s1;) {
+    const MarchSeg sg = march_segment(m.geo, s, s1);
+    int zc, py0, px0;
+    march_tile_origin(a, m, sg.col, zc, py0, px0);
+    const int iy0 = py0 * a.sy - a.py, ix0 = px0 * a.sx - a.px;
+    for (int l = 0; l < sg.nl; ++l) {
+      const int idx = L + l;
+      int plane, pi;
+      march_load_plane(m.geo, sg, l, plane, pi);
+      if (idx >= m.R && !march_wait_released(flags, idx - m.R + 1, m.err, lane)) return;
+      asm volatile("" ::: "memory");
+      const int q = march_uniform(pi * 4 + pw);  // 4-channel group of inter3 this wave produces for this load
+      float wr[4][FZ];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < FZ; ++c) wr[r][c] = a.fz_w[(4 * q + r) * FZ + c];
+      const float4 fb = *reinterpret_cast<const float4 *>(a.fz_b + 4 * q);
+      float4 *dst = lds4 + (size_t)(idx % m.R) * m.PS;
+      for (int p0 = 0; p0 < m.NP; p0 += 64 * kB) {
+        float4 xv[kB][FZ / 4], up[kB];
+        bool in[kB];
+#pragma unroll
+        for (int k = 0; k < kB; ++k) {
+          const int pos = p0 + k * 64 + lane;
+          const unsigned y = (unsigned)pos / (unsigned)a.TXI, x = (unsigned)pos - y * a.TXI;
+          const int gy = iy0 + (int)y, gx = ix0 + (int)x;
+          in[k] = pos < m.NP && gy >= 0 && gy < a.inH && gx >= 0 && gx < a.inW;
+          up[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int c = 0; c < FZ / 4; ++c) xv[k][c] = up[k];
+          if (in[k]) {
+            const float *xp = a.fz_x + (((size_t)zc * a.inH + gy) * a.inW + gx) * FZ;
+#pragma unroll
+            for (int c = 0; c < FZ / 4; ++c) xv[k][c] = *reinterpret_cast<const float4 *>(xp + 4 * c);
+            up[k] = *reinterpret_cast<const float4 *>(a.fz_coarse + (((size_t)zc * Hc + (gy >> 1)) * Wc + (gx >> 1)) * a.inC + 4 * q);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < kB; ++k) {
+          const int pos = p0 + k * 64 + lane;
+          float acc4[4] = {0.f, 0.f, 0.f, 0.f}, xi[FZ];
+#pragma unroll
+          for (int c = 0; c < FZ / 4; ++c) { xi[4 * c] = xv[k][c].x; xi[4 * c + 1] = xv[k][c].y; xi[4 * c + 2] = xv[k][c].z; xi[4 * c + 3] = xv[k][c].w; }
+#pragma unroll
+          for (int sft = 0; sft < 4; ++sft)
+#pragma unroll
+            for (int gq = 0; gq < FZ / 4; ++gq)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc4[r] = __builtin_fmaf(wr[r][4 * gq + sft], xi[4 * gq + sft], acc4[r]);
+          float4 o = make_float4(0.f, 0.f, 0.f, 0.f);  // outside the tensor: the 3x3 layer's zero padding
+          if (in[k]) { o.x = (acc4[0] + fb.x) + up[k].x; o.y = (acc4[1] + fb.y) + up[k].y; o.z = (acc4[2] + fb.z) + up[k].z; o.w = (acc4[3] + fb.w) + up[k].w; }
+          if (pos < m.NP) dst[conv_a_unit<16>(pos, pw)] = o;
+        }
+      }
+      asm volatile("" ::: "memory");  // the ds_writes above and the flag below execute in program order
+      if (lane == 0) flags[pw] = idx + 1;
+    }
+    L += sg.nl;
+    s += sg.zb - sg.za;
+  }
+}
+
+// grid = (persistent workgroups (multiple of 8), 1, output-row groups); 8 consumer waves + 2 (DMA) or 4 (fused skip) producer waves.
+template <int CI, int NUP, int CT, int PT, int FZ = 0>
+__global__ __launch_bounds__(64 * (kMarchConsumers + (FZ ? kMarchFzProducers : kMarchProducers))) void k_conv_m(const ConvArgs a, const MarchArgs m) {
   extern __shared__ float4 lds4[];
   const int tid = threadIdx.x, lane = tid & 63, wave = march_uniform(tid >> 6);
   float4 *wl = lds4 + (size_t)m.R * m.PS;
@@ -304,7 +401,8 @@ __global__ __launch_bounds__(kMarchThreads) void k_conv_m(const ConvArgs a, cons
   int s0, s1;
   march_range(m.steps, id, nwg, s0, s1);
   if (s0 >= s1) return;
-  if (wave < kMarchConsumers) march_consumer<CI, NUP, CT, PT>(a, m, lds4, flags, wl, wave, lane, s0, s1);
+  if (wave < kMarchConsumers) march_consumer<CI, NUP, CT, PT, (FZ ? kMarchFzProducers : kMarchProducers)>(a, m, lds4, flags, wl, wave, lane, s0, s1);
+  else if constexpr (FZ > 0) march_producer_fz<FZ>(a, m, lds4, flags, wl, wave - kMarchConsumers, lane, s0, s1, NUP, CT);
   else march_producer<CI>(a, m, lds4, flags, wl, wave - kMarchConsumers, lane, s0, s1, NUP, CT);
 }
 

@@ -808,7 +808,9 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
     }
   }
   // k_conv_m: the stride-1 3x3 / 3x3x3 layers on the marching producer/consumer kernel (conv_march.h)
-  const int march_policy = fz ? 0 : conv_march_policy();
+  // (a fused FeatureNet skip runs on it in exactly one form: 8-channel source, 32 -> 8 XPAIR 3x3 layer, producers compute the tile)
+  const bool march_fz_ok = !fz || (fz->cin == 8 && L.Cin == 32 && L.kd == 1 && mode == CONV_XPAIR && !getenv("DR_FZ_NO_MARCH"));
+  const int march_policy = march_fz_ok ? conv_march_policy() : 0;
   const bool march_ok = march_policy >= 1 && ncls == 1 && !L.transposed && mode != CONV_X8 && L.kh == 3 && L.kw == 3 && (L.kd == 1 || L.kd == 3) &&
                         SZ == 1 && SY == 1 && L.sw == 1;
   const int march_ntp = march_ok ? 3 * (int)cx[0].t.size() : 0;  // taps per input plane
@@ -821,7 +823,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
           if ((ty > 1 && ty / 2 >= nPH) || (txt > 1 && (txt / 2) * 16 >= nPW)) continue;
           for (int ct : {2, 1}) {
             const MarchShape ms = march_shape(L.kd, march_ntp, L.Cin, ci, ct, pt, ty, txt, SX, exy, exx, nPD, nPH, nPW, CTtot);
-            if (!ms.ok) continue;
+            if (!ms.ok || (fz && (ci != 16 || ct != 1))) continue;
             const double spw = std::ceil((double)ms.steps / ms.grid);
             const double unit = ms.ns * ms.nup * 4.0 * ct * pt * 64.0;  // MFMA cycles of a step per SIMD (two consumer waves each)
             const double startup = (double)ms.lds_bytes / 16.0 + 3000.0;
@@ -1056,13 +1058,19 @@ inline void launch_conv_a_inst(const ConvLaunch &c, hipStream_t st) {
   conv_allow_big_lds(reinterpret_cast<const void *>(&k_conv_a<CI, CT, PT>), done, c.lds_bytes);
   hipLaunchKernelGGL((k_conv_a<CI, CT, PT>), c.grid, dim3(kConvAThreads), c.lds_bytes, st, c.args);
 }
-template <int CI, int NUP, int CT, int PT>
+template <int CI, int NUP, int CT, int PT, int FZ = 0>
 inline void launch_conv_m_inst(const ConvLaunch &c, hipStream_t st) {
   static std::atomic<unsigned long long> done{0};
-  conv_allow_big_lds(reinterpret_cast<const void *>(&k_conv_m<CI, NUP, CT, PT>), done, c.lds_bytes);
-  hipLaunchKernelGGL((k_conv_m<CI, NUP, CT, PT>), c.grid, dim3(kMarchThreads), c.lds_bytes, st, c.args, c.march);
+  conv_allow_big_lds(reinterpret_cast<const void *>(&k_conv_m<CI, NUP, CT, PT, FZ>), done, c.lds_bytes);
+  hipLaunchKernelGGL((k_conv_m<CI, NUP, CT, PT, FZ>), c.grid, dim3(64 * (kMarchConsumers + (FZ ? kMarchFzProducers : kMarchProducers))), c.lds_bytes, st, c.args, c.march);
 }
 inline void launch_conv(const ConvLaunch &c, hipStream_t st) {
+  if (c.async == 2 && c.fz) {
+    if (c.fz != 8 || c.ci != 16 || c.nup != 12 || c.ct != 1) fail(DR_ERR_ARG, "launch_conv: no fused-skip marching instance FZ=%d CI=%d NUP=%d CT=%d", c.fz, c.ci, c.nup, c.ct);
+    if (c.pt == 4) launch_conv_m_inst<16, 12, 1, 4, 8>(c, st);
+    else launch_conv_m_inst<16, 12, 1, 2, 8>(c, st);
+    return;
+  }
   if (c.async == 2) {
 #define DR_CONV_M_CASE(CI_, NUP_, CT_)                                          \
   if (c.ci == CI_ && c.nup == NUP_ && c.ct == CT_) {                            \

@@ -297,3 +297,30 @@ def test_fused_skip_equals_the_two_kernel_path(trained_blob, monkeypatch):
     for a, b in zip(*outs):
         assert np.array_equal(a.depth_dense, b.depth_dense) and np.array_equal(a.confidence_dense, b.confidence_dense)
         assert np.array_equal(a.depth, b.depth) and np.array_equal(a.confidence, b.confidence)
+
+
+def test_fused_skip_on_the_marching_kernel(trained_blob, monkeypatch):
+    """out.stage3 with the skip computed by k_conv_m's producer waves (conv_march.h, march_producer_fz) against the same
+    layer on k_conv's fused staging: same fmaf chain in the skip, same channel-pass and tap order in the 3x3 layer, so
+    feat3 agrees to fp32 reassociation at most (tolerance 2e-5 of the tensor's range; observed: bit-identical)."""
+    from oracle import scene
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    feats = []
+    for env in ({"DR_CONV_MARCH": "2", "DR_CONV_NO_TUNED": "1"}, {"DR_FZ_NO_MARCH": "1", "DR_CONV_NO_TUNED": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = DrMvsnet(trained_blob)
+        res = []
+        for (h, w, v) in ((96, 160, 4), (224, 352, 3)):
+            win = scene.make_window(h, w, v, seed=6)
+            m.upload(h, w, v, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), 0.5, 5.0, 2.5)
+            m.forward(1)
+            prof = {r["op"]: r["kernel"] for r in m.profile()}
+            res.append((m.tensor("feat3").copy(), prof["fn.out3"]))
+        feats.append(res)
+        m.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    for (fa, ka), (fb, kb) in zip(*feats):
+        assert "k_conv_m" in ka and "k_conv_m" not in kb, (ka, kb)
+        assert np.abs(fa - fb).max() <= 2e-5 * np.abs(fb).max()
