@@ -134,24 +134,26 @@ __device__ inline void march_anchor(const float4 (&av)[CT], const float4 (&bv)[P
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) asm volatile("" ::"v"(bv[pt].x), "v"(bv[pt].y), "v"(bv[pt].z), "v"(bv[pt].w));
 }
-template <int NUP, int CT, int PT>
+// DEPTH = how many chunks ahead the operands are fetched (DEPTH + 1 register sets used in rotation).  One chunk ahead
+// leaves an LDS read 8 MFMAs = 256 cycles to return at CT = 1, PT = 2; with eight waves reading it takes longer than that
+// (tools/ubench/march_kloop.hip), so the wave stalls at every chunk.
+#ifndef DR_MARCH_DEPTH
+#define DR_MARCH_DEPTH 2
+#endif
+template <int NUP, int CT, int PT, int DEPTH = (CT * PT >= 4 ? 1 : DR_MARCH_DEPTH)>  // 16 MFMAs per chunk cover an LDS round trip with one chunk of prefetch
 __device__ inline void march_kloop(const float4 *tile, const float4 *wp, const int (&sw)[NUP][PT], floatx4 (&acc)[CT][PT]) {
-  float4 a0[CT], b0[PT], a1[CT], b1[PT];
-  march_load<NUP, CT, PT>(tile, wp, sw, 0, a0, b0);
+  constexpr int NS = DEPTH + 1;
+  float4 av[NS][CT], bv[NS][PT];
 #pragma unroll
-  for (int u = 0; u + 1 < NUP; u += 2) {
-    march_load<NUP, CT, PT>(tile, wp, sw, u + 1, a1, b1);
+  for (int u = 0; u < DEPTH && u < NUP; ++u) march_load<NUP, CT, PT>(tile, wp, sw, u, av[u % NS], bv[u % NS]);
+#pragma unroll
+  for (int u = 0; u < NUP; ++u) {
+    if (u + DEPTH < NUP) march_load<NUP, CT, PT>(tile, wp, sw, u + DEPTH, av[(u + DEPTH) % NS], bv[(u + DEPTH) % NS]);
     __builtin_amdgcn_sched_barrier(0);
-    conv_chunk_mfma<CT, PT>(a0, b0, acc);
+    conv_chunk_mfma<CT, PT>(av[u % NS], bv[u % NS], acc);
     __builtin_amdgcn_sched_barrier(0);
-    march_anchor<CT, PT>(a1, b1);
-    if (u + 2 < NUP) march_load<NUP, CT, PT>(tile, wp, sw, u + 2, a0, b0);
-    __builtin_amdgcn_sched_barrier(0);
-    conv_chunk_mfma<CT, PT>(a1, b1, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    if (u + 2 < NUP) march_anchor<CT, PT>(a0, b0);
+    if (u + 1 < NUP) march_anchor<CT, PT>(av[(u + 1) % NS], bv[(u + 1) % NS]);  // the next chunk's operands are waited for here, behind this chunk's MFMAs
   }
-  if (NUP & 1) conv_chunk_mfma<CT, PT>(a0, b0, acc);
 }
 
 // ---- epilogue of one step; raw: 0 = final, 1 = store raw partial sums, 2 = add the stored partial sums, then final ----

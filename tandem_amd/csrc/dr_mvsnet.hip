@@ -825,6 +825,14 @@ class MvsEngine {
           int pb = 256, xo = 1;  // r2 sweep: one output column per lane (4x the waves) beats the 4-column variant 0.204 -> 0.124 ms over the three stages
           if (const char *e = getenv("DR_PROB_BLOCK")) pb = std::max(64, std::min(256, atoi(e) / 64 * 64));  // tuning hooks
           if (const char *e = getenv("DR_PROB_XO")) xo = atoi(e) == 2 ? 2 : (atoi(e) == 4 ? 4 : 1);
+          if (!getenv("DR_PROB_V1")) {  // LDS-staged plane tiles (k_prob2); DR_PROB_V1=1: the L1-gather kernel (A/B hook)
+            int zc = std::min(o.d0, 8);
+            while (zc > 2 && cdiv(o.d1, kProbTY) * cdiv(o.d2, kProbTX) * cdiv(o.d0, zc) < 1024) zc /= 2;  // ~4 workgroups per CU
+            if (const char *e = getenv("DR_PROB_ZCHUNK")) zc = std::max(1, std::min(o.d0, atoi(e)));
+            const int gxp = cdiv(o.d2, kProbTX), gyp = cdiv(o.d1, kProbTY), gzp = cdiv(o.d0, zc), nw = gxp * gyp * gzp;
+            hipLaunchKernelGGL(k_prob2, dim3(8 * cdiv(nw, 8)), dim3(256), 0, stream_, o.p0, o.p1, o.p2, o.d0, o.d1, o.d2, zc, gxp, gyp, gzp, nw);
+            break;
+          }
           dim3 grid(cdiv(o.d1 * (o.d2 / xo), pb), cdiv(o.d0, zchunk));
           int gz = 0, nwg = 0;
           if (!getenv("DR_PROB_LAUNCH_ORDER")) {  // XCD-band workgroup order (A/B hook: the plain 2-D launch order)

@@ -427,6 +427,78 @@ __global__ __launch_bounds__(256) void k_prob(const float *__restrict__ x, const
   }
 }
 
+// k_prob2: the same layer with the input plane staged through LDS.  k_prob reads every input position nine times per
+// plane from L1 (three rows x three columns per lane: 288 B per output and plane against 64 B/clk/CU of L1 bandwidth,
+// and PMC showed 3.3x the input bytes fetched from L2); here a workgroup of 256 lanes owns a 4-row x 64-column tile and
+// marches along z: one input plane of the tile (6 x 66 positions, two float4 halves kept in separate arrays so that
+// consecutive lanes read consecutive 16-byte slots) is staged ONCE per plane -- global -> registers while the previous
+// plane is being consumed, registers -> the other LDS buffer afterwards, one barrier per plane -- and serves the nine
+// taps of all 256 lanes and the three output planes it contributes to.  Arithmetic and summation order are k_prob's.
+constexpr int kProbTY = 4, kProbTX = 64, kProbPos = (kProbTY + 2) * (kProbTX + 2);  // 396 staged positions per plane
+__global__ __launch_bounds__(256) void k_prob2(const float *__restrict__ x, const float *__restrict__ wt /*[27][8]*/,
+                                               float *__restrict__ out, int D, int h, int w, int zchunk, int gx, int gy, int gz, int nwg) {
+  __shared__ float4 lds[2][2][kProbPos];  // [buffer][channel half][position]
+  const int per = (nwg + 7) >> 3, nid = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);  // XCD k walks the k-th band of tile rows
+  if (nid >= nwg) return;
+  const int bz = nid % gz, bxy = nid / gz, bx = bxy % gx, by = bxy / gx;
+  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+  const int x0 = bx * kProbTX, y0 = by * kProbTY, xo = x0 + tx, yo = y0 + ty;
+  const int z0 = bz * zchunk, z1 = min(D, z0 + zchunk);
+  // this thread's share of a plane: staged positions tid, tid + 256 (both halves each)
+  int spos[2];
+  const float *sptr[2];
+  bool sin[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int p = tid + k * 256, py = p / (kProbTX + 2), px = p - py * (kProbTX + 2);
+    const int gyy = y0 - 1 + py, gxx = x0 - 1 + px;
+    spos[k] = p < kProbPos ? p : -1;
+    sin[k] = p < kProbPos && gyy >= 0 && gyy < h && gxx >= 0 && gxx < w;
+    sptr[k] = x + ((size_t)(sin[k] ? gyy : 0) * w + (sin[k] ? gxx : 0)) * 8;
+  }
+  const size_t plane = (size_t)h * w * 8;
+  float4 r[2][2];
+  auto fetch = [&](int zz) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      r[k][0] = r[k][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (sin[k] && zz >= 0 && zz < D) { r[k][0] = ld4(sptr[k] + (size_t)zz * plane); r[k][1] = ld4(sptr[k] + (size_t)zz * plane + 4); }
+    }
+  };
+  auto stash = [&](int b) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (spos[k] >= 0) { lds[b][0][spos[k]] = r[k][0]; lds[b][1][spos[k]] = r[k][1]; }
+  };
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;  // output planes zz-1, zz, zz+1 while input plane zz is being consumed
+  fetch(z0 - 1);
+  stash(0);
+  int b = 0;
+  for (int zz = z0 - 1; zz <= z1; ++zz, b ^= 1) {
+    __syncthreads();  // plane zz is in buffer b; everybody is done with buffer b ^ 1
+    if (zz + 1 <= z1) fetch(zz + 1);
+    if (zz >= 0 && zz < D) {
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        if (yo + kh - 1 < 0 || yo + kh - 1 >= h) continue;  // as k_prob: rows outside the image are skipped (their staged zeros are never read)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int p = (ty + kh) * (kProbTX + 2) + tx + kw;
+          const float4 lo = lds[b][0][p], hi = lds[b][1][p];
+          const float *w2 = wt + ((2 * 3 + kh) * 3 + kw) * 8, *w1 = wt + ((1 * 3 + kh) * 3 + kw) * 8, *w0 = wt + ((0 * 3 + kh) * 3 + kw) * 8;
+#define DR_DOT8(A, WK) A += lo.x * WK[0] + lo.y * WK[1] + lo.z * WK[2] + lo.w * WK[3] + hi.x * WK[4] + hi.y * WK[5] + hi.z * WK[6] + hi.w * WK[7]
+          DR_DOT8(a0, w2); DR_DOT8(a1, w1); DR_DOT8(a2, w0);
+#undef DR_DOT8
+        }
+      }
+    }
+    const int zo = zz - 1;
+    if (zo >= z0 && zo < z1 && xo < w && yo < h) out[((size_t)zo * h + yo) * w + xo] = a0;
+    a0 = a1; a1 = a2; a2 = 0.f;
+    if (zz + 1 <= z1) stash(b ^ 1);
+  }
+}
+
 // ------------------------------------------------------------------ regression
 struct RegressArgs {
   const float *logits;  // (D,h,w)
