@@ -1,8 +1,8 @@
 // conv_march.h -- k_conv_m: the stride-1 3x3 / 3x3x3 convolutions as a MARCHING, producer/consumer-specialised kernel.
 //
 // Same implicit GEMM as conv_mfma.h (operand mapping, packed weights, swizzled LDS-DMA image, epilogue), different engine:
-//   * a persistent workgroup = 8 CONSUMER waves (two per SIMD: ds_read_b128 + v_mfma_f32_16x16x4_f32 and nothing else in
-//     the K loop) + 2 PRODUCER waves that issue every LDS-DMA (global_load_lds_dwordx4) from a per-lane offset table built
+//   * a persistent workgroup = 8 or 12 CONSUMER waves (two / three per SIMD: ds_read_b128 + v_mfma_f32_16x16x4_f32 and nothing
+//     else in the K loop) + 2 PRODUCER waves that issue every LDS-DMA (global_load_lds_dwordx4) from a per-lane offset table built
 //     once per workgroup -- no address decode, no vmcnt wait and no barrier in the MFMA waves;
 //   * the workgroup owns a contiguous range of steps (march_plan.h) and MARCHES along z: a ring of R input planes stays
 //     in LDS, a step computes one output plane of the tile from the three planes around it and only ONE new plane is
@@ -33,15 +33,16 @@ struct MarchArgs {
   int wsec;            // float4 per weight section (NUP * CT * 64)
   int NU;              // K chunks per channel pass in the packed weight array (KZ * NUP)
   int steps;           // ncols * Dc
+  int ncw;             // consumer waves (8 or 12)
   int *err;            // raised when a wait gave up (nullptr: not reported)
 };
 
-constexpr int kMarchConsumers = 8, kMarchProducers = 2;
-constexpr int kMarchThreads = 64 * (kMarchConsumers + kMarchProducers);
+constexpr int kMarchProducers = 2;       // DMA producer waves (the fused-skip producers are four: kMarchFzProducers)
+constexpr int kMarchMaxConsumers = 12;   // consumer waves: 8 (two per SIMD) or 12 (three per SIMD, smaller position tiles per wave)
 constexpr int kMarchMaxIt = 24;          // DMA pieces per producer wave per plane (planes up to 48 KB)
 constexpr int kMarchSpinLimit = 1 << 18; // polls before a wait gives up (tens of milliseconds)
-// flag words (ints) behind the weights: [0..3] ready (one per producer wave), [4..11] released (one per consumer wave), [12] abort
-constexpr int kMarchFlagInts = 16;
+// flag words (ints) behind the weights: [0..3] ready (one per producer wave), [4..15] released (one per consumer wave), [28] abort
+constexpr int kMarchFlagInts = 32, kMarchAbort = 28;
 
 // the flag words are read and written with LDS instructions (ds_read / ds_write), never through flat addressing
 typedef __attribute__((address_space(3))) volatile int march_flag_t;
@@ -99,23 +100,23 @@ __device__ inline bool march_wait_ready(march_flag_t *flags, int idx, int &cache
     for (int p = 1; p < NPW; ++p) { const int t = flags[p]; r = t < r ? t : r; }
     cached = march_uniform(r);
     if (cached > idx) return true;
-    if (march_uniform(flags[12])) break;
+    if (march_uniform(flags[kMarchAbort])) break;
     __builtin_amdgcn_s_sleep(1);
   }
-  if (lane == 0) { flags[12] = 1; if (err) *err = 1; }
+  if (lane == 0) { flags[kMarchAbort] = 1; if (err) *err = 1; }
   return false;
 }
 // Producer side: wait until every consumer wave has released `need` loads.
-__device__ inline bool march_wait_released(march_flag_t *flags, int need, int *err, int lane) {
+__device__ inline bool march_wait_released(march_flag_t *flags, int ncw, int need, int *err, int lane) {
   for (int spin = 0; spin < kMarchSpinLimit; ++spin) {
     int v = flags[4];
 #pragma unroll
-    for (int w = 1; w < kMarchConsumers; ++w) { const int t = flags[4 + w]; v = t < v ? t : v; }
+    for (int w = 1; w < kMarchMaxConsumers; ++w) { const int t = flags[4 + (w < ncw ? w : 0)]; v = t < v ? t : v; }
     if (march_uniform(v) >= need) return true;
-    if (march_uniform(flags[12])) break;
+    if (march_uniform(flags[kMarchAbort])) break;
     __builtin_amdgcn_s_sleep(2);
   }
-  if (lane == 0) { flags[12] = 1; if (err) *err = 2; }
+  if (lane == 0) { flags[kMarchAbort] = 1; if (err) *err = 2; }
   return false;
 }
 
@@ -140,20 +141,26 @@ __device__ inline void march_anchor(const float4 (&av)[CT], const float4 (&bv)[P
 #ifndef DR_MARCH_DEPTH
 #define DR_MARCH_DEPTH 2
 #endif
-template <int NUP, int CT, int PT, int DEPTH = (CT * PT >= 4 ? 1 : DR_MARCH_DEPTH)>  // 16 MFMAs per chunk cover an LDS round trip with one chunk of prefetch
+template <int NUP, int CT, int PT, int DEPTH = (CT * PT >= 4 ? 1 : (CT * PT == 1 ? DR_MARCH_DEPTH + 1 : DR_MARCH_DEPTH))>  // 16 MFMAs per chunk cover an LDS round trip with one chunk of prefetch
 __device__ inline void march_kloop(const float4 *tile, const float4 *wp, const int (&sw)[NUP][PT], floatx4 (&acc)[CT][PT]) {
   constexpr int NS = DEPTH + 1;
   float4 av[NS][CT], bv[NS][PT];
+  // one accumulator per wave (CT = PT = 1): odd chunks go to a second one, so that consecutive MFMAs never wait for each
+  // other (40-cycle dependent latency against a 32-cycle issue interval); the two are added at the end of the section
+  floatx4 acc2[CT][PT];
+  if constexpr (CT * PT == 1) acc2[0][0] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int u = 0; u < DEPTH && u < NUP; ++u) march_load<NUP, CT, PT>(tile, wp, sw, u, av[u % NS], bv[u % NS]);
 #pragma unroll
   for (int u = 0; u < NUP; ++u) {
     if (u + DEPTH < NUP) march_load<NUP, CT, PT>(tile, wp, sw, u + DEPTH, av[(u + DEPTH) % NS], bv[(u + DEPTH) % NS]);
     __builtin_amdgcn_sched_barrier(0);
-    conv_chunk_mfma<CT, PT>(av[u % NS], bv[u % NS], acc);
+    if (CT * PT == 1 && (u & 1)) conv_chunk_mfma<CT, PT>(av[u % NS], bv[u % NS], acc2);
+    else conv_chunk_mfma<CT, PT>(av[u % NS], bv[u % NS], acc);
     __builtin_amdgcn_sched_barrier(0);
     if (u + 1 < NUP) march_anchor<CT, PT>(av[(u + 1) % NS], bv[(u + 1) % NS]);  // the next chunk's operands are waited for here, behind this chunk's MFMAs
   }
+  if constexpr (CT * PT == 1) acc[0][0] += acc2[0][0];
 }
 
 // ---- epilogue of one step; raw: 0 = final, 1 = store raw partial sums, 2 = add the stored partial sums, then final ----
@@ -198,7 +205,6 @@ __device__ inline void march_consumer(const ConvArgs &a, const MarchArgs &m, flo
   constexpr int TPC = 16 / CI;
   const int j = lane & 15, g = lane >> 4;
   const int sub = (4 * g) / CI, c4 = ((4 * g) % CI) / 4, ct0 = blockIdx.z * CT;
-  const int NS = m.geo.KZ * m.geo.NPI;
   // swizzled 16-byte slot of this lane's operand for every chunk of a plane and every position tile of the wave
   int sw[NUP][PT];
 #pragma unroll
@@ -213,6 +219,7 @@ __device__ inline void march_consumer(const ConvArgs &a, const MarchArgs &m, flo
   float4 scv[CT], biv[CT];
   conv_load_affine<CT>(a, g, ct0, scv, biv);
   const float4 *wp = wl + lane;
+  const int KZ = m.geo.KZ, NPI = m.geo.NPI, R = m.R, Dc = m.geo.Dc;
   int cached = 0, L = 0;
   for (int po = 0; po < m.NPO; ++po) {
     const int raw = m.NPO == 1 ? 0 : (po == 0 ? 1 : 2);  // the planner produces NPO <= 2
@@ -220,33 +227,41 @@ __device__ inline void march_consumer(const ConvArgs &a, const MarchArgs &m, flo
       const MarchSeg sg = march_segment(m.geo, s, s1);
       int zc, py0, px0;
       march_tile_origin(a, m, sg.col, zc, py0, px0);
+      MarchCursor cur;
+      cur.begin(m.geo, sg, L, R);
       for (int z = sg.za; z < sg.zb; ++z) {
         floatx4 acc[CT][PT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
           for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
-        for (int sec = 0; sec < NS; ++sec) {
-          const int rel = march_section_load(m.geo, sg, z, sec);
-          if (rel < 0) continue;
-          const int idx = L + rel;
+        int rel = cur.rel0, slot = cur.slot0;
+        for (int dz = 0; dz < KZ; ++dz) {
+          const int plane = KZ == 3 ? z - 1 + dz : z;
+          const bool there = plane >= 0 && plane < Dc;  // else: z padding, the section is skipped
+          const bool rls = KZ == 1 || dz == 0 || z == sg.zb - 1;
+          for (int pi = 0; pi < NPI; ++pi, ++rel, slot = slot + 1 == R ? 0 : slot + 1) {
+            if (!there) continue;
+            const int idx = L + rel;
 #if !defined(DR_MABL_NO_WAIT) && !defined(DR_MABL_FREE)  // (timing ablations, tools/gpu_r3_ablate.sh: results are wrong by design)
-          if (!march_wait_ready<NPW>(flags, idx, cached, m.err, lane)) return;
+            if (!march_wait_ready<NPW>(flags, idx, cached, m.err, lane)) return;
 #endif
-          asm volatile("" ::: "memory");
-#ifndef DR_MABL_NO_KLOOP
-          march_kloop<NUP, CT, PT>(lds4 + (size_t)(idx % m.R) * m.PS, wp + (size_t)sec * m.wsec, sw, acc);
-#endif
-          if (march_section_releases(m.geo, sg, z, sec)) {
             asm volatile("" ::: "memory");
-            if (lane == 0) flags[4 + wave] = idx + 1;
+#ifndef DR_MABL_NO_KLOOP
+            march_kloop<NUP, CT, PT>(lds4 + (size_t)slot * m.PS, wp + (size_t)(dz * NPI + pi) * m.wsec, sw, acc);
+#endif
+            if (rls) {
+              asm volatile("" ::: "memory");
+              if (lane == 0) flags[4 + wave] = idx + 1;
+            }
           }
         }
-        const int qz = m.geo.KZ == 3 ? z : zc;
+        const int qz = KZ == 3 ? z : zc;
 #if defined(DR_MABL_NO_EPI) || defined(DR_MABL_FREE)
         if (m.NPO > 7)  // never true: keeps the accumulators live
 #endif
         march_epilogue<CT, PT>(a, acc, scv, biv, raw, wave, j, g, ct0, qz, py0, px0);
+        cur.next_step(m.geo, R);
       }
       L += sg.nl;
       s += sg.zb - sg.za;
@@ -267,7 +282,7 @@ __device__ inline void march_producer(const ConvArgs &a, const MarchArgs &m, flo
   for (int it = 0; it < kMarchMaxIt; ++it) march_piece_entry<CI>(a, m, pw, it, lane, rel[it], yx[it]);
   int L = 0;
   for (int po = 0; po < m.NPO; ++po) {
-    if (po > 0 && !march_wait_released(flags, L, m.err, lane)) return;  // nobody reads the previous pass's weights any more
+    if (po > 0 && !march_wait_released(flags, m.ncw, L, m.err, lane)) return;  // nobody reads the previous pass's weights any more
     // packed weights of this outer pass: section (dz, pi) = chunks dz*NUP .. of channel pass po*NPI + pi
     for (int e = pw; e < NS * NUP * CT; e += kMarchProducers)  // piece e = (sec * NUP + u) * CT + ct
       conv_a_dma16(a.wpk + march_weight_src(a, m, po, e, NUP, CT, ct0) + lane, march_uniform(conv_a_lds_addr(wl + (size_t)e * 64)));
@@ -282,7 +297,7 @@ __device__ inline void march_producer(const ConvArgs &a, const MarchArgs &m, flo
         march_load_plane(m.geo, sg, l, plane, pi);
         const int gz = m.geo.KZ == 3 ? plane : zc;
 #ifndef DR_MABL_FREE
-        if (idx >= m.R && !march_wait_released(flags, idx - m.R + 1, m.err, lane)) return;
+        if (idx >= m.R && !march_wait_released(flags, m.ncw, idx - m.R + 1, m.err, lane)) return;
 #endif
         asm volatile("" ::: "memory");
         const float *pbase = a.in + march_plane_offset(a, gz, iy0, ix0, po * m.geo.NPI + pi, CI);
@@ -334,7 +349,7 @@ __device__ inline void march_producer_fz(const ConvArgs &a, const MarchArgs &m, 
       const int idx = L + l;
       int plane, pi;
       march_load_plane(m.geo, sg, l, plane, pi);
-      if (idx >= m.R && !march_wait_released(flags, idx - m.R + 1, m.err, lane)) return;
+      if (idx >= m.R && !march_wait_released(flags, m.ncw, idx - m.R + 1, m.err, lane)) return;
       asm volatile("" ::: "memory");
       const int q = march_uniform(pi * 4 + pw);  // 4-channel group of inter3 this wave produces for this load
       float wr[4][FZ];
@@ -389,8 +404,8 @@ __device__ inline void march_producer_fz(const ConvArgs &a, const MarchArgs &m, 
 }
 
 // grid = (persistent workgroups (multiple of 8), 1, output-row groups); 8 consumer waves + 2 (DMA) or 4 (fused skip) producer waves.
-template <int CI, int NUP, int CT, int PT, int FZ = 0>
-__global__ __launch_bounds__(64 * (kMarchConsumers + (FZ ? kMarchFzProducers : kMarchProducers))) void k_conv_m(const ConvArgs a, const MarchArgs m) {
+template <int CI, int NUP, int CT, int PT, int FZ = 0, int NCW = 8>
+__global__ __launch_bounds__(64 * (NCW + (FZ ? kMarchFzProducers : kMarchProducers))) void k_conv_m(const ConvArgs a, const MarchArgs m) {
   extern __shared__ float4 lds4[];
   const int tid = threadIdx.x, lane = tid & 63, wave = march_uniform(tid >> 6);
   float4 *wl = lds4 + (size_t)m.R * m.PS;
@@ -403,9 +418,9 @@ __global__ __launch_bounds__(64 * (kMarchConsumers + (FZ ? kMarchFzProducers : k
   int s0, s1;
   march_range(m.steps, id, nwg, s0, s1);
   if (s0 >= s1) return;
-  if (wave < kMarchConsumers) march_consumer<CI, NUP, CT, PT, (FZ ? kMarchFzProducers : kMarchProducers)>(a, m, lds4, flags, wl, wave, lane, s0, s1);
-  else if constexpr (FZ > 0) march_producer_fz<FZ>(a, m, lds4, flags, wl, wave - kMarchConsumers, lane, s0, s1, NUP, CT);
-  else march_producer<CI>(a, m, lds4, flags, wl, wave - kMarchConsumers, lane, s0, s1, NUP, CT);
+  if (wave < NCW) march_consumer<CI, NUP, CT, PT, (FZ ? kMarchFzProducers : kMarchProducers)>(a, m, lds4, flags, wl, wave, lane, s0, s1);
+  else if constexpr (FZ > 0) march_producer_fz<FZ>(a, m, lds4, flags, wl, wave - NCW, lane, s0, s1, NUP, CT);
+  else march_producer<CI>(a, m, lds4, flags, wl, wave - NCW, lane, s0, s1, NUP, CT);
 }
 
 }  // namespace dr

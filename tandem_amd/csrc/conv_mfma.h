@@ -580,6 +580,7 @@ struct ConvLaunch {
   int async = 0;  // 1: k_conv_a (persistent, LDS-DMA staged, 512 threads); 2: k_conv_m (marching, 8 consumer + 2 producer waves)
   MarchArgs march{};
   int nup = 0;    // k_conv_m: K chunks per input plane
+  int ncw = 8;    // k_conv_m: consumer waves (8 or 12)
   dim3 grid;
   size_t lds_bytes;
   double flops;  // useful (algorithmic) flops of this launch
@@ -661,10 +662,12 @@ inline bool conv_instance_exists(int ci, int ct) {
 inline bool conv_a_instance_exists(int ci, int ct, int pt) {
   return (pt == 2 || pt == 4) && ((ci == 4 && ct == 1) || ((ci == 8 || ci == 16) && (ct == 1 || ct == 2)));
 }
-inline bool conv_m_instance_exists(int ci, int nup, int ct, int pt) {
-  if (pt != 2 && pt != 4) return false;
+inline bool conv_m_instance_exists(int ci, int nup, int ct, int pt, int ncw) {
+  const bool family = (ci == 8 && nup == 6) || (ci == 16 && (nup == 12 || nup == 9));
+  if (ncw == 12) return family && ct == 1 && (pt == 1 || pt == 2);  // three consumer waves per SIMD: at most 128 registers each
+  if (ncw != 8 || (pt != 2 && pt != 4)) return false;
   if (ct == 2) return ci == 16 && nup == 9 && pt == 2;  // (CT = 2, PT = 4 needs more than the 168 registers three waves per SIMD leave)
-  return ct == 1 && ((ci == 8 && nup == 6) || (ci == 16 && (nup == 12 || nup == 9)));
+  return ct == 1 && family;
 }
 // DR_CONV_MARCH: 0 = never plan k_conv_m, 1 = rank it with the other families (default), 2 = prefer it wherever it applies (A/B hook)
 inline int conv_march_policy() {
@@ -672,7 +675,7 @@ inline int conv_march_policy() {
   return 1;
 }
 struct MarchShape {  // derived geometry of a k_conv_m candidate
-  int nup, npi, npo, ns, tyi, txi, np, ps, r;
+  int nup, npi, npo, ns, tyi, txi, np, ps, r, ncw;
   size_t wbytes, lds_bytes;
   long long steps;
   int grid;
@@ -681,9 +684,10 @@ struct MarchShape {  // derived geometry of a k_conv_m candidate
 inline MarchShape march_shape(int KZ, int ntp, int Cin, int ci, int ct, int pt, int ty, int txt, int SX, int exy, int exx, int nPD, int nPH, int nPW, int CTtot) {
   MarchShape m{};
   const int tpc = 16 / ci;
-  if (Cin % ci || ntp % tpc || CTtot % ct || ty * txt != kMarchConsumers * pt) return m;
+  if (Cin % ci || ntp % tpc || CTtot % ct || (ty * txt) % pt) return m;
+  m.ncw = ty * txt / pt;  // one wave per PT position tiles
   m.nup = ntp / tpc;
-  if (!conv_m_instance_exists(ci, m.nup, ct, pt)) return m;
+  if (!conv_m_instance_exists(ci, m.nup, ct, pt, m.ncw)) return m;
   const int npass = Cin / ci;
   if (npass > 2) return m;
   m.npi = KZ == 1 ? npass : 1; m.npo = KZ == 1 ? 1 : npass; m.ns = KZ * m.npi;
@@ -817,15 +821,17 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   if (march_ok) {
     for (int ci : {16, 8}) {
       if (ci == 8 && L.Cin != 8) continue;
-      for (int pt : {2, 4})
-        for (int ty = 1; ty <= kMarchConsumers * pt; ty *= 2) {
-          const int txt = kMarchConsumers * pt / ty;
+      for (int ncw : {8, 12})
+      for (int pt : {1, 2, 4})
+        for (int ty = 1; ty <= ncw * pt; ++ty) {
+          if ((ncw * pt) % ty) continue;
+          const int txt = ncw * pt / ty;
           if ((ty > 1 && ty / 2 >= nPH) || (txt > 1 && (txt / 2) * 16 >= nPW)) continue;
           for (int ct : {2, 1}) {
             const MarchShape ms = march_shape(L.kd, march_ntp, L.Cin, ci, ct, pt, ty, txt, SX, exy, exx, nPD, nPH, nPW, CTtot);
-            if (!ms.ok || (fz && (ci != 16 || ct != 1))) continue;
+            if (!ms.ok || (fz && (ci != 16 || ct != 1 || ncw != 8))) continue;
             const double spw = std::ceil((double)ms.steps / ms.grid);
-            const double unit = ms.ns * ms.nup * 4.0 * ct * pt * 64.0;  // MFMA cycles of a step per SIMD (two consumer waves each)
+            const double unit = ms.ns * ms.nup * 4.0 * ct * pt * 32.0 * (ncw / 4) * (ncw == 12 ? 0.94 : 1.0);  // MFMA cycles of a step per SIMD (ncw / 4 consumer waves each; three hide each other's gaps better)
             const double startup = (double)ms.lds_bytes / 16.0 + 3000.0;
             double cost = ms.npo * (spw * unit * 1.02 + startup);
             if (march_policy >= 2) cost *= 1e-3;
@@ -1009,7 +1015,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   if (ASYNC == 2) {
     const MarchShape ms = march_shape(L.kd, march_ntp, L.Cin, CI, CT, PT, TY, TXT, SX, exy, exx, nPD, nPH, nPW, CTtot);
     if (!ms.ok) fail(DR_ERR_ARG, "plan_conv: inconsistent k_conv_m plan");
-    cl.async = 2; cl.nup = ms.nup;
+    cl.async = 2; cl.nup = ms.nup; cl.ncw = ms.ncw;
     a.zero16 = arena.upload(std::vector<float>(4, 0.f));
     a.a_slots = 0; a.a_wbufs = 0;
     MarchArgs &m = cl.march;
@@ -1027,6 +1033,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
     m.R = ms.r; m.PS = ms.ps; m.NP = ms.np; m.nit = ms.ps / 128;
     m.wsec = ms.nup * CT * 64; m.NU = L.kd * ms.nup;
     m.steps = (int)ms.steps;
+    m.ncw = ms.ncw;
     m.err = arena.err_flag;
     cl.lds_bytes = ms.lds_bytes;
     cl.grid = dim3(ms.grid, 1, CTtot / CT);
@@ -1058,32 +1065,33 @@ inline void launch_conv_a_inst(const ConvLaunch &c, hipStream_t st) {
   conv_allow_big_lds(reinterpret_cast<const void *>(&k_conv_a<CI, CT, PT>), done, c.lds_bytes);
   hipLaunchKernelGGL((k_conv_a<CI, CT, PT>), c.grid, dim3(kConvAThreads), c.lds_bytes, st, c.args);
 }
-template <int CI, int NUP, int CT, int PT, int FZ = 0>
+template <int CI, int NUP, int CT, int PT, int FZ = 0, int NCW = 8>
 inline void launch_conv_m_inst(const ConvLaunch &c, hipStream_t st) {
   static std::atomic<unsigned long long> done{0};
-  conv_allow_big_lds(reinterpret_cast<const void *>(&k_conv_m<CI, NUP, CT, PT, FZ>), done, c.lds_bytes);
-  hipLaunchKernelGGL((k_conv_m<CI, NUP, CT, PT, FZ>), c.grid, dim3(64 * (kMarchConsumers + (FZ ? kMarchFzProducers : kMarchProducers))), c.lds_bytes, st, c.args, c.march);
+  conv_allow_big_lds(reinterpret_cast<const void *>(&k_conv_m<CI, NUP, CT, PT, FZ, NCW>), done, c.lds_bytes);
+  hipLaunchKernelGGL((k_conv_m<CI, NUP, CT, PT, FZ, NCW>), c.grid, dim3(64 * (NCW + (FZ ? kMarchFzProducers : kMarchProducers))), c.lds_bytes, st, c.args, c.march);
 }
 inline void launch_conv(const ConvLaunch &c, hipStream_t st) {
   if (c.async == 2 && c.fz) {
-    if (c.fz != 8 || c.ci != 16 || c.nup != 12 || c.ct != 1) fail(DR_ERR_ARG, "launch_conv: no fused-skip marching instance FZ=%d CI=%d NUP=%d CT=%d", c.fz, c.ci, c.nup, c.ct);
+    if (c.fz != 8 || c.ci != 16 || c.nup != 12 || c.ct != 1 || c.ncw != 8) fail(DR_ERR_ARG, "launch_conv: no fused-skip marching instance FZ=%d CI=%d NUP=%d CT=%d", c.fz, c.ci, c.nup, c.ct);
     if (c.pt == 4) launch_conv_m_inst<16, 12, 1, 4, 8>(c, st);
     else launch_conv_m_inst<16, 12, 1, 2, 8>(c, st);
     return;
   }
   if (c.async == 2) {
-#define DR_CONV_M_CASE(CI_, NUP_, CT_)                                          \
-  if (c.ci == CI_ && c.nup == NUP_ && c.ct == CT_) {                            \
-    if (c.pt == 4) launch_conv_m_inst<CI_, NUP_, CT_, 4>(c, st);                \
-    else launch_conv_m_inst<CI_, NUP_, CT_, 2>(c, st);                          \
-    return;                                                                     \
+#define DR_CONV_M_CASE(CI_, NUP_)                                                         \
+  if (c.ci == CI_ && c.nup == NUP_ && c.ct == 1) {                                        \
+    if (c.ncw == 12 && c.pt == 1) { launch_conv_m_inst<CI_, NUP_, 1, 1, 0, 12>(c, st); return; } \
+    if (c.ncw == 12 && c.pt == 2) { launch_conv_m_inst<CI_, NUP_, 1, 2, 0, 12>(c, st); return; } \
+    if (c.ncw == 8 && c.pt == 2) { launch_conv_m_inst<CI_, NUP_, 1, 2>(c, st); return; }  \
+    if (c.ncw == 8 && c.pt == 4) { launch_conv_m_inst<CI_, NUP_, 1, 4>(c, st); return; }  \
   }
-    DR_CONV_M_CASE(8, 6, 1)
-    DR_CONV_M_CASE(16, 12, 1)
-    DR_CONV_M_CASE(16, 9, 1)
+    DR_CONV_M_CASE(8, 6)
+    DR_CONV_M_CASE(16, 12)
+    DR_CONV_M_CASE(16, 9)
 #undef DR_CONV_M_CASE
-    if (c.ci == 16 && c.nup == 9 && c.ct == 2 && c.pt == 2) { launch_conv_m_inst<16, 9, 2, 2>(c, st); return; }
-    fail(DR_ERR_ARG, "launch_conv: no marching instance CI=%d NUP=%d CT=%d PT=%d", c.ci, c.nup, c.ct, c.pt);
+    if (c.ci == 16 && c.nup == 9 && c.ct == 2 && c.pt == 2 && c.ncw == 8) { launch_conv_m_inst<16, 9, 2, 2>(c, st); return; }
+    fail(DR_ERR_ARG, "launch_conv: no marching instance CI=%d NUP=%d CT=%d PT=%d waves=%d", c.ci, c.nup, c.ct, c.pt, c.ncw);
   }
   if (c.async) {
 #define DR_CONV_A_CASE(CI_, CT_)                                                \

@@ -62,6 +62,20 @@ DR_HD inline void march_load_plane(const MarchGeom &g, const MarchSeg &sg, int l
   plane = sg.p0 + l / g.NPI;
   pi = l % g.NPI;
 }
+// The consumer's view of a segment without divisions in its loops: section (dz, pi) of the current step reads load
+// L + rel0 + dz * NPI + pi (== march_section_load) out of ring slot (that index) % R; both advance by NPI per step.
+struct MarchCursor {
+  int rel0, slot0;
+  DR_HD void begin(const MarchGeom &g, const MarchSeg &sg, int L, int R) {
+    rel0 = (sg.za - (g.KZ == 3 ? 1 : 0) - sg.p0) * g.NPI;  // -NPI when the segment starts at z = 0
+    slot0 = (L + rel0 + 2 * R) % R;
+  }
+  DR_HD void next_step(const MarchGeom &g, int R) {
+    rel0 += g.NPI;
+    slot0 = slot0 + g.NPI >= R ? slot0 + g.NPI - R : slot0 + g.NPI;
+  }
+};
+
 // Balanced step range of workgroup `id` of `n`.
 DR_HD inline void march_range(long long steps, int id, int n, int &s0, int &s1) {
   s0 = (int)(steps * id / n);

@@ -82,16 +82,19 @@ static bool emulate(const ConvLaunch &c, const float *in, float *out, const floa
           const MarchSeg sg = march_segment(m.geo, s, s1);
           int zc, py0, px0;
           march_tile_origin(a, m, sg.col, zc, py0, px0);
-          for (int z = sg.za; z < sg.zb; ++z) {
-            std::vector<float> acc((size_t)kMarchConsumers * CT * PT * 64 * 4, 0.f);
+          MarchCursor cur;  // the kernel's division-free bookkeeping, checked against march_section_load
+          cur.begin(m.geo, sg, L, m.R);
+          for (int z = sg.za; z < sg.zb; cur.next_step(m.geo, m.R), ++z) {
+            std::vector<float> acc((size_t)m.ncw * CT * PT * 64 * 4, 0.f);
             for (int sec = 0; sec < NS; ++sec) {
               const int rel = march_section_load(m.geo, sg, z, sec);
               if (rel < 0) continue;
               const int idx = L + rel;
+              if (cur.rel0 + sec != rel || (cur.slot0 + sec) % m.R != idx % m.R) { printf("emul: cursor disagrees with march_section_load (step %d section %d)\n", z, sec); return false; }
               if (idx - Lpass >= (int)loads.size()) { printf("emul: section reads load %d beyond the producer's list\n", idx); return false; }
               while (loaded <= idx) { if (!do_load(loaded)) return false; ++loaded; }
               if (idx < released) { printf("emul: section reads load %d after releasing it\n", idx); return false; }
-              for (int wave = 0; wave < kMarchConsumers; ++wave)
+              for (int wave = 0; wave < m.ncw; ++wave)
                 for (int u = 0; u < NUP; ++u)
                   for (int ct = 0; ct < CT; ++ct)
                     for (int pt = 0; pt < PT; ++pt) {
@@ -117,7 +120,7 @@ static bool emulate(const ConvLaunch &c, const float *in, float *out, const floa
               }
             }
             const int qz = m.geo.KZ == 3 ? z : zc;
-            for (int wave = 0; wave < kMarchConsumers; ++wave)
+            for (int wave = 0; wave < m.ncw; ++wave)
               for (int pt = 0; pt < PT; ++pt)
                 for (int lane = 0; lane < 64; ++lane) {
                   const int j = lane & 15, g = lane >> 4;
@@ -196,7 +199,7 @@ static int run_case(const Case &cs, int max_plans) {
     double worst = 0;
     for (size_t i = 0; i < on; ++i) worst = std::max(worst, (double)std::fabs(out[i] - ref[i]) / (1.0 + std::fabs(ref[i])));
     const bool pass = ok && worst < 2e-5;
-    printf("%-22s plan ci=%d nup=%d ct=%d pt=%d tile %dx%d R=%d PS=%d NPI=%d NPO=%d grid %ux%u steps %d: %s (max rel err %.2e)\n", cs.name, c.ci, c.nup, c.ct, c.pt,
+    printf("%-22s plan w=%d ci=%d nup=%d ct=%d pt=%d tile %dx%d R=%d PS=%d NPI=%d NPO=%d grid %ux%u steps %d: %s (max rel err %.2e)\n", cs.name, c.ncw, c.ci, c.nup, c.ct, c.pt,
            c.args.TY, c.args.TXT * 16, c.march.R, c.march.PS, c.march.geo.NPI, c.march.NPO, c.grid.x, c.grid.z, c.march.steps, pass ? "ok" : "FAIL", worst);
     ++done;
     if (!pass) ++fails;

@@ -17,11 +17,11 @@ def test_march_emulation_matches_direct_convolution(tmp_path):
     exe = tmp_path / "march_emul"
     subprocess.check_call([HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-Wno-unused-function",
                            "-Wno-pass-failed", "-Wno-unused-result", os.path.join(ROOT, "tests", "cpp", "march_emul.hip"), "-o", str(exe)])
-    out = subprocess.run([str(exe), "40"], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([str(exe), "80"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if " plan " in l]
     assert len(lines) >= 30 and all(" ok " in l for l in lines), out.stdout[-4000:]
     # every instance family and both pass structures were exercised
     text = out.stdout
-    for needle in ("ci=8 nup=6", "ci=16 nup=12", "ci=16 nup=9", "ct=2", "pt=4", "NPI=2", "NPO=2"):
+    for needle in ("ci=8 nup=6", "ci=16 nup=12", "ci=16 nup=9", "ct=2", "pt=4", "pt=1", "w=12", "NPI=2", "NPO=2"):
         assert needle in text, needle
