@@ -41,8 +41,8 @@ constexpr int kMarchProducers = 2;       // DMA producer waves (the fused-skip p
 constexpr int kMarchMaxConsumers = 12;   // consumer waves: 8 (two per SIMD) or 12 (three per SIMD, smaller position tiles per wave)
 constexpr int kMarchMaxIt = 24;          // DMA pieces per producer wave per plane (planes up to 48 KB)
 constexpr int kMarchSpinLimit = 1 << 18; // polls before a wait gives up (tens of milliseconds)
-// flag words (ints) behind the weights: [0..3] ready (one per producer wave), [4..15] released (one per consumer wave), [28] abort
-constexpr int kMarchFlagInts = 32, kMarchAbort = 28;
+// flag words (ints) behind the weights: [0..7] ready (one per producer wave), [8..19] released (one per consumer wave), [28] abort
+constexpr int kMarchFlagInts = 32, kMarchReleased = 8, kMarchAbort = 28;
 
 // the flag words are read and written with LDS instructions (ds_read / ds_write), never through flat addressing
 typedef __attribute__((address_space(3))) volatile int march_flag_t;
@@ -109,9 +109,9 @@ __device__ inline bool march_wait_ready(march_flag_t *flags, int idx, int &cache
 // Producer side: wait until every consumer wave has released `need` loads.
 __device__ inline bool march_wait_released(march_flag_t *flags, int ncw, int need, int *err, int lane) {
   for (int spin = 0; spin < kMarchSpinLimit; ++spin) {
-    int v = flags[4];
+    int v = flags[kMarchReleased];
 #pragma unroll
-    for (int w = 1; w < kMarchMaxConsumers; ++w) { const int t = flags[4 + (w < ncw ? w : 0)]; v = t < v ? t : v; }
+    for (int w = 1; w < kMarchMaxConsumers; ++w) { const int t = flags[kMarchReleased + (w < ncw ? w : 0)]; v = t < v ? t : v; }
     if (march_uniform(v) >= need) return true;
     if (march_uniform(flags[kMarchAbort])) break;
     __builtin_amdgcn_s_sleep(2);
@@ -252,7 +252,7 @@ __device__ inline void march_consumer(const ConvArgs &a, const MarchArgs &m, flo
 #endif
             if (rls) {
               asm volatile("" ::: "memory");
-              if (lane == 0) flags[4 + wave] = idx + 1;
+              if (lane == 0) flags[kMarchReleased + wave] = idx + 1;
             }
           }
         }
@@ -323,12 +323,12 @@ __device__ inline void march_producer(const ConvArgs &a, const MarchArgs &m, flo
 }
 
 // Fused-skip producer (FeatureNet out.stage3, module.py:517-529): the layer's 32-channel input `inter3 = W1 . c3 + b1 +
-// nearest_up2(inter2)` is never materialised -- producer wave pw computes channel group pw (4 channels) of the current
-// 16-channel pass for every staged position of the tile and writes it into the ring slot with ds_write_b128 (the image
+// nearest_up2(inter2)` is never materialised -- producer wave pw computes channel group pw & 3 (4 channels) of the current
+// 16-channel pass for every other batch of staged positions of the tile and writes it into the ring slot with ds_write_b128 (the image
 // the DMA would have produced: same slot permutation, zeros outside the tensor).  Its 4 x 8 weights are wave-uniform
 // (scalar registers); a lane reads 32 contiguous bytes of c3 and 16 bytes of inter2.  The arithmetic is k_skip_up's
 // (same fmaf chain, (acc + b) + up), so the result is bit-identical to the two-kernel path.
-constexpr int kMarchFzProducers = 4;
+constexpr int kMarchFzProducers = 8;  // 4 channel groups x 2 interleaved halves of the positions: one batch of loads in flight per wave and load
 template <int FZ>
 __device__ inline void march_producer_fz(const ConvArgs &a, const MarchArgs &m, float4 *lds4, march_flag_t *flags, float4 *wl, int pw, int lane, int s0,
                                          int s1, int NUP, int CT) {
@@ -351,7 +351,8 @@ __device__ inline void march_producer_fz(const ConvArgs &a, const MarchArgs &m, 
       march_load_plane(m.geo, sg, l, plane, pi);
       if (idx >= m.R && !march_wait_released(flags, m.ncw, idx - m.R + 1, m.err, lane)) return;
       asm volatile("" ::: "memory");
-      const int q = march_uniform(pi * 4 + pw);  // 4-channel group of inter3 this wave produces for this load
+      const int cg = pw & 3, half = pw >> 2;
+      const int q = march_uniform(pi * 4 + cg);  // 4-channel group of inter3 this wave produces for this load
       float wr[4][FZ];
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -359,7 +360,7 @@ __device__ inline void march_producer_fz(const ConvArgs &a, const MarchArgs &m, 
         for (int c = 0; c < FZ; ++c) wr[r][c] = a.fz_w[(4 * q + r) * FZ + c];
       const float4 fb = *reinterpret_cast<const float4 *>(a.fz_b + 4 * q);
       float4 *dst = lds4 + (size_t)(idx % m.R) * m.PS;
-      for (int p0 = 0; p0 < m.NP; p0 += 64 * kB) {
+      for (int p0 = half * 64 * kB; p0 < m.NP; p0 += 2 * 64 * kB) {
         float4 xv[kB][FZ / 4], up[kB];
         bool in[kB];
 #pragma unroll
@@ -392,7 +393,7 @@ __device__ inline void march_producer_fz(const ConvArgs &a, const MarchArgs &m, 
               for (int r = 0; r < 4; ++r) acc4[r] = __builtin_fmaf(wr[r][4 * gq + sft], xi[4 * gq + sft], acc4[r]);
           float4 o = make_float4(0.f, 0.f, 0.f, 0.f);  // outside the tensor: the 3x3 layer's zero padding
           if (in[k]) { o.x = (acc4[0] + fb.x) + up[k].x; o.y = (acc4[1] + fb.y) + up[k].y; o.z = (acc4[2] + fb.z) + up[k].z; o.w = (acc4[3] + fb.w) + up[k].w; }
-          if (pos < m.NP) dst[conv_a_unit<16>(pos, pw)] = o;
+          if (pos < m.NP) dst[conv_a_unit<16>(pos, cg)] = o;
         }
       }
       asm volatile("" ::: "memory");  // the ds_writes above and the flag below execute in program order

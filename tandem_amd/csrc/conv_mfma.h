@@ -834,6 +834,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
             const double unit = ms.ns * ms.nup * 4.0 * ct * pt * 32.0 * (ncw / 4) * (ncw == 12 ? 0.94 : 1.0);  // MFMA cycles of a step per SIMD (ncw / 4 consumer waves each; three hide each other's gaps better)
             const double startup = (double)ms.lds_bytes / 16.0 + 3000.0;
             double cost = ms.npo * (spw * unit * 1.02 + startup);
+            if (fz) cost *= 1.5;  // measured (r3): with a 3-slot ring and two channel passes per tile the fused-skip producers are the bottleneck (0.24 ms against k_conv's 0.214 at 480 x 640)
             if (march_policy >= 2) cost *= 1e-3;
             cands.push_back({cost, ci, pt, ct, 1, ty, txt, L.kd, ms.tyi, ms.txi, 2});
           }
