@@ -812,6 +812,82 @@ __device__ inline Voxel interp_voxel(const FusionDev &d, F3 pos, bool far_blocks
   v.sdf = dist;
   return v;
 }
+// interp_voxel in TWO memory round trips.  The statistics of the bench loop (DR_RAYCAST_STATS, r3): a ray takes ~62
+// samples, 52 of them inside allocated, carved space (the reference allocates every block between the camera and the
+// surface), and all lanes of a wave need about the same number -- the kernel is a chain of dependent gathers, each as slow
+// as the slowest of a wave's 64 lanes (some lane always misses L2).  interp_voxel has four dependent stages per sample
+// (centre block -> centre voxel -> neighbour blocks -> corner voxels); here every block look-up (centre + the 2x2x2 corner
+// blocks, computed from the position alone) is issued at once, then every voxel load (centre + 8 corners, unconditional
+// 8-byte loads from a clamped address, masked afterwards) at once.  Same values, same arithmetic, same result.
+template <bool FAST, bool COLOUR>
+__device__ inline Voxel interp_voxel2(const FusionDev &d, F3 pos, bool far_blocks, bool &bail, int *empty_cell = nullptr) {
+  const float vs = d.o.voxel_size, hv = vs / 2.0f, y = d.vs_rcp;
+  Voxel zero; zero.sdf = 0.f; zero.c[0] = zero.c[1] = zero.c[2] = 0; zero.weight = 0;
+  const float qx = div_by<FAST>(pos.x, vs, y), qy = div_by<FAST>(pos.y, vs, y), qz = div_by<FAST>(pos.z, vs, y);
+  const int g0x = f2i(qx + signf_(pos.x) * 0.5f), g0y = f2i(qy + signf_(pos.y) * 0.5f), g0z = f2i(qz + signf_(pos.z) * 0.5f);
+  const float pdx = pos.x - hv, pdy = pos.y - hv, pdz = pos.z - hv;
+  int gx[2], gy[2], gz[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float ax = pdx + (j ? vs : 0.0f), ay = pdy + (j ? vs : 0.0f), az = pdz + (j ? vs : 0.0f);
+    gx[j] = f2i(div_by<FAST>(ax, vs, y) + signf_(ax) * 0.5f);
+    gy[j] = f2i(div_by<FAST>(ay, vs, y) + signf_(ay) * 0.5f);
+    gz[j] = f2i(div_by<FAST>(az, vs, y) + signf_(az) * 0.5f);
+  }
+  // ---- round trip 1: nine block look-ups (identical addresses coalesce in the load unit) ----
+  auto cell_of = [&](int x, int yy, int z, bool &ok) { I3 p; p.x = x; p.y = yy; p.z = z; unsigned idx = 0; ok = grid_index(p, idx); return ok ? idx : 0u; };
+  bool ok0, okc[8];
+  const unsigned i0 = cell_of(g0x >> 3, g0y >> 3, g0z >> 3, ok0);
+  unsigned ic[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) ic[c] = cell_of(gx[c & 1] >> 3, gy[(c >> 1) & 1] >> 3, gz[(c >> 2) & 1] >> 3, okc[c]);
+  int b0 = d.grid[i0];
+  int P[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) P[c] = d.grid[ic[c]];
+  b0 = ok0 ? b0 - 1 : -1;
+  if (!ok0 && far_blocks) bail = true;
+  if (empty_cell) *empty_cell = (b0 < 0 && ok0) ? (int)i0 : -1;
+  if (b0 < 0) return zero;  // (weight 0: the corner look-ups above were speculative)
+#pragma unroll
+  for (int c = 0; c < 8; ++c) P[c] = okc[c] ? P[c] - 1 : -1;
+  // ---- round trip 2: the centre voxel and the eight corners ----
+  const Voxel8 t0 = *reinterpret_cast<const Voxel8 *>(d.vox + (size_t)b0 * 512 + (((g0x & 7) << 6) | ((g0y & 7) << 3) | (g0z & 7)));
+  Voxel8 tc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int local = ((gx[c & 1] & 7) << 6) | ((gy[(c >> 1) & 1] & 7) << 3) | (gz[(c >> 2) & 1] & 7);
+    tc[c] = *reinterpret_cast<const Voxel8 *>(d.vox + (size_t)(P[c] >= 0 ? P[c] : b0) * 512 + local);
+  }
+  const Voxel v0 = unpack_voxel(t0.lo, t0.hi);
+  if (v0.weight == 0) return v0;
+  // the far-block bail of the literal order: a corner outside the dense grid only matters once the centre voxel has weight
+#pragma unroll
+  for (int c = 0; c < 8; ++c) if (!okc[c] && far_blocks) bail = true;
+  const float wx = qx - floorf(qx), wy = qy - floorf(qy), wz = qz - floorf(qz);
+  float dist = 0.0f, cx = 0.0f, cy = 0.0f, cz = 0.0f;
+  const int order[8] = {0, 1, 2, 4, 3, 6, 5, 7};  // the reference's corner order: 000 100 010 001 110 011 101 111
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = order[k];
+    const float a = (c & 1) ? wx : (1.0f - wx), b = (c & 2) ? wy : (1.0f - wy), cc = (c & 4) ? wz : (1.0f - wz);
+    const float wt = a * b * cc;
+    Voxel cvx = unpack_voxel(tc[c].lo, tc[c].hi);
+    if (P[c] < 0) cvx = zero;
+    const Voxel &src = cvx.weight == 0 ? v0 : cvx;
+    dist += wt * src.sdf;
+    if (COLOUR) {
+      cx = cx + (float)src.c[0] * wt;
+      cy = cy + (float)src.c[1] * wt;
+      cz = cz + (float)src.c[2] * wt;
+    }
+  }
+  Voxel v;
+  v.c[0] = f2u8(cx); v.c[1] = f2u8(cy); v.c[2] = f2u8(cz);
+  v.weight = v0.weight;
+  v.sdf = dist;
+  return v;
+}
 // Pixels are flagged for the literal pass (k_raycast_fix) with depth -1 when a sample leaves the range div_exact was
 // verified on, or needs a block outside the dense grid while the table is not empty.  Neither happens in a room-sized map.
 // How many further samples q + j * trunc * dir (j = 1..k) stay inside the superblock of `cell`, shrunk by one voxel on
@@ -831,9 +907,13 @@ __device__ inline int skip_steps(unsigned cell, F3 q, F3 dirw, F3 inv_dir, float
   if (dirw.z != 0.f) t = fminf(t, ((gz + (dirw.z > 0.f ? hi_off : 0.5f)) * vs - q.z) * inv_dir.z);
   return (int)fminf(t * inv_trunc - 0.5f, 256.f);
 }
-template <bool FAST>
+// STATS (DR_RAYCAST_STATS=1, a measuring build of the same loop): per-launch totals of the ray loop in st[] --
+// [0] lane iterations, [1] longest ray, [2] sum over waves of their longest ray (what the wave pays), [3] samples whose
+// centre block does not exist, [4] skip events, [5] skipped steps, [6] samples with weight != 0, [7] waves, [8..] histogram
+// of the waves' longest rays in buckets of 16 iterations.
+template <bool FAST, bool STATS = false, bool STAGED = true>
 __global__ __launch_bounds__(64) void k_raycast2(const FusionDev d, const Mat pose, unsigned char *__restrict__ bgr,
-                                                 float *__restrict__ depth_out, int *__restrict__ n_flagged) {
+                                                 float *__restrict__ depth_out, int *__restrict__ n_flagged, unsigned long long *st = nullptr) {
   const drf_options_t &o = d.o;
   const int size = o.height * o.width;
   const bool far_blocks = d.n_alloc[3] != 0;
@@ -881,24 +961,40 @@ __global__ __launch_bounds__(64) void k_raycast2(const FusionDev d, const Mat po
     }
     const float inv_trunc = 1.0f / o.truncation_distance, vs = o.voxel_size;
     float cur = 0.f;
+    unsigned n_it = 0, n_miss = 0, n_skip = 0, n_skipped = 0, n_full = 0;
     while (cur < o.max_sensor_depth) {
       const F3 q = sample_pos(cur);
       int cell = -1;
-      const Voxel v = interp_voxel<FAST, false>(d, q, far_blocks, bail, d.super[0] ? &cell : nullptr);
+      const Voxel v = STAGED ? interp_voxel2<FAST, false>(d, q, far_blocks, bail, d.super[0] ? &cell : nullptr)
+                             : interp_voxel<FAST, false>(d, q, far_blocks, bail, d.super[0] ? &cell : nullptr);
       if (bail) break;
+      if (STATS) { ++n_it; n_miss += cell >= 0; n_full += v.weight != 0; }
       if (v.weight == 0) {
         cur += o.truncation_distance;
         if (cell >= 0) {
           int k = 0;
           if (d.super[0][super_index<kSuperShift[0]>((unsigned)cell)] == 0) k = skip_steps<kSuperShift[0]>((unsigned)cell, q, dirw, inv_dir, vs, inv_trunc);
           else if (d.super[1][super_index<kSuperShift[1]>((unsigned)cell)] == 0) k = skip_steps<kSuperShift[1]>((unsigned)cell, q, dirw, inv_dir, vs, inv_trunc);
+          if (STATS && k > 0) { ++n_skip; n_skipped += k; }
           for (; k > 0 && cur < o.max_sensor_depth; --k) cur += o.truncation_distance;
         }
       } else cur += v.sdf;
       if (v.weight != 0 && v.sdf < o.voxel_size) break;
     }
+    if (STATS) {
+      unsigned mx = n_it, sum = n_it, sm = n_miss, ss = n_skip, sk = n_skipped, sf = n_full;
+      for (int off = 32; off; off >>= 1) {
+        mx = max(mx, (unsigned)__shfl_xor((int)mx, off)); sum += __shfl_xor((int)sum, off); sm += __shfl_xor((int)sm, off);
+        ss += __shfl_xor((int)ss, off); sk += __shfl_xor((int)sk, off); sf += __shfl_xor((int)sf, off);
+      }
+      if (threadIdx.x == 0) {
+        atomicAdd(&st[0], (unsigned long long)sum); atomicMax(&st[1], (unsigned long long)mx); atomicAdd(&st[2], (unsigned long long)mx);
+        atomicAdd(&st[3], (unsigned long long)sm); atomicAdd(&st[4], (unsigned long long)ss); atomicAdd(&st[5], (unsigned long long)sk);
+        atomicAdd(&st[6], (unsigned long long)sf); atomicAdd(&st[7], 1ull); atomicAdd(&st[8 + min(mx / 16u, 23u)], 1ull);
+      }
+    }
     if (!bail && cur < o.max_sensor_depth) {
-      const Voxel v = interp_voxel<FAST, true>(d, sample_pos(cur), far_blocks, bail);
+      const Voxel v = STAGED ? interp_voxel2<FAST, true>(d, sample_pos(cur), far_blocks, bail) : interp_voxel<FAST, true>(d, sample_pos(cur), far_blocks, bail);
       bgr[3 * i] = v.c[0]; bgr[3 * i + 1] = v.c[1]; bgr[3 * i + 2] = v.c[2];
       depth_out[i] = cur;
     } else {
@@ -1089,8 +1185,24 @@ class FusionEngine {
     hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(1), 0, st, d_flag);
     FusionDev dv = d_;
     if (raycast_no_skip_) dv.super[0] = nullptr;  // DR_RAYCAST_NO_SKIP=1: every sample is looked up (A/B and parity hook)
-    if (d_.fast_div) hipLaunchKernelGGL(k_raycast2<true>, grid, block, 0, st, dv, P, d_bgr, d_depth, d_flag);
-    else hipLaunchKernelGGL(k_raycast2<false>, grid, block, 0, st, dv, P, d_bgr, d_depth, d_flag);
+    if (raycast_stats_ && d_.fast_div) {  // DR_RAYCAST_STATS=1: a synchronous, counting launch of the same loop (prints to stderr)
+      if (!d_rstats_) d_rstats_ = dalloc<unsigned long long>(32);
+      DR_HIP(hipMemsetAsync(d_rstats_, 0, 32 * 8, st));
+      hipLaunchKernelGGL((k_raycast2<true, true>), grid, block, 0, st, dv, P, d_bgr, d_depth, d_flag, d_rstats_);
+      unsigned long long h[32];
+      DR_HIP(hipMemcpyAsync(h, d_rstats_, sizeof h, hipMemcpyDeviceToHost, st));
+      DR_HIP(hipStreamSynchronize(st));
+      fprintf(stderr, "raycast stats: waves %llu  iterations/lane %.1f  longest ray %llu  mean wave-longest %.1f | per lane: missing-block samples %.1f, full samples %.1f, skip events %.2f (%.1f steps)\n  wave-longest histogram (x16):",
+              h[7], (double)h[0] / (64.0 * h[7]), h[1], (double)h[2] / h[7], (double)h[3] / (64.0 * h[7]), (double)h[6] / (64.0 * h[7]), (double)h[4] / (64.0 * h[7]), (double)h[5] / (64.0 * h[7]));
+      for (int i = 0; i < 24; ++i) fprintf(stderr, " %llu", h[8 + i]);
+      fprintf(stderr, "\n");
+    } else
+    if (raycast_unstaged_) {  // DR_RAYCAST_UNSTAGED=1: the four-stage sampler of round 2 (A/B and parity hook)
+      if (d_.fast_div) hipLaunchKernelGGL((k_raycast2<true, false, false>), grid, block, 0, st, dv, P, d_bgr, d_depth, d_flag, (unsigned long long *)nullptr);
+      else hipLaunchKernelGGL((k_raycast2<false, false, false>), grid, block, 0, st, dv, P, d_bgr, d_depth, d_flag, (unsigned long long *)nullptr);
+    } else
+    if (d_.fast_div) hipLaunchKernelGGL((k_raycast2<true, false, true>), grid, block, 0, st, dv, P, d_bgr, d_depth, d_flag, (unsigned long long *)nullptr);
+    else hipLaunchKernelGGL((k_raycast2<false, false, true>), grid, block, 0, st, dv, P, d_bgr, d_depth, d_flag, (unsigned long long *)nullptr);
     hipLaunchKernelGGL(k_raycast_fix, dim3(512), dim3(64), 0, st, d_, P, d_bgr, d_depth, d_flag);
   }
   // tsdf_volume.cu:634-700
@@ -1442,6 +1554,9 @@ class FusionEngine {
   unsigned long long fast_div_mismatches_ = 0;
   bool raycast_v1_ = getenv("DR_RAYCAST_V1") != nullptr;  // A/B hook: the literal first-generation ray-caster
   bool raycast_no_skip_ = getenv("DR_RAYCAST_NO_SKIP") != nullptr;  // A/B hook: no empty-space skip in k_raycast2
+  bool raycast_unstaged_ = getenv("DR_RAYCAST_UNSTAGED") != nullptr;
+  bool raycast_stats_ = getenv("DR_RAYCAST_STATS") != nullptr;     // measuring hook: iteration statistics of k_raycast2 on stderr
+  unsigned long long *d_rstats_ = nullptr;
   std::vector<Render> renders_;
   int free_slot_ = 0;
   Next next_ = kIntegrate;

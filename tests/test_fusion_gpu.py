@@ -284,16 +284,17 @@ def test_exact_fast_division_is_verified_at_construction(vs, f):
 
 
 def test_raycast_generations_agree_and_ieee_fallback(monkeypatch):
-    """k_raycast2 (dense-grid look-ups, exact fast division, shared corner coordinates, empty-superblock skip) against the
-    literal k_raycast, against k_raycast2 with IEEE division and against k_raycast2 without the skip, on the same volume:
-    bit-identical depth and colour."""
+    """k_raycast2 (dense-grid look-ups, exact fast division, shared corner coordinates, empty-superblock skip, two-round-trip
+    sampler) against the literal k_raycast, against k_raycast2 with IEEE division, without the skip and with round 2's
+    four-stage sampler, on the same volume: bit-identical depth and colour."""
     from oracle import scene
     from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
     H, W = 120, 160
     sc = scene.make_scans(3, H, W, seed=4)
     outs = []
-    for env in ({}, {"DR_RAYCAST_V1": "1"}, {"DR_FUSION_IEEE_DIV": "1"}, {"DR_RAYCAST_NO_SKIP": "1"}):
-        for k in ("DR_RAYCAST_V1", "DR_FUSION_IEEE_DIV", "DR_RAYCAST_NO_SKIP"):
+    for env in ({}, {"DR_RAYCAST_V1": "1"}, {"DR_FUSION_IEEE_DIV": "1"}, {"DR_RAYCAST_NO_SKIP": "1"}, {"DR_RAYCAST_UNSTAGED": "1"},
+                {"DR_RAYCAST_UNSTAGED": "1", "DR_FUSION_IEEE_DIV": "1"}):
+        for k in ("DR_RAYCAST_V1", "DR_FUSION_IEEE_DIV", "DR_RAYCAST_NO_SKIP", "DR_RAYCAST_UNSTAGED"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
