@@ -7,7 +7,7 @@ LIB   := tandem_amd/libdr_mi355x.so
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-pass-failed
 OBJS := $(CSRC)/dr_mvsnet.o $(CSRC)/dr_fusion.o $(CSRC)/dr_tracker.o
 
-all: $(LIB) oracle/libtsdf_oracle.so oracle/libtracker_oracle.so
+all: $(LIB) oracle/libtsdf_oracle.so oracle/libtsdf_oracle_omp.so oracle/libtracker_oracle.so
 
 # the depth pipeline is held to a float tolerance, not to bit-exactness: let hipcc contract a*b+c into FMAs there (the
 # vector-pipe kernels -- cost volume, prob -- are VALU-bound, and the reference's cuDNN/ATen kernels use FMAs too)
@@ -23,9 +23,13 @@ $(LIB): $(OBJS)
 oracle/libtsdf_oracle.so: oracle/tsdf_oracle.c tandem_amd/csrc/mc_tables.h
 	gcc -O2 -std=c99 -fPIC -shared -ffp-contract=off -fno-fast-math $< -o $@ -lm
 
+# the same restatement with its integration loop parallel over blocks (OpenMP): bench.py's multi-core CPU baseline only
+oracle/libtsdf_oracle_omp.so: oracle/tsdf_oracle.c tandem_amd/csrc/mc_tables.h
+	gcc -O2 -std=c99 -fPIC -shared -ffp-contract=off -fno-fast-math -fopenmp $< -o $@ -lm
+
 oracle/libtracker_oracle.so: oracle/tracker_oracle.c
 	gcc -O2 -std=c99 -fPIC -shared -ffp-contract=off -fno-fast-math $< -o $@ -lm
 
 clean:
-	rm -f $(OBJS) $(LIB) oracle/libtsdf_oracle.so oracle/libtracker_oracle.so
+	rm -f $(OBJS) $(LIB) oracle/libtsdf_oracle.so oracle/libtsdf_oracle_omp.so oracle/libtracker_oracle.so
 .PHONY: all clean

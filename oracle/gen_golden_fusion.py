@@ -11,7 +11,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import scene  # noqa: E402
+from synth import scene  # noqa: E402
 from oracle.tracker_oracle import TrackerOracle  # noqa: E402
 from oracle.tsdf_oracle import TsdfOracle  # noqa: E402
 

@@ -322,13 +322,18 @@ static void integrate_scan(tsdf_t *t, const unsigned char *bgr, const float *dep
   float vs = o->voxel_size, trunc = o->truncation_distance;
   unsigned long long upd = 0;
   int nb = t->nblk;
+  /* Built with -fopenmp (libtsdf_oracle_omp.so, bench.py's multi-core CPU baseline only): blocks are independent as long as
+   * every voxel's world -> camera -> world round trip lands on itself (mismatch counter 0, which the baseline asserts). */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : upd)
+#endif
   for (int e = 0; e < nb; ++e) {
     i3 P = t->coord[e];
+    int ix, iy;
     f3 position = {P.x * vs * bs, P.y * vs * bs, P.z * vs * bs};
     f3 pc = xform(Ti, position);
     if (pc.z < 0) continue;
     f3 center = {(float)(pc.x + 0.5 * vs * bs), (float)(pc.y + 0.5 * vs * bs), (float)(pc.z + 0.5 * vs * bs)};
-    int ix, iy;
     project(o, center, &ix, &iy);
     if (!(ix >= 0 && iy >= 0 && ix < o->width && iy < o->height)) continue;
     for (int bx = 0; bx < bs; bx++) for (int by = 0; by < bs; by++) for (int bz = 0; bz < bs; bz++) {

@@ -95,7 +95,7 @@ def test_weight_blob_roundtrip(tmp_path):
 
 
 def test_scene_generator_is_deterministic():
-    from oracle import scene
+    from synth import scene
     a, b = scene.make_window(64, 96, 3, seed=5), scene.make_window(64, 96, 3, seed=5)
     assert all(np.array_equal(x, y) for x, y in zip(a["bgrs"], b["bgrs"]))
     assert a["ref_index"] == 1 and a["c2ws"].shape == (3, 4, 4)

@@ -27,7 +27,7 @@ def assert_same_volume(f, o):
 
 @pytest.mark.parametrize("H,W,vs,n", [(96, 128, 0.02, 4), (120, 160, 0.01, 3), (64, 64, 0.04, 6)])
 def test_integrate_and_raycast_bit_exact(H, W, vs, n):
-    from oracle import scene
+    from synth import scene
     from oracle.tsdf_oracle import TsdfOracle
     from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
     sc = scene.make_scans(n, H, W, seed=H + n)
@@ -48,7 +48,7 @@ def test_integrate_and_raycast_bit_exact(H, W, vs, n):
 
 
 def test_edge_cases_empty_invalid_and_rotated():
-    from oracle import scene
+    from synth import scene
     from oracle.tsdf_oracle import TsdfOracle
     from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
     H, W = 64, 96
@@ -82,7 +82,7 @@ def test_edge_cases_empty_invalid_and_rotated():
 
 def test_call_order_state_machine():
     """tsdf_volume.cu:520-524,635-653,703-713: wrong order is a protocol error (reference: exit(1))."""
-    from oracle import scene
+    from synth import scene
     from tandem_amd import _lib
     from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
     H, W = 64, 96
@@ -110,7 +110,7 @@ def test_call_order_state_machine():
 
 
 def test_pool_exhaustion_is_reported():
-    from oracle import scene
+    from synth import scene
     from tandem_amd import _lib
     from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
     H, W = 64, 96
@@ -128,7 +128,7 @@ def test_full_size_properties():
     """BASELINE config 4 shape (640x480 scans, 5 mm voxels) at a bounded scan count: size-independent properties
     the domain offers -- weights count observations and saturate, re-integrating a scan allocates nothing new,
     update counts repeat, the volume ray-casts back to the scanned depth."""
-    from oracle import scene
+    from synth import scene
     from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
     H, W, vs = 480, 640, 0.005
     sc = scene.make_scans(3, H, W, seed=0)
@@ -157,7 +157,8 @@ def test_combine_exhaustive_against_reference_and_restatement():
     sdf / weight / cap cases, against the reference's own Combine compiled for the host (oracle/_ref) when present and
     against the restatement always."""
     import ctypes as C
-    from oracle import ref_fusion, scene, tsdf_oracle
+    from oracle import ref_fusion, tsdf_oracle
+    from synth import scene
     from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
     sc = scene.make_scans(1, 8, 8)
     f = DrFusion(DrFusionOptions(**options(sc, 8, 8, 0.02, num_blocks=64, num_buckets=64)))
@@ -215,7 +216,8 @@ def test_hip_path_equals_the_reference_build(H, W, vs, n):
     oracle/Makefile.ref from the sources under /root/reference; the prebuilt library travels to the GPU box): allocated
     set, every voxel, ray-cast depth and colour bit-exact.  Scenes keep block (0,0,0) out of the frustum (the reference's
     free-entry alias, tests/test_ref_fusion.py::test_origin_block_alias_is_the_only_deviation)."""
-    from oracle import ref_fusion, scene
+    from oracle import ref_fusion
+    from synth import scene
     from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
     if not ref_fusion.available():
         pytest.skip("oracle/_ref/libdr_fusion_ref.so not present")
@@ -251,7 +253,7 @@ def test_full_size_bit_exact_against_the_oracle():
     """BASELINE config 4's shape -- 640x480 scans into 5 mm voxels (truncation 20 mm) -- two scans, voxel state, update
     counts and the ray-cast of the second view BIT-EXACT against oracle/tsdf_oracle.c (which tests/test_ref_fusion.py
     pins to the reference build)."""
-    from oracle import scene
+    from synth import scene
     from oracle.tsdf_oracle import TsdfOracle
     from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
     H, W, vs = 480, 640, 0.005
@@ -275,7 +277,7 @@ def test_full_size_bit_exact_against_the_oracle():
 def test_exact_fast_division_is_verified_at_construction(vs, f):
     """div_exact (reciprocal + FMA correction, 3 instructions) replaces the IEEE division by voxel_size / fx / fy in the
     ray-caster: the engine checks it against a / b for ALL 2^32 dividends per divisor when it is created."""
-    from oracle import scene
+    from synth import scene
     from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
     sc = scene.make_scans(1, 8, 8)
     fu = DrFusion(DrFusionOptions(**options(sc, 8, 8, vs, num_blocks=64, num_buckets=64, fx=f, fy=f * 0.997)))
@@ -287,7 +289,7 @@ def test_raycast_generations_agree_and_ieee_fallback(monkeypatch):
     """k_raycast2 (dense-grid look-ups, exact fast division, shared corner coordinates, empty-superblock skip, two-round-trip
     sampler) against the literal k_raycast, against k_raycast2 with IEEE division, without the skip and with round 2's
     four-stage sampler, on the same volume: bit-identical depth and colour."""
-    from oracle import scene
+    from synth import scene
     from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
     H, W = 120, 160
     sc = scene.make_scans(3, H, W, seed=4)
@@ -320,7 +322,7 @@ def test_blocks_outside_the_dense_grid():
     """The dense block grid covers block coordinates [-256, 256)^3; beyond it the open-addressing table takes over.  A scene
     pushed 40.9 m along +x at 2 cm voxels (block edge 16 cm) straddles the border: allocation, integration, the
     ray-caster's hand-over to the literal pass and the mesh all have to agree with the oracle bit for bit."""
-    from oracle import scene
+    from synth import scene
     from oracle.tsdf_oracle import TsdfOracle
     from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
     H, W, vs = 96, 128, 0.02

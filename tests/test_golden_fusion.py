@@ -15,7 +15,7 @@ GOLD = os.path.join(ROOT, "tests", "golden", "fusion_tracker_small.npz")
 
 
 def check_fusion(make, g):
-    from oracle import scene
+    from synth import scene
     sc = scene.make_scans(3, G.H, G.W, seed=12)
     f = make(G.fusion_options(sc))
     for bgr, depth, pose in sc["scans"]:

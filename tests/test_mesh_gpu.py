@@ -50,7 +50,7 @@ def assert_same_mesh(got, want):
     (120, 160, 0.01, 2, (-1.0, -1.0, 0.5), (1.0, 1.0, 2.5)),
 ])
 def test_mesh_bit_exact(H, W, vs, n, lo, hi):
-    from oracle import scene
+    from synth import scene
     sc = scene.make_scans(n, H, W, seed=H + n)
     f, o = fuse(sc, options(sc, H, W, vs))
     f.ExtractMeshAsync(lo, hi)
@@ -63,7 +63,7 @@ def test_mesh_bit_exact(H, W, vs, n, lo, hi):
 
 
 def test_mesh_order_is_deterministic_and_repeatable():
-    from oracle import scene
+    from synth import scene
     sc = scene.make_scans(3, 96, 128, seed=5)
     lo, hi = (-3.0, -3.0, -3.0), (3.0, 3.0, 3.0)
     runs = []
@@ -80,7 +80,7 @@ def test_mesh_order_is_deterministic_and_repeatable():
 
 
 def test_mesh_edge_cases_and_protocol(tmp_path):
-    from oracle import scene
+    from synth import scene
     from tandem_amd._lib import DrError
     from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
     sc = scene.make_scans(2, 64, 96, seed=3)
@@ -133,7 +133,7 @@ def test_mesh_at_bench_grid_properties():
     check is by properties -- every vertex lies within half a voxel of a zero crossing of the scene's analytic
     surfaces as seen through the fused band (|sdf| small: the mesh sits inside the truncation band of the scans),
     colours are valid, the count is stable across two extractions."""
-    from oracle import scene
+    from synth import scene
     from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
     H, W, vs = 480, 640, 0.005
     sc = scene.make_scans(3, H, W, seed=11)

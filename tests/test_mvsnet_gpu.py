@@ -68,7 +68,8 @@ def test_golden_fixture_through_call_async(path, trained_blob, tmp_path):
 
 def test_full_size_window_against_oracle(trained_blob):
     """BASELINE config 2: 640x480, ref + 6 src, planes (48,32,8)."""
-    from oracle import mvsnet_oracle as O, scene
+    from oracle import mvsnet_oracle as O
+    from synth import scene
     from tandem_amd import weights as Wt
     from tandem_amd.dr_mvsnet import DrMvsnet
     meta, tens = Wt.read_blob(trained_blob)
@@ -86,7 +87,7 @@ def test_full_size_window_against_oracle(trained_blob):
 
 
 def test_protocol_and_argument_errors(trained_blob):
-    from oracle import scene
+    from synth import scene
     from tandem_amd import _lib
     from tandem_amd.dr_mvsnet import DrMvsnet
     win = scene.make_window(64, 96, 3, seed=1)
@@ -117,7 +118,7 @@ def test_protocol_and_argument_errors(trained_blob):
 
 def test_pipelined_calls_keep_order(trained_blob):
     """Back-to-back CallAsync/GetResult pairs on different windows (TandemBackend's usage, tandem_backend.cpp:147,268)."""
-    from oracle import scene
+    from synth import scene
     from tandem_amd.dr_mvsnet import DrMvsnet
     m = DrMvsnet(trained_blob)
     wins = [scene.make_window(64, 96, 3, seed=s) for s in (1, 2, 1)]
@@ -134,7 +135,8 @@ def test_edge_filter_is_exact_given_the_same_depth(trained_blob):
     """The order-statistic filter is pure comparisons: fed the engine's own depth map, the oracle filter must
     reproduce the engine's mask bit for bit (module.py:1320-1361)."""
     import torch
-    from oracle import mvsnet_oracle as O, scene
+    from oracle import mvsnet_oracle as O
+    from synth import scene
     from tandem_amd.dr_mvsnet import DrMvsnet
     m = DrMvsnet(trained_blob)
     win = scene.make_window(128, 160, 3, seed=4)
@@ -150,7 +152,8 @@ def test_edge_filter_is_exact_given_the_same_depth(trained_blob):
 
 def test_plain_variance_model_without_view_aggregation(tmp_path):
     """abl01/abl02 models: no gate, variance over all views incl. the reference (module.py:1074-1075,1094-1096,1110)."""
-    from oracle import mvsnet_oracle as O, scene
+    from oracle import mvsnet_oracle as O
+    from synth import scene
     from tandem_amd import weights as Wt
     from tandem_amd.dr_mvsnet import DrMvsnet
     tens = Wt.random_state((48, 32, 8), seed=11)
@@ -168,7 +171,8 @@ def test_plain_variance_model_without_view_aggregation(tmp_path):
 
 def test_resolution_and_view_count_can_change_between_calls(trained_blob):
     """The engine re-plans when TANDEM changes the window shape (dr_mvsnet.cpp builds tensors per call)."""
-    from oracle import mvsnet_oracle as O, scene
+    from oracle import mvsnet_oracle as O
+    from synth import scene
     from tandem_amd import weights as Wt
     from tandem_amd.dr_mvsnet import DrMvsnet
     meta, tens = Wt.read_blob(trained_blob)
@@ -186,7 +190,7 @@ def test_resolution_and_view_count_can_change_between_calls(trained_blob):
 def test_ref_index_and_view_order(trained_blob):
     """Model order is [ref, others in window order] (dr_mvsnet.cpp:190-197): permuting the window consistently with
     ref_index must not change the result when the source order is preserved."""
-    from oracle import scene
+    from synth import scene
     from tandem_amd.dr_mvsnet import DrMvsnet
     win = scene.make_window(64, 96, 4, seed=6)  # ref_index = 2
     m = DrMvsnet(trained_blob)
@@ -203,7 +207,8 @@ def test_maximum_views_large_frame_and_textureless_input(trained_blob):
     """Edges of the supported range: view_num = 8 (kMaxSrc + 1), a 1280x960 frame (4x the headline size: every conv
     plan, halo tile and cost-volume grid is re-derived), and a textureless window (all views one grey level: the cost
     volume is exactly zero, every plane ties, depth = mean hypothesis) -- each against the oracle."""
-    from oracle import mvsnet_oracle as O, scene
+    from oracle import mvsnet_oracle as O
+    from synth import scene
     from tandem_amd import weights as Wt
     from tandem_amd.dr_mvsnet import DrMvsnet
     meta, tens = Wt.read_blob(trained_blob)
@@ -229,7 +234,7 @@ def test_concurrent_engines_give_the_sequential_answer(trained_blob):
     """bench.py's throughput configuration: several DrMvsnet engines (own stream + worker each) running at once on
     one GPU must each return exactly what they return alone."""
     import threading
-    from oracle import scene
+    from synth import scene
     from tandem_amd.dr_mvsnet import DrMvsnet
     wins = [scene.make_window(96, 128, 5, seed=20 + i) for i in range(3)]
     alone = []
@@ -262,7 +267,8 @@ def test_concurrent_engines_give_the_sequential_answer(trained_blob):
 
 def test_autotuned_plan_stays_within_tolerance(trained_blob):
     """drm_autotune swaps convolution tilings by measured time; the result may move by accumulation order only."""
-    from oracle import mvsnet_oracle as O, scene
+    from oracle import mvsnet_oracle as O
+    from synth import scene
     from tandem_amd import weights as Wt
     from tandem_amd.dr_mvsnet import DrMvsnet
     meta, tens = Wt.read_blob(trained_blob)
@@ -280,7 +286,7 @@ def test_autotuned_plan_stays_within_tolerance(trained_blob):
 def test_fused_skip_equals_the_two_kernel_path(trained_blob, monkeypatch):
     """FeatureNet stage 3 (module.py:524-529): skip.stage3 + upsample computed inside out.stage3's staging step gives
     bit-for-bit what k_skip_up followed by the plain convolution gives (a second shape with partial tiles)."""
-    from oracle import scene
+    from synth import scene
     from tandem_amd.dr_mvsnet import DrMvsnet
     outs = []
     for unfused in (False, True):
@@ -303,7 +309,7 @@ def test_fused_skip_on_the_marching_kernel(trained_blob, monkeypatch):
     """out.stage3 with the skip computed by k_conv_m's producer waves (conv_march.h, march_producer_fz) against the same
     layer on k_conv's fused staging: same fmaf chain in the skip, same channel-pass and tap order in the 3x3 layer, so
     feat3 agrees to fp32 reassociation at most (tolerance 2e-5 of the tensor's range; observed: bit-identical)."""
-    from oracle import scene
+    from synth import scene
     from tandem_amd.dr_mvsnet import DrMvsnet
     feats = []
     for env in ({"DR_CONV_MARCH": "2", "DR_CONV_NO_TUNED": "1"}, {"DR_FZ_NO_MARCH": "1", "DR_CONV_NO_TUNED": "1"}):

@@ -4,7 +4,7 @@ the reference's formulas plus domain properties."""
 import numpy as np
 import pytest
 
-from oracle import scene
+from synth import scene
 from oracle.tsdf_oracle import TsdfOracle, lib
 
 F = np.float32
@@ -149,3 +149,19 @@ def test_frame_order_matters_but_is_deterministic():
             t.integrate(bgr, depth, pose)
         runs.append(t.export_blocks())
     assert runs[0].keys() == runs[1].keys() and all(np.array_equal(runs[0][k], runs[1][k]) for k in runs[0])
+
+
+def test_openmp_build_equals_the_serial_restatement():
+    """bench.py's multi-core CPU baseline runs the restatement with its integration loop parallel over blocks
+    (oracle/libtsdf_oracle_omp.so): same voxel state, same counters as the single-threaded library."""
+    from oracle.tsdf_oracle import TsdfOracle
+    sc = scene.make_scans(3, 96, 128, seed=3)
+    opt = dict(voxel_size=0.02, num_buckets=20000, bucket_size=10, num_blocks=20000, block_size=8, max_sdf_weight=64,
+               truncation_distance=0.08, max_sensor_depth=10.0, min_sensor_depth=0.1, num_render_streams=1,
+               fx=sc["fx"], fy=sc["fy"], cx=sc["cx"], cy=sc["cy"], height=96, width=128)
+    a, b = TsdfOracle(**opt), TsdfOracle(omp=True, **opt)
+    for bgr, depth, pose in sc["scans"]:
+        assert a.integrate(bgr, depth, pose) == 0 and b.integrate(bgr, depth, pose) == 0
+    ea, eb = a.export_blocks(), b.export_blocks()
+    assert ea.keys() == eb.keys() and all(np.array_equal(ea[k], eb[k]) for k in ea)
+    assert a.stats() == b.stats() and a.stats()["mismatches"] == 0

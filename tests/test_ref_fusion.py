@@ -16,7 +16,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from oracle import ref_fusion, scene
+from oracle import ref_fusion
+from synth import scene
 from oracle import tsdf_oracle
 
 pytestmark = pytest.mark.skipif(not ref_fusion.available(), reason="reference build (oracle/_ref) not available")

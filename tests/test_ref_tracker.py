@@ -13,7 +13,8 @@ Skipped when neither oracle/_ref/libcoarse_tracker_ref.so nor /root/reference ex
 import numpy as np
 import pytest
 
-from oracle import ref_tracker, scene
+from oracle import ref_tracker
+from synth import scene
 from oracle.tracker_oracle import TrackerOracle
 
 pytestmark = pytest.mark.skipif(not ref_tracker.available(), reason="reference build (oracle/_ref) not available")

@@ -13,7 +13,7 @@ SUM_RTOL = 1e-11
 
 
 def pair(H, W, seed, frac):
-    from oracle import scene
+    from synth import scene
     return scene.make_tracking_pair(H, W, seed=seed, sparse_fraction=frac)
 
 
@@ -149,7 +149,7 @@ def test_device_pointers_protocol_and_capacity():
 def test_render_to_tracker_handoff_stays_on_the_device():
     """SURVEY 8(f) row 3 end to end: DrFusion renders the fused map for the keyframe pose, the tracker appends the
     dense reference points straight from the render's device buffer -- same list as through the host copy."""
-    from oracle import scene
+    from synth import scene
     from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
     from tandem_amd.dr_tracker import DrCoarseTracker
     H, W = 96, 128

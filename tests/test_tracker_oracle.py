@@ -3,7 +3,7 @@ its own driver reads (cuda_coarse_tracker/src/main.cu wants cct_data/*.npy), so 
 hand-derived known answers of the reference's formulas plus domain properties."""
 import numpy as np
 
-from oracle import scene
+from synth import scene
 from oracle.tracker_oracle import TrackerOracle
 
 F = np.float32

@@ -35,7 +35,8 @@ WORKER = textwrap.dedent("""
     import numpy as np, torch
     import torch.distributed as dist
     torch.set_num_threads(4)
-    from oracle import mvsnet_oracle as O, scene
+    from oracle import mvsnet_oracle as O
+    from synth import scene
     from tandem_amd import replicas, view_shard, weights as Wt
 
     class OracleShardModel:  # protocol stand-in for tandem_amd.dr_mvsnet.DrMvsnet, arithmetic = oracle

@@ -55,7 +55,7 @@ def run_sharded(blob, window, world):
 @pytest.mark.parametrize("H,W,V,world", [(64, 96, 7, 2), (64, 96, 7, 3), (96, 128, 4, 8), (64, 96, 7, 1)])
 def test_sharded_equals_unsharded(H, W, V, world):
     import os
-    from oracle import scene
+    from synth import scene
     from tandem_amd.dr_mvsnet import DrMvsnet
     blob = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "weights", "tandem_va.tdmw")
     win = scene.make_window(H, W, V, seed=V + world)
@@ -83,7 +83,7 @@ def test_sharded_equals_unsharded(H, W, V, world):
 
 def test_shard_requires_view_aggregation_and_resets():
     import os
-    from oracle import scene
+    from synth import scene
     from tandem_amd import _lib
     from tandem_amd.dr_mvsnet import DrMvsnet
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -138,7 +138,7 @@ def test_engine_collective_single_rank(trained_blob):
     """drm_comm_init / in-stream ncclAllReduce: with one rank that holds every source view the sharded forward (divisor
     = all source views, all-reduce over a 1-rank communicator after every cost volume, no host step) must reproduce the
     ordinary forward bit for bit; the communicator can be destroyed and re-created."""
-    from oracle import scene
+    from synth import scene
     from tandem_amd.dr_mvsnet import DrMvsnet
     H, W, V = 64, 96, 5
     win = scene.make_window(H, W, V, seed=8)

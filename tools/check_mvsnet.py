@@ -9,7 +9,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import mvsnet_oracle as O, scene  # noqa: E402
+from oracle import mvsnet_oracle as O  # noqa: E402
+from synth import scene  # noqa: E402
 from tandem_amd import weights as Wt  # noqa: E402
 from tandem_amd.dr_mvsnet import DrMvsnet  # noqa: E402
 

@@ -3,7 +3,7 @@ import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from oracle import room
+from synth import room
 from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 H, W = 480, 640

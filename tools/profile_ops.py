@@ -2,7 +2,7 @@
 import os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import scene
+from synth import scene
 from tandem_amd.dr_mvsnet import DrMvsnet
 H, W, V = 480, 640, 7
 m = DrMvsnet(os.path.join(ROOT, "weights", "tandem_va.tdmw"))

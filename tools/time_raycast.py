@@ -3,7 +3,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
-from oracle import scene
+from synth import scene
 from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
 H, W = 480, 640
 sc = scene.make_scans(10, H, W, seed=100, texture_terms=3)

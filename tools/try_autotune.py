@@ -2,7 +2,7 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import scene
+from synth import scene
 from tandem_amd.dr_mvsnet import DrMvsnet
 # usage: try_autotune.py [candidates] [H W d1,d2,d3]   (default: the headline 480 x 640, planes 48,32,8)
 H, W, V = 480, 640, 7
