@@ -463,14 +463,21 @@ def view_shard_leg(args, rank, dev, world):
     window = dict(bgrs=win["bgrs"], K=win["K"], c2ws=list(win["c2ws"]), ref_index=win["ref_index"],
                   depth_min=win["depth_min"], depth_max=win["depth_max"], discard=DISCARD)
     m = DrMvsnet(model_blob(), device=dev)
-    mine = view_shard.upload(m, window, rank, world)
     one_dev = os.environ.get("DR_BENCH_ONE_DEVICE") == "1"  # test scaffold: RCCL refuses two ranks on one device
-    if not one_dev and view_shard.init_engine_collective(m, rank, world):
-        # the engine's own collective: ncclAllReduce of each cost volume on the engine stream, no host step per phase
-        step = lambda n: m.forward(n)
-        mode = "in-engine RCCL all-reduce of the fp32 cost volume after each stage's cost-volume kernel, stream-ordered"
-        nbytes = sum(m.device_tensor("volume%d" % s)[1] for s in (1, 2, 3)) * 4
+    P = view_shard.shard_world(V, world)  # at most one rank per source view takes part (8 GPUs, 6 source views: two stay out)
+    if not one_dev and view_shard.init_engine_collective(m, rank, world, participants=P):
+        # the engine's own collective, stream-ordered, no host step per phase: ncclReduce of each cost volume to rank 0,
+        # which alone regularises the stage, ncclBroadcast of the stage's depth map back
+        active = rank < P
+        mine = view_shard.upload(m, window, rank, P) if active else [win["ref_index"]]
+        step = (lambda n: m.forward(n)) if active else (lambda n: None)
+        mode = "in-engine RCCL: reduce of the fp32 cost volume to rank 0 after each stage's cost-volume kernel, broadcast of the stage depth map back; %d of %d ranks take part" % (P, world)
+        nbytes = sum(48 * 120 * 160 * 32 * 4 if s == 1 else (32 * 240 * 320 * 16 * 4 if s == 2 else 8 * 480 * 640 * 8 * 4) for s in (1, 2, 3)) if PLANES == (48, 32, 8) and (H, W) == (480, 640) else 0
+        if active:
+            nbytes = sum(m.device_tensor("volume%d" % s)[1] for s in (1, 2, 3)) * 4
     else:
+        active = True
+        mine = view_shard.upload(m, window, rank, world)
         nmax = max(m.device_tensor("volume%d" % s)[1] for s in (1, 2, 3))
         ar = view_shard.TorchAllReduce(dev, nmax)
 
@@ -488,14 +495,16 @@ def view_shard_leg(args, rank, dev, world):
     t1 = time.perf_counter()
     replicas.barrier(dev)
     tmax, nsrc = replicas.reduce_max_sum(t1 - t0, len(mine) - 1, dev)
-    out = m.download()
-    chk = replicas.reduce_max_sum(float(out.depth_dense.astype("float64").sum()), 0, dev)[0]
-    same = abs(chk - float(out.depth_dense.astype("float64").sum())) == 0.0  # every rank holds the same depth map
+    # every participating rank holds the same depth map (idle ranks report the maximum's negative so that they never win it)
+    mysum = float(m.download().depth_dense.astype("float64").sum()) if active else -1e300
+    chk = replicas.reduce_max_sum(mysum, 0, dev)[0]
+    same = (not active) or abs(chk - mysum) == 0.0
+    same = replicas.reduce_max_sum(0.0 if same else 1.0, 0, dev)[0] == 0.0
     m.close()
     return dict(depth_maps_per_s=steps / tmax, ms_per_depth_map=1e3 * tmax / steps, steps=steps, n_gpus=world,
                 source_views_total=int(nsrc), source_views_this_rank=len(mine) - 1,
                 allreduce_mb_per_depth_map=nbytes / 1e6, ranks_agree=bool(same), collective=mode,
-                note="one window sharded over the ranks; 3 fp32 volume all-reduces (RCCL) per depth map")
+                note="one window sharded over the ranks; 3 fp32 volume reductions (RCCL) per depth map")
 
 
 def tsdf_cpu_baseline(scans, opt):

@@ -88,9 +88,14 @@ int drm_forward_phase(drm_t *h, int phase);
 /* The same collective INSIDE the engine, for hosts without a collective library of their own (TANDEM's C++ back-end):
  * rank 0 draws an id (drm_comm_unique_id) and hands the 128 bytes to every rank by any means; each rank calls
  * drm_comm_init on its engine (RCCL communicator on the engine's device, librccl bound with dlopen).  From then on a
- * sharded window (drm_set_view_shard > 0) needs no host step between phases: drm_call_async / drm_forward enqueue the
- * cost-volume kernels each followed by an in-place ncclAllReduce(sum) of that volume on the engine's stream, overlapped
- * with FeatureNet's stage-2/3 heads on the side stream.  drm_forward_phase keeps the host-reduced protocol. */
+ * sharded window (drm_set_view_shard > 0) needs no host step between phases: drm_call_async / drm_forward enqueue, on
+ * the engine's stream, each cost-volume kernel followed by ncclReduce(sum) of that volume to rank 0; rank 0 alone
+ * regularises and regresses the stage and ncclBroadcast()s its depth map (stage 3: depth and confidence) -- what the next
+ * stage's hypotheses hang on -- back to every rank, so all ranks end with the same four output maps.  ((n-1)/n x 354 MB per
+ * depth map over xGMI instead of an all-reduce's 2(n-1)/n; DR_SHARD_ALLREDUCE=1 selects the all-reduce
+ * form, in which every rank regularises redundantly.)  FeatureNet's stage-2/3 heads overlap the first reduce on the side
+ * stream.  Use at most as many ranks as the window has source views.  drm_forward_phase keeps the host-reduced protocol. */
+int drm_comm_available(void);                /* DR_OK when RCCL (librccl.so.1, or $DR_RCCL_LIB) can be bound in this process */
 int drm_comm_unique_id(uint8_t id[128]);
 int drm_comm_init(drm_t *h, int rank, int world, const uint8_t id[128]);
 int drm_comm_destroy(drm_t *h);

@@ -58,6 +58,7 @@ SIGNATURES = {
     "drm_autotune": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "drm_set_view_shard": (C.c_int, [vp, C.c_int]),
     "drm_forward_phase": (C.c_int, [vp, C.c_int]),
+    "drm_comm_available": (C.c_int, []),
     "drm_comm_unique_id": (C.c_int, [u8p]),
     "drm_comm_init": (C.c_int, [vp, C.c_int, C.c_int, u8p]),
     "drm_comm_destroy": (C.c_int, [vp]),

@@ -1579,6 +1579,11 @@ using dr::guarded;
 struct drf_s {
   std::unique_ptr<dr::FusionEngine> e;
 };
+// every C-ABI entry point goes through this: a NULL handle is an argument error, not a crash
+static inline dr::FusionEngine *eng(drf_s *h) {
+  if (!h || !h->e) dr::fail(DR_ERR_ARG, "NULL handle");
+  return h->e.get();
+}
 
 extern "C" {
 
@@ -1592,38 +1597,38 @@ int drf_create(const drf_options_t *opt, int device, drf_t **out) {
 }
 void drf_destroy(drf_t *h) { delete h; }
 int drf_integrate_scan_async(drf_t *h, const uint8_t *bgr, const float *depth, const float *pose16) {
-  return guarded([&] { h->e->integrate_scan_async(bgr, depth, pose16); });
+  return guarded([&] { eng(h)->integrate_scan_async(bgr, depth, pose16); });
 }
-int drf_render_async(drf_t *h, const float *const *poses16, int n) { return guarded([&] { h->e->render_async(poses16, n); }); }
-int drf_get_render_result(drf_t *h, uint8_t **bgr, float **depth, int n) { return guarded([&] { h->e->get_render_result(bgr, depth, n); }); }
+int drf_render_async(drf_t *h, const float *const *poses16, int n) { return guarded([&] { eng(h)->render_async(poses16, n); }); }
+int drf_get_render_result(drf_t *h, uint8_t **bgr, float **depth, int n) { return guarded([&] { eng(h)->get_render_result(bgr, depth, n); }); }
 int drf_extract_mesh_async(drf_t *h, const float *lower, const float *upper) {
-  return guarded([&] { h->e->extract_mesh_async(lower, upper); });
+  return guarded([&] { eng(h)->extract_mesh_async(lower, upper); });
 }
 int drf_get_mesh_sync(drf_t *h, size_t num_max, size_t *num, float *vert, float *cols) {
-  return guarded([&] { h->e->get_mesh_sync(num_max, num, vert, cols); });
+  return guarded([&] { eng(h)->get_mesh_sync(num_max, num, vert, cols); });
 }
 int drf_mesh_num_triangles(drf_t *h, size_t *ntri) {
-  return guarded([&] { if (!ntri) dr::fail(DR_ERR_ARG, "drf_mesh_num_triangles: null argument"); *ntri = h->e->mesh_num_triangles(); });
+  return guarded([&] { if (!ntri) dr::fail(DR_ERR_ARG, "drf_mesh_num_triangles: null argument"); *ntri = eng(h)->mesh_num_triangles(); });
 }
 int drf_save_mesh(drf_t *h, const char *filename, const float *lower, const float *upper) {
-  return guarded([&] { h->e->save_mesh(filename, lower, upper); });
+  return guarded([&] { eng(h)->save_mesh(filename, lower, upper); });
 }
 int drf_get_render_device(drf_t *h, int stream, const uint8_t **d_bgr, const float **d_depth) {
-  return guarded([&] { h->e->get_render_device(stream, d_bgr, d_depth); });
+  return guarded([&] { eng(h)->get_render_device(stream, d_bgr, d_depth); });
 }
-int drf_synchronize(drf_t *h) { return guarded([&] { h->e->synchronize(); }); }
-int drf_stats(drf_t *h, uint64_t out[4]) { return guarded([&] { h->e->stats(out); }); }
+int drf_synchronize(drf_t *h) { return guarded([&] { eng(h)->synchronize(); }); }
+int drf_stats(drf_t *h, uint64_t out[4]) { return guarded([&] { eng(h)->stats(out); }); }
 int drf_export_blocks(drf_t *h, int max_blocks, int32_t *coords, uint8_t *voxels, int *n) {
-  return guarded([&] { h->e->export_blocks(max_blocks, coords, voxels, n); });
+  return guarded([&] { eng(h)->export_blocks(max_blocks, coords, voxels, n); });
 }
 int drf_fast_div_status(drf_t *h, int *enabled, uint64_t *mismatches) {
-  return guarded([&] { unsigned long long m = 0; h->e->fast_div_status(enabled, &m); if (mismatches) *mismatches = m; });
+  return guarded([&] { unsigned long long m = 0; eng(h)->fast_div_status(enabled, &m); if (mismatches) *mismatches = m; });
 }
 int drf_test_combine(drf_t *h, size_t n, const uint8_t *a, const uint8_t *b, int max_weight, uint8_t *out) {
-  return guarded([&] { if (!a || !b || !out) dr::fail(DR_ERR_ARG, "drf_test_combine: null argument"); h->e->test_combine(n, a, b, max_weight, out); });
+  return guarded([&] { if (!a || !b || !out) dr::fail(DR_ERR_ARG, "drf_test_combine: null argument"); eng(h)->test_combine(n, a, b, max_weight, out); });
 }
 int drf_integrate_device(drf_t *h, const void *d_bgr, const void *d_depth, const float *pose16) {
-  return guarded([&] { h->e->integrate_device(d_bgr, d_depth, pose16); });
+  return guarded([&] { eng(h)->integrate_device(d_bgr, d_depth, pose16); });
 }
 int dr_device_alloc(int device, size_t bytes, void **dptr) {
   return guarded([&] { DR_HIP(hipSetDevice(device)); DR_HIP(hipMalloc(dptr, bytes)); });
@@ -1634,18 +1639,23 @@ int dr_memcpy_d2d(void *dst, const void *src, size_t bytes) {
   // a device-to-device hipMemcpy may return before the copy has run, and the engines' streams are non-blocking:
   // synchronise so that whatever the caller enqueues next (on any stream) sees the data
   return guarded([&] {
-    hipPointerAttribute_t at;  // synchronise the device that owns the destination, not whichever is current on this thread
-    if (hipPointerGetAttributes(&at, dst) == hipSuccess) DR_HIP(hipSetDevice(at.device));
-    DR_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice));
-    DR_HIP(hipDeviceSynchronize());
+    hipPointerAttribute_t at;  // synchronise the device that owns the destination, not whichever is current on this thread --
+    int prev = -1;             // and leave the caller's current device as it was (a helper must not move a host thread between GPUs)
+    (void)hipGetDevice(&prev);
+    const bool moved = hipPointerGetAttributes(&at, dst) == hipSuccess && at.device != prev;
+    if (moved) DR_HIP(hipSetDevice(at.device));
+    const hipError_t e1 = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice);
+    const hipError_t e2 = e1 == hipSuccess ? hipDeviceSynchronize() : e1;
+    if (moved && prev >= 0) (void)hipSetDevice(prev);
+    DR_HIP(e2);
   });
 }
 int dr_memcpy_d2h(void *dst, const void *dptr, size_t bytes) { return guarded([&] { DR_HIP(hipMemcpy(dst, dptr, bytes, hipMemcpyDeviceToHost)); }); }
 int drf_bench_sequence(drf_t *h, const void *d_bgr, const void *d_depth, const float *poses16, int nframes, int render, float ms[6]) {
-  return guarded([&] { h->e->bench_sequence(d_bgr, d_depth, poses16, nframes, render, ms); });
+  return guarded([&] { eng(h)->bench_sequence(d_bgr, d_depth, poses16, nframes, render, ms); });
 }
 int drf_bench_integrate(drf_t *h, const void *d_bgr, const void *d_depth, const float *poses16, int nscans, float *ms, float *kernel_ms) {
-  return guarded([&] { h->e->bench_integrate(d_bgr, d_depth, poses16, nscans, ms, kernel_ms); });
+  return guarded([&] { eng(h)->bench_integrate(d_bgr, d_depth, poses16, nscans, ms, kernel_ms); });
 }
 
 }  // extern "C"

@@ -131,12 +131,18 @@ struct Rccl {
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclReduce) Reduce = nullptr;
+  decltype(&ncclBroadcast) Broadcast = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   static Rccl &get() {
     static Rccl r;
     static std::mutex m;
     std::lock_guard<std::mutex> g(m);
     if (!r.lib) {
+      // DR_RCCL_LIB: bind this library instead (tests/test_view_shard_gpu.py runs two ranks on one GPU against a
+      // shared-memory stand-in, tests/cpp/rccl_stub.cpp: RCCL itself refuses two ranks on one device)
+      if (const char *e = getenv("DR_RCCL_LIB")) r.lib = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
+      else
       for (const char *n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
         if ((r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
       if (!r.lib) fail(DR_ERR_UNSUPPORTED, "RCCL not found (librccl.so.1): %s", dlerror());
@@ -144,8 +150,10 @@ struct Rccl {
       r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
       r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
       r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.lib, "ncclAllReduce"));
+      r.Reduce = reinterpret_cast<decltype(r.Reduce)>(dlsym(r.lib, "ncclReduce"));
+      r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(dlsym(r.lib, "ncclBroadcast"));
       r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
-      if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString) {
+      if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.Reduce || !r.Broadcast || !r.GetErrorString) {
         r.lib = nullptr;
         fail(DR_ERR_UNSUPPORTED, "RCCL: missing symbols in librccl");
       }
@@ -254,6 +262,7 @@ class MvsEngine {
   void autotune(int k, float *before_ms, float *after_ms) {
     std::unique_lock<std::mutex> lk(mu_);
     require_config();
+    if (comm_ && shard_nsrc_) fail(DR_ERR_PROTOCOL, "autotune(): not on a view-sharded engine (tune the unsharded plan)");
     DR_HIP(hipSetDevice(device_));
     hipEvent_t e0, e1;
     DR_HIP(hipEventCreate(&e0)); DR_HIP(hipEventCreate(&e1));
@@ -321,6 +330,7 @@ class MvsEngine {
     memcpy(&id, unique_id, sizeof id);
     r.check(r.CommInitRank(&comm_, world, id, rank), "ncclCommInitRank");
     comm_world_ = world;
+    comm_rank_ = rank;
   }
   void comm_destroy() {
     std::unique_lock<std::mutex> lk(mu_);
@@ -384,6 +394,7 @@ class MvsEngine {
   void profile(std::string &names, std::vector<float> &ms) {
     std::unique_lock<std::mutex> lk(mu_);
     require_config();
+    if (comm_ && shard_nsrc_) fail(DR_ERR_PROTOCOL, "profile(): a view-sharded engine enqueues collectives -- every rank would have to profile in lockstep");
     DR_HIP(hipSetDevice(device_));
     forward(nullptr);  // warm
     std::vector<hipEvent_t> ev(ops_.size() + 1);
@@ -787,11 +798,15 @@ class MvsEngine {
   // The next forward's main-stream work is ordered after those waits, so the side stream never runs ahead of a reader.
   void forward(std::vector<hipEvent_t> *ev, size_t first = 0, size_t last = ~(size_t)0) {
     const bool fork = side_enabled_ && !ev && first == 0 && last >= ops_.size() && fork_lo_ < fork_hi_;
+    // view shard, reduce-to-root form: between a stage's cost volume and its regression only rank 0 works
+    const bool rooted = comm_ && shard_nsrc_ && !phase_mode_ && !shard_allreduce_;
+    bool idle_stage = false;
     size_t i = 0;
     for (const Op &o : ops_) {
       if (ev) DR_HIP(hipEventRecord((*ev)[i], stream_));
       ++i;
       if (i - 1 < first || i - 1 >= last) continue;
+      if (idle_stage && o.kind != Op::REGRESS) continue;  // (CostRegNet and prob of this stage run on rank 0 only)
       const bool on_side = fork && i - 1 >= fork_lo_ && i - 1 < fork_hi_;
       if (fork && i - 1 == fork_lo_) { DR_HIP(hipEventRecord(ev_fork_, stream_)); DR_HIP(hipStreamWaitEvent(side_, ev_fork_, 0)); }
       if (fork && o.kind == Op::COSTVOL && o.stage == 2) DR_HIP(hipStreamWaitEvent(stream_, ev_feat2_, 0));
@@ -870,13 +885,26 @@ class MvsEngine {
           if (comm_ && shard_nsrc_ && !phase_mode_) {  // view shard: sum the partial volumes of all ranks, in place, in stream order
             const DevTensor &vol = T("volume" + std::to_string(o.stage));
             Rccl &r = Rccl::get();
-            r.check(r.AllReduce(vol.d, vol.d, vol.n(), ncclFloat, ncclSum, comm_, stream_), "ncclAllReduce");
+            if (rooted) {
+              r.check(r.Reduce(vol.d, vol.d, vol.n(), ncclFloat, ncclSum, 0, comm_, stream_), "ncclReduce");
+              idle_stage = comm_rank_ != 0;
+            } else r.check(r.AllReduce(vol.d, vol.d, vol.n(), ncclFloat, ncclSum, comm_, stream_), "ncclAllReduce");
           }
           break;
         }
         case Op::REGRESS: {
           const RegressArgs &r = rg_[o.stage - 1];
-          hipLaunchKernelGGL(k_regress, dim3(cdiv(r.h * r.w, 256)), dim3(256), 0, stream_, r);
+          if (!idle_stage) hipLaunchKernelGGL(k_regress, dim3(cdiv(r.h * r.w, 256)), dim3(256), 0, stream_, r);
+          if (rooted) {  // the stage's depth map goes back to every rank: stage s + 1 centres its hypotheses on it; stage 3's
+            Rccl &c = Rccl::get();  // depth and confidence are the result (the edge filter then runs on every rank: 0.08 ms)
+            const DevTensor &dep = T("depth" + std::to_string(o.stage));
+            c.check(c.Broadcast(dep.d, dep.d, dep.n(), ncclFloat, 0, comm_, stream_), "ncclBroadcast");
+            if (o.stage == 3) {
+              const DevTensor &cf = T("conf3");
+              c.check(c.Broadcast(cf.d, cf.d, cf.n(), ncclFloat, 0, comm_, stream_), "ncclBroadcast");
+            }
+            idle_stage = false;
+          }
           break;
         }
         case Op::EDGE:
@@ -930,7 +958,13 @@ class MvsEngine {
   int H_ = 0, W_ = 0, V_ = 0;
   int shard_nsrc_ = 0;  // > 0: view-shard rank, cost-volume divisor = source views of the whole window
   ncclComm_t comm_ = nullptr;  // view-shard communicator (drm_comm_init); the volumes are reduced in stream order when set
-  int comm_world_ = 0;
+  int comm_world_ = 0, comm_rank_ = 0;
+  // Collective form of a sharded forward.  Default: the partial volumes are REDUCED to rank 0, which alone regularises and
+  // regresses the stage, and the stage's depth map (what the next stage's hypotheses hang on: 77 / 307 / 1229 KB) is
+  // BROADCAST back -- (n-1)/n x 354 MB over xGMI per depth map instead of the all-reduce's 2(n-1)/n, and no redundant
+  // CostRegNet on the other ranks.  DR_SHARD_ALLREDUCE=1: round 2's form (sum all-reduce, every rank
+  // regularises redundantly; no broadcast).
+  bool shard_allreduce_ = getenv("DR_SHARD_ALLREDUCE") != nullptr;
   bool phase_mode_ = false;
 
   std::thread worker_;
@@ -949,6 +983,11 @@ using dr::guarded;
 struct drm_s {
   std::unique_ptr<dr::MvsEngine> e;
 };
+// every C-ABI entry point goes through this: a NULL handle is an argument error, not a crash
+static inline dr::MvsEngine *eng(drm_s *h) {
+  if (!h || !h->e) dr::fail(DR_ERR_ARG, "NULL handle");
+  return h->e.get();
+}
 
 extern "C" {
 
@@ -966,23 +1005,24 @@ int drm_create(const char *weights_path, int device, drm_t **out) {
 void drm_destroy(drm_t *h) { delete h; }
 int drm_call_async(drm_t *h, int height, int width, int view_num, int ref_index, const uint8_t *const *bgrs, const float *K9,
                    const float *const *c2ws, float depth_min, float depth_max, float discard_percentage) {
-  return guarded([&] { h->e->call_async(height, width, view_num, ref_index, bgrs, K9, c2ws, depth_min, depth_max, discard_percentage); });
+  return guarded([&] { eng(h)->call_async(height, width, view_num, ref_index, bgrs, K9, c2ws, depth_min, depth_max, discard_percentage); });
 }
-int drm_ready(drm_t *h) { return h->e->ready() ? 1 : 0; }
-int drm_wait(drm_t *h) { return guarded([&] { h->e->wait(); }); }
+int drm_ready(drm_t *h) { return (h && h->e && h->e->ready()) ? 1 : 0; }
+int drm_wait(drm_t *h) { return guarded([&] { eng(h)->wait(); }); }
 int drm_get_result(drm_t *h, float *depth, float *confidence, float *depth_dense, float *confidence_dense) {
-  return guarded([&] { h->e->get_result(depth, confidence, depth_dense, confidence_dense); });
+  return guarded([&] { eng(h)->get_result(depth, confidence, depth_dense, confidence_dense); });
 }
 int drm_upload(drm_t *h, int height, int width, int view_num, int ref_index, const uint8_t *const *bgrs, const float *K9,
                const float *const *c2ws, float depth_min, float depth_max, float discard_percentage) {
-  return guarded([&] { h->e->upload(height, width, view_num, ref_index, bgrs, K9, c2ws, depth_min, depth_max, discard_percentage); });
+  return guarded([&] { eng(h)->upload(height, width, view_num, ref_index, bgrs, K9, c2ws, depth_min, depth_max, discard_percentage); });
 }
-int drm_forward(drm_t *h, int iters, float *ms_total) { return guarded([&] { h->e->forward_n(iters, ms_total); }); }
+int drm_forward(drm_t *h, int iters, float *ms_total) { return guarded([&] { eng(h)->forward_n(iters, ms_total); }); }
 int drm_autotune(drm_t *h, int max_candidates, float *before_ms, float *after_ms) {
-  return guarded([&] { h->e->autotune(max_candidates, before_ms, after_ms); });
+  return guarded([&] { eng(h)->autotune(max_candidates, before_ms, after_ms); });
 }
-int drm_set_view_shard(drm_t *h, int nsrc_total) { return guarded([&] { h->e->set_view_shard(nsrc_total); }); }
-int drm_forward_phase(drm_t *h, int phase) { return guarded([&] { h->e->forward_phase(phase); }); }
+int drm_set_view_shard(drm_t *h, int nsrc_total) { return guarded([&] { eng(h)->set_view_shard(nsrc_total); }); }
+int drm_forward_phase(drm_t *h, int phase) { return guarded([&] { eng(h)->forward_phase(phase); }); }
+int drm_comm_available(void) { return guarded([&] { (void)dr::Rccl::get(); }); }
 int drm_comm_unique_id(uint8_t id[128]) {
   return guarded([&] {
     if (!id) dr::fail(DR_ERR_ARG, "drm_comm_unique_id: null argument");
@@ -993,36 +1033,36 @@ int drm_comm_unique_id(uint8_t id[128]) {
     memcpy(id, &u, 128);
   });
 }
-int drm_comm_init(drm_t *h, int rank, int world, const uint8_t id[128]) { return guarded([&] { h->e->comm_init(rank, world, id); }); }
-int drm_comm_destroy(drm_t *h) { return guarded([&] { h->e->comm_destroy(); }); }
+int drm_comm_init(drm_t *h, int rank, int world, const uint8_t id[128]) { return guarded([&] { eng(h)->comm_init(rank, world, id); }); }
+int drm_comm_destroy(drm_t *h) { return guarded([&] { eng(h)->comm_destroy(); }); }
 int drm_device_tensor(drm_t *h, const char *name, void **dptr, size_t *nfloats) {
-  return guarded([&] { if (!name) dr::fail(DR_ERR_ARG, "drm_device_tensor: null name"); h->e->device_tensor(name, dptr, nfloats); });
+  return guarded([&] { if (!name) dr::fail(DR_ERR_ARG, "drm_device_tensor: null name"); eng(h)->device_tensor(name, dptr, nfloats); });
 }
 int drm_download(drm_t *h, float *depth, float *confidence, float *depth_dense, float *confidence_dense) {
-  return guarded([&] { h->e->download(depth, confidence, depth_dense, confidence_dense); });
+  return guarded([&] { eng(h)->download(depth, confidence, depth_dense, confidence_dense); });
 }
 int drm_get_stage_output(drm_t *h, int stage, float *depth, float *confidence) {
   return guarded([&] {
     if (stage < 1 || stage > 3) dr::fail(DR_ERR_ARG, "stage must be 1..3");
     size_t n; int dims[4];
-    h->e->get_tensor(("depth" + std::to_string(stage)).c_str(), nullptr, 0, &n, dims);
-    h->e->get_tensor(("depth" + std::to_string(stage)).c_str(), depth, n, &n, dims);
-    h->e->get_tensor(("conf" + std::to_string(stage)).c_str(), confidence, n, &n, dims);
+    eng(h)->get_tensor(("depth" + std::to_string(stage)).c_str(), nullptr, 0, &n, dims);
+    eng(h)->get_tensor(("depth" + std::to_string(stage)).c_str(), depth, n, &n, dims);
+    eng(h)->get_tensor(("conf" + std::to_string(stage)).c_str(), confidence, n, &n, dims);
   });
 }
 int drm_get_tensor(drm_t *h, const char *name, float *out, size_t n_max, size_t *n, int dims[4]) {
-  return guarded([&] { h->e->get_tensor(name, out, n_max, n, dims); });
+  return guarded([&] { eng(h)->get_tensor(name, out, n_max, n, dims); });
 }
 int drm_profile(drm_t *h, char *names, size_t names_cap, float *ms, int cap, int *count) {
   return guarded([&] {
     std::string nm; std::vector<float> t;
-    h->e->profile(nm, t);
+    eng(h)->profile(nm, t);
     if (count) *count = (int)t.size();
     if (names && names_cap) { strncpy(names, nm.c_str(), names_cap - 1); names[names_cap - 1] = 0; }
     for (int i = 0; i < (int)t.size() && i < cap; ++i) ms[i] = t[i];
   });
 }
-int drm_work(drm_t *h, double *flops, double *bytes) { return guarded([&] { h->e->work(flops, bytes); }); }
+int drm_work(drm_t *h, double *flops, double *bytes) { return guarded([&] { eng(h)->work(flops, bytes); }); }
 
 int drm_debug_conv(int device, const float *in, int D, int H, int W, int Cin, const float *weight, int Cout, int kd, int kh, int kw,
                    int sd, int sh, int sw, int transposed, const float *scale, const float *bias, int relu, const float *add,

@@ -472,6 +472,11 @@ using dr::guarded;
 struct drt_s {
   std::unique_ptr<dr::TrackerEngine> e;
 };
+// every C-ABI entry point goes through this: a NULL handle is an argument error, not a crash
+static inline dr::TrackerEngine *eng(drt_s *h) {
+  if (!h || !h->e) dr::fail(DR_ERR_ARG, "NULL handle");
+  return h->e.get();
+}
 
 extern "C" {
 
@@ -484,30 +489,30 @@ int drt_create(int w, int h, float setting_huberTH, float setting_coarseCutoffTH
   });
 }
 void drt_destroy(drt_t *t) { delete t; }
-int drt_set_k(drt_t *t, int w, int h, float fx, float fy, float cx, float cy) { return guarded([&] { t->e->set_k(w, h, fx, fy, cx, cy); }); }
-int drt_init(drt_t *t, int n_max) { return guarded([&] { t->e->init(n_max); }); }
+int drt_set_k(drt_t *t, int w, int h, float fx, float fy, float cx, float cy) { return guarded([&] { eng(t)->set_k(w, h, fx, fy, cx, cy); }); }
+int drt_init(drt_t *t, int n_max) { return guarded([&] { eng(t)->init(n_max); }); }
 int drt_set_reference(drt_t *t, int n, const float *pc_u, const float *pc_v, const float *pc_idepth, const float *pc_color, float ref_exposure,
                       const double ref_aff_g2l[2]) {
-  return guarded([&] { t->e->set_reference(n, pc_u, pc_v, pc_idepth, pc_color, ref_exposure, ref_aff_g2l); });
+  return guarded([&] { eng(t)->set_reference(n, pc_u, pc_v, pc_idepth, pc_color, ref_exposure, ref_aff_g2l); });
 }
-int drt_set_new(drt_t *t, const float *dInew) { return guarded([&] { t->e->set_new(dInew); }); }
+int drt_set_new(drt_t *t, const float *dInew) { return guarded([&] { eng(t)->set_new(dInew); }); }
 int drt_calc_res(drt_t *t, const double refToNew[16], float new_exposure, const double aff_g2l[2], float cutoffTH, double out6[6], double sums7[7]) {
-  return guarded([&] { t->e->calc_res(refToNew, new_exposure, aff_g2l, cutoffTH, out6, sums7); });
+  return guarded([&] { eng(t)->calc_res(refToNew, new_exposure, aff_g2l, cutoffTH, out6, sums7); });
 }
 int drt_calc_g(drt_t *t, double H_out[64], double b_out[8], float new_exposure, const double aff_g2l[2], double raw45[45]) {
-  return guarded([&] { t->e->calc_g(H_out, b_out, new_exposure, aff_g2l, raw45); });
+  return guarded([&] { eng(t)->calc_g(H_out, b_out, new_exposure, aff_g2l, raw45); });
 }
 int drt_append_dense_reference(drt_t *t, const float *depth, const float KRKi[9], const float Kt[3], int step, int dense_only, const float *idepth0,
                                const float *dIp0, int on_device, int *n_out) {
-  return guarded([&] { const int n = t->e->append_dense(depth, KRKi, Kt, step, dense_only, idepth0, dIp0, on_device); if (n_out) *n_out = n; });
+  return guarded([&] { const int n = eng(t)->append_dense(depth, KRKi, Kt, step, dense_only, idepth0, dIp0, on_device); if (n_out) *n_out = n; });
 }
 int drt_get_points(drt_t *t, float *pc_u, float *pc_v, float *pc_idepth, float *pc_color, int cap, int *n) {
-  return guarded([&] { t->e->get_points(pc_u, pc_v, pc_idepth, pc_color, cap, n); });
+  return guarded([&] { eng(t)->get_points(pc_u, pc_v, pc_idepth, pc_color, cap, n); });
 }
-int drt_get_warped(drt_t *t, int which, float *out, int cap) { return guarded([&] { t->e->get_warped(which, out, cap); }); }
-int drt_get_zbuffer(drt_t *t, float *out) { return guarded([&] { t->e->get_zbuffer(out); }); }
-int drt_synchronize(drt_t *t) { return guarded([&] { t->e->synchronize(); }); }
-int drt_start_timing(drt_t *t) { return guarded([&] { t->e->start_timing(); }); }
-int drt_end_timing_ms(drt_t *t, float *ms) { return guarded([&] { const float v = t->e->end_timing_ms(); if (ms) *ms = v; }); }
+int drt_get_warped(drt_t *t, int which, float *out, int cap) { return guarded([&] { eng(t)->get_warped(which, out, cap); }); }
+int drt_get_zbuffer(drt_t *t, float *out) { return guarded([&] { eng(t)->get_zbuffer(out); }); }
+int drt_synchronize(drt_t *t) { return guarded([&] { eng(t)->synchronize(); }); }
+int drt_start_timing(drt_t *t) { return guarded([&] { eng(t)->start_timing(); }); }
+int drt_end_timing_ms(drt_t *t, float *ms) { return guarded([&] { const float v = eng(t)->end_timing_ms(); if (ms) *ms = v; }); }
 
 }  // extern "C"

@@ -107,6 +107,11 @@ class DrMvsnet:
         check(_lib.lib().drm_forward_phase(self._h, int(phase)))
 
     @staticmethod
+    def comm_available():
+        """True when this process can bind RCCL (librccl.so.1 or $DR_RCCL_LIB) for the in-engine collective."""
+        return _lib.lib().drm_comm_available() == 0
+
+    @staticmethod
     def comm_unique_id():
         """128-byte RCCL id drawn by one rank; hand it to every rank's comm_init."""
         buf = (C.c_uint8 * 128)()
@@ -114,7 +119,8 @@ class DrMvsnet:
         return bytes(buf)
 
     def comm_init(self, rank, world, unique_id):
-        """In-engine view-shard collective: afterwards a sharded window's cost volumes are all-reduced on the engine's stream."""
+        """In-engine view-shard collective: afterwards a sharded window's cost volumes are reduced to rank 0 and the stage depth
+        maps broadcast back on the engine's stream (include/dr_mi355x.h)."""
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         check(_lib.lib().drm_comm_init(self._h, int(rank), int(world), buf))
 

@@ -6,10 +6,13 @@ Where the exchange is: the reference builds the stage volume as  sum_v (gate_v +
 FeatureNet runs per view, everything after the volume has no view axis).  So rank r
   * runs FeatureNet on [reference view] + its own source views only,
   * builds the partial volume of its views with the WHOLE window's divisor (drm_set_view_shard),
-  * all-reduces (sum) the fp32 volume in place: 118 / 157 / 79 MB for stages 1..3 at 640x480, (48,32,8),
-  * runs the (view-free) regularisation, regression and -- after stage 3 -- the edge filter redundantly, so every
-    rank ends with the same depth map and no broadcast of the stage depth (the next stage's planes) is needed.
-Ranks beyond the number of source views hold the reference view only and contribute a zero volume.
+  * in-engine collective (drm_comm_*, the form bench.py measures): the fp32 volume (118 / 157 / 79 MB for stages 1..3 at
+    640x480, (48,32,8)) is REDUCED to rank 0, which alone runs the (view-free) regularisation and regression and
+    BROADCASTS the stage's depth map (77 / 307 / 1229 KB; stage 3: depth + confidence) back -- the next stage's planes
+    hang on it; every rank then runs the edge filter and ends with the same four maps;
+  * host-driven protocol (drm_forward_phase + any all-reduce; the gloo / one-GPU test double): the volume is sum
+    all-reduced in place and every rank regularises redundantly, so no broadcast is needed.
+At most one rank per source view takes part (shard_world): further ranks would only add zero volumes to the reduce.
 
 This is NOT the throughput configuration: by SURVEY 5.8/8e the reduce alone (>= 2.3 ms per depth map over xGMI)
 exceeds the whole single-GPU pipeline (bench.py's replicas mode is the headline); it exists for windows whose
@@ -75,23 +78,38 @@ def forward(model, allreduce):
     model.forward_phase(3)
 
 
-def init_engine_collective(model, rank, world):
-    """Give `model` an RCCL communicator of its own (drm_comm_init): rank 0 draws the id, torch.distributed carries the 128
-    bytes to the other ranks.  Afterwards `model.forward(n)` / CallAsync run a sharded window without any host step.
-    Returns False (on every rank alike) when rank 0 could not bind RCCL; the caller then uses the host-driven phases."""
+def shard_world(view_num, world):
+    """Ranks that take part in a sharded window: at most one per source view (a rank without source views would only add a
+    zero volume to the reduce; with 8 GPUs and 6 source views two ranks stay out)."""
+    return max(1, min(world, view_num - 1))
+
+
+def init_engine_collective(model, rank, world, participants=None):
+    """Give `model` an RCCL communicator of its own (drm_comm_init) over the first `participants` ranks (default: all):
+    every rank probes whether it can bind RCCL and the ranks agree (MIN over the group) BEFORE anyone enters
+    ncclCommInitRank -- a rank that cannot must not leave the others blocked in it.  Rank 0 draws the id, torch.distributed
+    carries the 128 bytes.  Afterwards `model.forward(n)` / CallAsync run a sharded window without any host step.
+    Returns False (on every rank alike) when some rank could not bind RCCL; the caller then uses the host-driven phases.
+    Ranks >= participants return True without a communicator: they take no part in the window."""
     import sys
+    import torch
     import torch.distributed as dist
-    uid = [None]
-    if rank == 0:
-        try:
-            uid = [model.comm_unique_id()]
-        except Exception as e:  # no librccl.so.1 to bind: every rank learns it from the broadcast and falls back together
-            print("view_shard: engine collective unavailable (%s); using torch.distributed" % e, file=sys.stderr)
+    participants = world if participants is None else participants
+    ok = 1 if type(model).comm_available() else 0
+    if world > 1:
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = int(t.item())
+    if not ok:
+        if rank == 0:
+            print("view_shard: engine collective unavailable on some rank; using torch.distributed", file=sys.stderr)
+        return False
+    uid = [type(model).comm_unique_id() if rank == 0 else None]
     if world > 1:
         dist.broadcast_object_list(uid, src=0)
-    if uid[0] is None:
-        return False
-    model.comm_init(rank, world, uid[0])
+    if rank < participants:
+        model.comm_init(rank, participants, uid[0])
     return True
 
 

@@ -144,7 +144,7 @@ def _strip(name):
     return name
 
 
-def load_reference_weights(path):
+def load_reference_weights(path, allow_pickle=False):
     """Reads what the reference can hand over for a trained CVA-MVSNet and returns (state dict name -> float32 array,
     hparams dict or None):
       * a PyTorch-Lightning checkpoint written by cva_mvsnet/train.py (dict with 'state_dict' whose keys carry the
@@ -157,7 +157,13 @@ def load_reference_weights(path):
     try:
         sd = torch.jit.load(path, map_location="cpu").state_dict()
     except Exception:
-        obj = torch.load(path, map_location="cpu", weights_only=False)
+        try:  # tensors and plain containers only: no code from the file is executed
+            obj = torch.load(path, map_location="cpu", weights_only=True)
+        except Exception as e:
+            if not allow_pickle:
+                raise ValueError("%s cannot be read with weights_only=True (%s); a Lightning checkpoint that pickles arbitrary objects needs "
+                                 "--allow-pickle, which EXECUTES code stored in the file -- only for checkpoints you trust" % (path, str(e).splitlines()[0][:120]))
+            obj = torch.load(path, map_location="cpu", weights_only=False)
         if isinstance(obj, dict) and "state_dict" in obj:
             hparams = obj.get("hparams") or obj.get("hyper_parameters")
             sd = obj["state_dict"]
@@ -175,12 +181,19 @@ def load_reference_weights(path):
     return out, (dict(hparams) if hparams else None)
 
 
-def convert(path, out_path, depth_num=None, interval_ratio=None, view_aggregation=None):
+def convert(path, out_path, depth_num=None, interval_ratio=None, view_aggregation=None, allow_pickle=False):
     """`python -m tandem_amd.weights <ckpt | model.pt> out.tdmw`: header fields come from the checkpoint's hyper-parameters
     (MODEL.DEPTH_NUM, MODEL.DEPTH_INTERVAL_RATIO, MODEL.VIEW_AGGREGATION, MODEL.FEATURE_NET_BASE_CHANNELS; config.py) when
     it has them, else from the arguments; view aggregation is recognised by the volume_gates.* parameters."""
-    sd, hp = load_reference_weights(path)
+    sd, hp = load_reference_weights(path, allow_pickle)
     hp = hp or {}
+    # The hypothesis counts are NOT in the parameters: a TorchScript model.pt (and a bare state_dict) does not carry them,
+    # and the shipped tandem_512x320/model.pt is a (48,4,4) model -- a silent (48,32,8) default would write a blob that
+    # loads, runs and is wrong.
+    if not depth_num and "MODEL.DEPTH_NUM" not in hp:
+        raise ValueError("%s stores no hyper-parameters: pass --depth-num (e.g. 48,32,8; 48,4,4 for the shipped tandem_512x320 model)" % path)
+    if int(hp.get("MODEL.COST_VOLUME_BASE_CHANNELS", 8)) != 8:
+        raise ValueError("MODEL.COST_VOLUME_BASE_CHANNELS=%s: only 8 (the architecture TANDEM ships) is supported" % hp["MODEL.COST_VOLUME_BASE_CHANNELS"])
     if (hp.get("MODEL.CONV2D_NORMALIZATION", "batchnorm") != "batchnorm" or hp.get("MODEL.CONV3D_NORMALIZATION", "batchnorm") != "batchnorm"
             or hp.get("MODEL.CONV2D_USE_BN_SKIP", False)):
         raise ValueError("only the batchnorm / no-BN-skip architecture TANDEM ships is supported")
@@ -209,8 +222,9 @@ def _main(argv=None):
                     help="e.g. 48,4,4 (the shipped tandem_512x320 model) -- needed for model.pt, which does not store it")
     ap.add_argument("--interval-ratio", type=lambda s: tuple(float(v) for v in s.split(",")), default=None)
     ap.add_argument("--view-aggregation", type=int, choices=(0, 1), default=None)
+    ap.add_argument("--allow-pickle", action="store_true", help="fall back to torch.load(weights_only=False) -- executes code stored in the checkpoint")
     a = ap.parse_args(argv)
-    info = convert(a.input, a.output, a.depth_num, a.interval_ratio, a.view_aggregation)
+    info = convert(a.input, a.output, a.depth_num, a.interval_ratio, a.view_aggregation, a.allow_pickle)
     print("wrote %s: %d tensors, depth_num %s, interval ratio %s, view aggregation %s, base channels %d"
           % (a.output, info["tensors"], info["depth_num"], info["interval_ratio"], info["view_aggregation"], info["base_channels"]))
 

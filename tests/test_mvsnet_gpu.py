@@ -4,7 +4,9 @@
 Tolerance (floating point, stated): the reference's own acceptance test passes at mean-abs error < 1e-2 for
 stage-3 depth and confidence (dr_mvsnet.cpp:505-513).  We hold the HIP path to
     mean|depth - ref| < 1e-4 m,  mean|confidence - ref| < 1e-4,
-    99.9 % of depth_dense pixels within 2e-3 m,  filter-mask disagreement < 0.2 % of pixels
+    99.9 % of depth_dense pixels within 2e-3 m,  EVERY depth_dense pixel within 2 % of the depth range (5e-2 m at the
+    windows used here: a hypothesis interval of the last stage is ~1e-2 m, so no pixel may jump planes by more than a few),
+    filter-mask disagreement < 0.2 % of pixels
 (fp32 reassociation in convolutions moves values by ~1e-5; the confidence index trunc(E[k]) and the exact
 quantile threshold are discontinuous, so isolated pixels may flip -- counted, not hidden)."""
 import glob
@@ -21,6 +23,7 @@ def compare(out, ref, what=""):
     d_err = np.abs(out.depth_dense - ref["depth_dense"])
     assert d_err.mean() < 1e-4, f"{what} depth_dense mean err {d_err.mean()}"
     assert (d_err < 2e-3).mean() > 0.999, f"{what} depth_dense outliers {(d_err >= 2e-3).mean()}"
+    assert d_err.max() < 5e-2, f"{what} depth_dense max err {d_err.max()} m"  # no pixel is arbitrarily wrong (observed max: 6e-4 m)
     assert np.abs(out.confidence_dense - ref["confidence_dense"]).mean() < 1e-4
     flips = ((out.depth == 0) != (ref["depth"] == 0)).mean()
     assert flips < 2e-3, f"{what} mask flips {flips}"

@@ -113,13 +113,19 @@ def test_two_rank_gloo_view_shard(tmp_path):
 
 
 def test_engine_collective_falls_back_when_rccl_cannot_be_bound():
-    """init_engine_collective must not raise when the engine cannot draw an RCCL id (no librccl.so.1): it reports False --
-    on every rank alike, the id travels by broadcast -- and bench.py's sharded leg then uses the host-driven phases."""
+    """init_engine_collective must not raise -- and must not enter ncclCommInitRank on any rank -- when some rank cannot bind
+    RCCL: every rank probes (drm_comm_available), the ranks agree on the minimum, it reports False on every rank alike and
+    bench.py's sharded leg then uses the host-driven phases."""
     from tandem_amd import view_shard
 
     class NoRccl:
-        def comm_unique_id(self):
-            raise RuntimeError("librccl.so.1: cannot open shared object file")
+        @staticmethod
+        def comm_available():
+            return False
+
+        @staticmethod
+        def comm_unique_id():
+            raise AssertionError("must not be reached when RCCL cannot be bound")
 
         def comm_init(self, rank, world, uid):
             raise AssertionError("must not be reached without an id")
@@ -128,7 +134,12 @@ def test_engine_collective_falls_back_when_rccl_cannot_be_bound():
         def __init__(self):
             self.got = None
 
-        def comm_unique_id(self):
+        @staticmethod
+        def comm_available():
+            return True
+
+        @staticmethod
+        def comm_unique_id():
             return b"\x01" * 128
 
         def comm_init(self, rank, world, uid):
@@ -137,3 +148,4 @@ def test_engine_collective_falls_back_when_rccl_cannot_be_bound():
     assert view_shard.init_engine_collective(NoRccl(), 0, 1) is False
     m = WithRccl()
     assert view_shard.init_engine_collective(m, 0, 1) is True and m.got == (0, 1, b"\x01" * 128)
+    assert view_shard.shard_world(7, 8) == 6 and view_shard.shard_world(7, 2) == 2 and view_shard.shard_world(2, 8) == 1

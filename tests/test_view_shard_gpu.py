@@ -158,3 +158,82 @@ def test_engine_collective_single_rank(trained_blob):
             assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
         b.comm_destroy()
     a.close(); b.close()
+
+
+_RANK_SCRIPT = r'''
+import os, sys, time
+import numpy as np
+rank, world, outdir, blob, H, W, V = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
+sys.path.insert(0, sys.argv[8])
+from synth import scene
+from tandem_amd import view_shard
+from tandem_amd.dr_mvsnet import DrMvsnet
+win = scene.make_window(H, W, V, seed=11)
+window = dict(bgrs=win["bgrs"], K=win["K"], c2ws=list(win["c2ws"]), ref_index=win["ref_index"], depth_min=0.5, depth_max=5.0, discard=2.5)
+assert DrMvsnet.comm_available()
+m = DrMvsnet(blob)
+uidf = os.path.join(outdir, "uid.bin")
+if rank == 0:
+    open(uidf + ".tmp", "wb").write(DrMvsnet.comm_unique_id())
+    os.rename(uidf + ".tmp", uidf)
+t0 = time.time()
+while not os.path.exists(uidf):
+    assert time.time() - t0 < 60
+    time.sleep(0.05)
+m.comm_init(rank, world, open(uidf, "rb").read())
+mine = view_shard.upload(m, window, rank, world)
+m.forward(2)  # two depth maps back to back: the collectives of consecutive forwards stay in step
+o = m.download()
+np.savez(os.path.join(outdir, "rank%d.npz" % rank), depth=o.depth, conf=o.confidence, dd=o.depth_dense, cd=o.confidence_dense, mine=np.array(mine))
+m.comm_destroy()
+m.close()
+'''
+
+
+@pytest.mark.parametrize("world,allreduce", [(2, False), (3, False), (2, True)])
+def test_engine_collective_with_several_ranks_on_one_gpu(world, allreduce, tmp_path, trained_blob):
+    """The engine's OWN multi-rank path -- drm_comm_init, then per stage ncclReduce of the cost volume to rank 0, CostRegNet
+    and regression on rank 0 only, ncclBroadcast of the stage depth map (stage 3: depth + confidence) back; or, with
+    DR_SHARD_ALLREDUCE=1, round 2's in-place all-reduce -- with world > 1.  RCCL refuses two ranks on one device, so the
+    ranks are processes sharing cuda:0 and the engine binds tests/cpp/rccl_stub.cpp (shared-memory stand-in, prototypes
+    from the real rccl.h) through DR_RCCL_LIB.  Checked: every rank ends with the same four maps (bit for bit) and they
+    equal the unsharded engine's to fp32 summation order; two forwards in a row stay in step."""
+    import os
+    import subprocess
+    import sys
+    from synth import scene
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stub = str(tmp_path / "librccl_stub.so")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(root, "tests", "cpp", "rccl_stub.cpp"), "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-o", stub])
+    H, W, V = 64, 96, 7
+    script = str(tmp_path / "rank.py")
+    open(script, "w").write(_RANK_SCRIPT)
+    env = dict(os.environ, DR_RCCL_LIB=stub)
+    if allreduce:
+        env["DR_SHARD_ALLREDUCE"] = "1"
+    procs = [subprocess.Popen([sys.executable, script, str(r), str(world), str(tmp_path), trained_blob, str(H), str(W), str(V), root], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    for p in procs:
+        try:
+            _, err = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("a rank hung in the collective path")
+        assert p.returncode == 0, err[-3000:]
+    win = scene.make_window(H, W, V, seed=11)
+    full = DrMvsnet(trained_blob)
+    full.CallAsync(H, W, V, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), 0.5, 5.0, 2.5)
+    ref = full.GetResult()
+    full.close()
+    outs = [np.load(str(tmp_path / ("rank%d.npz" % r))) for r in range(world)]
+    assert sorted(i for o in outs for i in o["mine"][1:]) == [i for i in range(V) if i != win["ref_index"]]
+    for o in outs:
+        assert np.abs(o["dd"] - ref.depth_dense).max() < DEPTH_TOL
+        assert np.abs(o["cd"] - ref.confidence_dense).mean() < 1e-4
+        assert ((o["depth"] == 0) != (ref.depth == 0)).mean() < 2e-3
+    for o in outs[1:]:
+        for k in ("depth", "conf", "dd", "cd"):
+            assert np.array_equal(o[k].view(np.uint32), outs[0][k].view(np.uint32)), k
