@@ -627,7 +627,7 @@ def main():
                        "reference_published": "2.70 FPS (abl03, unstated GPU, incl. data loading) -- not the same clock, so vs_baseline is null"},
             "event_ms_per_step": mv["event_ms_per_step"],
         }
-        for k in ("roofline", "cpu_baseline", "pipeline", "engines_per_gpu", "single_engine"):
+        for k in ("repeats", "roofline", "cpu_baseline", "pipeline", "engines_per_gpu", "single_engine"):
             if k in mv:
                 out[k] = mv[k]
         if ts is not None:

@@ -1074,6 +1074,7 @@ static void inverse4_host(const float *e, float *out) {
 }
 
 // ------------------------------------------------------------------ engine
+constexpr int kDefaultFusionPriority = 0;  // 0 least (the reference's), 1 normal, 2 greatest
 class FusionEngine {
  public:
   FusionEngine(const drf_options_t &o, int device) : device_(device), o_(o) {
@@ -1084,9 +1085,14 @@ class FusionEngine {
     if (o.height <= 0 || o.width <= 0 || o.num_blocks <= 0 || o.num_buckets <= 0 || o.bucket_size <= 0 || o.num_render_streams < 0)
       fail(DR_ERR_ARG, "DrFusion: invalid options");
     DR_HIP(hipSetDevice(device_));
-    int lo, hi;
-    DR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    DR_HIP(hipStreamCreateWithPriority(&int_stream_, hipStreamNonBlocking, lo));  // tsdf_volume.cu:64-70
+    // Stream priority of the integrate and render streams.  The reference creates them at the LEAST priority with a note that
+    // higher may be better (tsdf_volume.cu:64-70).  DR_FUSION_PRIORITY=low|normal|high selects it here; see DESIGN.md
+    // "TandemBackend loop" for the measurement behind the default.
+    int least, greatest;
+    DR_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    int lo = kDefaultFusionPriority == 2 ? greatest : (kDefaultFusionPriority == 1 ? 0 : least);
+    if (const char *e = getenv("DR_FUSION_PRIORITY")) lo = !strcmp(e, "high") ? greatest : (!strcmp(e, "normal") ? 0 : (!strcmp(e, "low") ? least : lo));
+    DR_HIP(hipStreamCreateWithPriority(&int_stream_, hipStreamNonBlocking, lo));
     npix_ = (size_t)o.height * o.width;
     size_t cap = 1024;
     const size_t want = std::max((size_t)o.num_buckets * (size_t)o.bucket_size, (size_t)2 * o.num_blocks);
