@@ -1074,7 +1074,7 @@ static void inverse4_host(const float *e, float *out) {
 }
 
 // ------------------------------------------------------------------ engine
-constexpr int kDefaultFusionPriority = 0;  // 0 least (the reference's), 1 normal, 2 greatest
+constexpr int kDefaultFusionPriority = 1;  // 0 least (the reference's), 1 normal (measured best in the TandemBackend loop), 2 greatest
 class FusionEngine {
  public:
   FusionEngine(const drf_options_t &o, int device) : device_(device), o_(o) {

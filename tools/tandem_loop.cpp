@@ -8,6 +8,8 @@
 // stored keyframe window (a TDMS sample, tools/export_fixture.py) whose poses are moved rigidly from keyframe to keyframe
 // (the network result is invariant, the map keeps growing).  Prints ONE JSON line: keyframes/s and the mean time of each call.
 //   usage: tandem_loop <weights.tdmw> <window.tdms> <keyframes> [voxel_size=0.01] [mesh_freq=0] [dense_tracking=1]
+// TANDEM_LOOP_SERIAL=1 (measurement aid, not TANDEM's order) waits for the depth network of keyframe k before fusing k-1:
+// the un-overlapped sum on the same map, to separate GPU contention from host gaps.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -52,6 +54,7 @@ int main(int argc, char **argv) {
   for (int v = 0; v < V; v++) { cur_ptr[v] = c2w_cur.data() + 16 * v; prev_ptr[v] = c2w_prev.data() + 16 * v; }
   float lower[3] = {-5, -5, -5}, upper[3] = {5, 5, 5};   // tandem_backend.cpp:80-81
 
+  const bool serial = getenv("TANDEM_LOOP_SERIAL") != nullptr;
   double t_get = 0, t_call = 0, t_int = 0, t_render = 0, t_getrender = 0, t_mesh = 0;
   int meshes = 0;
   size_t rendered = 0;
@@ -79,6 +82,7 @@ int main(int argc, char **argv) {
     // --- worker: CallSequential 3.5 (:147-160)
     t = Clock::now();
     mvsnet.CallAsync(H, W, V, ref, bgrs.data(), K, cur_ptr.data(), sc[0], sc[1], sc[2], false);
+    if (serial) mvsnet.Wait();
     t_call += ms_since(t);
     if (out_prev) {
       t = Clock::now();
@@ -118,10 +122,10 @@ int main(int argc, char **argv) {
   for (size_t i = 0; i < npx; i++) valid += last->depth[i] > 0;
   delete last; delete prev;
   printf("{\"keyframes\": %d, \"keyframes_per_s\": %.3f, \"ms_per_keyframe\": %.4f, \"height\": %d, \"width\": %d, \"views\": %d, "
-         "\"voxel_size\": %g, \"dense_tracking\": %d, \"mesh_every\": %d, \"meshes\": %d, "
+         "\"voxel_size\": %g, \"serial\": %d, \"dense_tracking\": %d, \"mesh_every\": %d, \"meshes\": %d, "
          "\"mean_ms\": {\"GetResult_wait\": %.4f, \"CallAsync\": %.4f, \"IntegrateScanAsync\": %.4f, \"RenderAsync\": %.4f, "
          "\"GetRenderResult\": %.4f, \"mesh\": %.4f}, \"valid_depth_fraction\": %.4f, \"rendered_sample\": %zu}\n",
-         n_kf, 1e3 * n_kf / total, total / n_kf, H, W, V, voxel, (int) dense_tracking, mesh_freq, meshes, t_get / n_kf, t_call / n_kf,
+         n_kf, 1e3 * n_kf / total, total / n_kf, H, W, V, voxel, (int) serial, (int) dense_tracking, mesh_freq, meshes, t_get / n_kf, t_call / n_kf,
          t_int / n_kf, t_render / n_kf, t_getrender / n_kf, meshes ? t_mesh / meshes : 0.0, (double) valid / npx, rendered);
   return 0;
 }
