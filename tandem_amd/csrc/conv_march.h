@@ -33,12 +33,23 @@ struct MarchArgs {
   int wsec;            // float4 per weight section (NUP * CT * 64)
   int NU;              // K chunks per channel pass in the packed weight array (KZ * NUP)
   int steps;           // ncols * Dc
-  int ncw;             // consumer waves (8 or 12)
+  int ncw;             // consumer waves (8, 10 or 12)
+  // Addressing (elements): position (image zc, marching index z, in-plane row y, x) of the input lies at
+  //   zc * i_sv + z * i_sz + y * i_sy + x * inC, the output likewise with o_*.
+  //   3-D layer  (KZ = 3, rm = 0): zc = 0, z = depth plane, y = row          i_sz = H*W*C, i_sy = W*C
+  //   2-D tiles  (KZ = 1, rm = 0): zc = image, z = 0, y = row                i_sv = H*W*C, i_sy = W*C
+  //   ROW MARCH  (KZ = 3, rm = 1): zc = image, z = ROW, no in-plane y        i_sv = H*W*C, i_sz = W*C, i_sy = 0
+  // The row march is the same ring protocol applied to a 2-D layer: a "plane" is one row strip of one image, a step produces one
+  // output row strip from the three row strips around it (sections = ky), so no row of the y halo is ever fetched twice.
+  int i_sv, i_sz, i_sy, o_sv, o_sz, o_sy;
+  int depth;           // loads a producer wave keeps in flight (1: publish every load before issuing the next)
+  int inHp;            // rows a plane has inside the tensor (inH, or 1 for the row march)
+  int rm;              // row march
   int *err;            // raised when a wait gave up (nullptr: not reported)
 };
 
 constexpr int kMarchProducers = 2;       // DMA producer waves (the fused-skip producers are four: kMarchFzProducers)
-constexpr int kMarchMaxConsumers = 12;   // consumer waves: 8 (two per SIMD) or 12 (three per SIMD, smaller position tiles per wave)
+constexpr int kMarchMaxConsumers = 12;   // consumer waves: 8 (two per SIMD), 10 (640-wide 2-D rows are 20 or 10 position tiles) or 12 (three per SIMD)
 constexpr int kMarchMaxIt = 24;          // DMA pieces per producer wave per plane (planes up to 48 KB)
 constexpr int kMarchSpinLimit = 1 << 18; // polls before a wait gives up (tens of milliseconds)
 // flag words (ints) behind the weights: [0..7] ready (one per producer wave), [8..19] released (one per consumer wave), [28] abort
@@ -68,16 +79,16 @@ DR_HD inline void march_piece_entry(const ConvArgs &a, const MarchArgs &m, int p
   conv_a_slot<CI>((it * kMarchProducers + pw) * 64 + lane, pos, c4);
   const unsigned y = (unsigned)pos / (unsigned)a.TXI, x = (unsigned)pos - y * a.TXI;
   const bool ok = it < m.nit && pos < m.NP;
-  rel = ok ? (int)((y * a.inW + x) * a.inC + c4 * 4) : 0;
+  rel = ok ? (int)(y * m.i_sy + x * a.inC + c4 * 4) : 0;
   yx = ok ? ((y << 16) | x) : 0x7fff7fffu;  // a position no tile origin can bring inside the tensor
 }
-DR_HD inline bool march_piece_inside(const ConvArgs &a, unsigned yx, int iy0, int ix0) {
+DR_HD inline bool march_piece_inside(const ConvArgs &a, const MarchArgs &m, unsigned yx, int iy0, int ix0) {
   const unsigned gy = (unsigned)(iy0 + (int)(yx >> 16)), gx = (unsigned)(ix0 + (int)(yx & 0xffffu));
-  return gy < (unsigned)a.inH && gx < (unsigned)a.inW;
+  return gy < (unsigned)m.inHp && gx < (unsigned)a.inW;
 }
-// element offset of the tile origin of input plane gz, channel slice `pass` (may be negative: the halo starts outside the tensor)
-DR_HD inline long long march_plane_offset(const ConvArgs &a, int gz, int iy0, int ix0, int pass, int CI) {
-  return (((long long)gz * a.inH + iy0) * a.inW + ix0) * a.inC + (long long)pass * CI;
+// element offset of the tile origin of input plane `plane` of image zc, channel slice `pass` (may be negative: the halo starts outside the tensor)
+DR_HD inline long long march_plane_offset(const ConvArgs &a, const MarchArgs &m, int zc, int plane, int iy0, int ix0, int pass, int CI) {
+  return (long long)zc * m.i_sv + (long long)plane * m.i_sz + (long long)iy0 * m.i_sy + (long long)ix0 * a.inC + (long long)pass * CI;
 }
 // weight piece e = (sec * NUP + u) * CT + ct of outer pass po -> float4 index (lane 0) in the packed weight array
 DR_HD inline size_t march_weight_src(const ConvArgs &a, const MarchArgs &m, int po, int e, int NUP, int CT, int ct0) {
@@ -85,8 +96,8 @@ DR_HD inline size_t march_weight_src(const ConvArgs &a, const MarchArgs &m, int 
   const int dz = sec / m.geo.NPI, pi = sec - dz * m.geo.NPI;
   return ((size_t)((po * m.geo.NPI + pi) * m.NU + dz * NUP + u) * a.ctTot + ct0 + ct) * 64;
 }
-DR_HD inline size_t march_out_index(const ConvArgs &a, int qz, int qy, int qx, int c0) {
-  return (((size_t)qz * a.outH + qy) * a.outW + qx) * a.outC + c0;
+DR_HD inline size_t march_out_index(const ConvArgs &a, const MarchArgs &m, int zc, int z, int qy, int qx, int c0) {
+  return (size_t)zc * m.o_sv + (size_t)z * m.o_sz + (size_t)qy * m.o_sy + (size_t)qx * a.outC + c0;
 }
 
 // Consumer side: wait until load `idx` has landed.  `cached` remembers the last value seen (the producers normally run
@@ -118,6 +129,26 @@ __device__ inline bool march_wait_released(march_flag_t *flags, int ncw, int nee
   }
   if (lane == 0) { flags[kMarchAbort] = 1; if (err) *err = 2; }
   return false;
+}
+
+// One poll of the same quantity (no waiting).
+__device__ inline int march_released_now(march_flag_t *flags, int ncw) {
+  int v = flags[kMarchReleased];
+#pragma unroll
+  for (int w = 1; w < kMarchMaxConsumers; ++w) { const int t = flags[kMarchReleased + (w < ncw ? w : 0)]; v = t < v ? t : v; }
+  return march_uniform(v);
+}
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate; the counter has six bits).
+__device__ inline void march_wait_vmcnt(int n) {
+  switch (n) {
+#define DR_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    DR_VM(1) DR_VM(2) DR_VM(3) DR_VM(4) DR_VM(5) DR_VM(6) DR_VM(7) DR_VM(8) DR_VM(9) DR_VM(10) DR_VM(11) DR_VM(12) DR_VM(13) DR_VM(14) DR_VM(15) DR_VM(16)
+    DR_VM(17) DR_VM(18) DR_VM(19) DR_VM(20) DR_VM(21) DR_VM(22) DR_VM(23) DR_VM(24) DR_VM(25) DR_VM(26) DR_VM(27) DR_VM(28) DR_VM(29) DR_VM(30) DR_VM(31)
+    DR_VM(32) DR_VM(33) DR_VM(34) DR_VM(35) DR_VM(36) DR_VM(37) DR_VM(38) DR_VM(39) DR_VM(40) DR_VM(41) DR_VM(42) DR_VM(43) DR_VM(44) DR_VM(45) DR_VM(46)
+    DR_VM(47) DR_VM(48) DR_VM(49) DR_VM(50) DR_VM(51) DR_VM(52) DR_VM(53) DR_VM(54) DR_VM(55) DR_VM(56) DR_VM(57) DR_VM(58) DR_VM(59) DR_VM(60)
+#undef DR_VM
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
 }
 
 // ---- K loop of one section: NUP chunks, fully unrolled, every LDS address known before the loop ----
@@ -165,8 +196,8 @@ __device__ inline void march_kloop(const float4 *tile, const float4 *wp, const i
 
 // ---- epilogue of one step; raw: 0 = final, 1 = store raw partial sums, 2 = add the stored partial sums, then final ----
 template <int CT, int PT>
-__device__ inline void march_epilogue(const ConvArgs &a, floatx4 (&acc)[CT][PT], const float4 (&scv)[CT], const float4 (&biv)[CT], int raw,
-                                      int wave, int j, int g, int ct0, int qz, int py0, int px0) {
+__device__ inline void march_epilogue(const ConvArgs &a, const MarchArgs &m, floatx4 (&acc)[CT][PT], const float4 (&scv)[CT], const float4 (&biv)[CT], int raw,
+                                      int wave, int j, int g, int ct0, int zc, int z, int py0, int px0) {
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
     const int tau = wave * PT + pt;
@@ -177,7 +208,7 @@ __device__ inline void march_epilogue(const ConvArgs &a, floatx4 (&acc)[CT][PT],
     for (int ct = 0; ct < CT; ++ct) {
       const int c0 = (ct0 + ct) * 16 + 4 * g;
       if (c0 >= a.rows_valid) continue;
-      const size_t obase = march_out_index(a, qz, qy, qx, c0);
+      const size_t obase = march_out_index(a, m, zc, z, qy, qx, c0);
       float4 v = make_float4(acc[ct][pt][0], acc[ct][pt][1], acc[ct][pt][2], acc[ct][pt][3]);
       if (raw == 2) {
         const float4 r = *reinterpret_cast<const float4 *>(a.out + obase);
@@ -189,7 +220,7 @@ __device__ inline void march_epilogue(const ConvArgs &a, floatx4 (&acc)[CT][PT],
         if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         if (a.add_mode) {
           size_t abase = obase;
-          if (a.add_mode == 2) abase = (((size_t)qz * a.addH + (qy >> 1)) * a.addW + (qx >> 1)) * a.outC + c0;
+          if (a.add_mode == 2) abase = (((size_t)(zc + z) * a.addH + (qy >> 1)) * a.addW + (qx >> 1)) * a.outC + c0;  // (never the row march: one of zc, z is 0)
           const float4 r = *reinterpret_cast<const float4 *>(a.add + abase);
           v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
         }
@@ -256,11 +287,10 @@ __device__ inline void march_consumer(const ConvArgs &a, const MarchArgs &m, flo
             }
           }
         }
-        const int qz = KZ == 3 ? z : zc;
 #if defined(DR_MABL_NO_EPI) || defined(DR_MABL_FREE)
         if (m.NPO > 7)  // never true: keeps the accumulators live
 #endif
-        march_epilogue<CT, PT>(a, acc, scv, biv, raw, wave, j, g, ct0, qz, py0, px0);
+        march_epilogue<CT, PT>(a, m, acc, scv, biv, raw, wave, j, g, ct0, zc, z, py0, px0);
         cur.next_step(m.geo, R);
       }
       L += sg.nl;
@@ -270,6 +300,11 @@ __device__ inline void march_consumer(const ConvArgs &a, const MarchArgs &m, flo
 }
 
 // Producer wave pw of kMarchProducers: takes DMA pieces pw, pw + 2, ... of every plane and of the weights.
+// Up to m.depth loads of the wave are in flight: after issuing the pieces of load i it waits only until the pieces of load
+// i - depth + 1 have landed (s_waitcnt vmcnt(in flight behind it); a wave's loads return in order) and publishes THAT one.  Small planes
+// (the row march: 10-20 KB per load, a step of 1-2 us) would otherwise be fetched one memory latency after the other.
+// When the ring has no free slot the wave first drains and publishes everything it has in flight -- the consumers may need
+// exactly those loads to release the slot it is waiting for.
 template <int CI>
 __device__ inline void march_producer(const ConvArgs &a, const MarchArgs &m, float4 *lds4, march_flag_t *flags, float4 *wl, int pw, int lane, int s0,
                                       int s1, int NUP, int CT) {
@@ -280,27 +315,35 @@ __device__ inline void march_producer(const ConvArgs &a, const MarchArgs &m, flo
   unsigned yx[kMarchMaxIt];
 #pragma unroll
   for (int it = 0; it < kMarchMaxIt; ++it) march_piece_entry<CI>(a, m, pw, it, lane, rel[it], yx[it]);
+  const int depth = m.depth;
   int L = 0;
   for (int po = 0; po < m.NPO; ++po) {
     if (po > 0 && !march_wait_released(flags, m.ncw, L, m.err, lane)) return;  // nobody reads the previous pass's weights any more
     // packed weights of this outer pass: section (dz, pi) = chunks dz*NUP .. of channel pass po*NPI + pi
     for (int e = pw; e < NS * NUP * CT; e += kMarchProducers)  // piece e = (sec * NUP + u) * CT + ct
       conv_a_dma16(a.wpk + march_weight_src(a, m, po, e, NUP, CT, ct0) + lane, march_uniform(conv_a_lds_addr(wl + (size_t)e * 64)));
+    int flight = 0;  // loads issued and not yet published (they are idx - flight .. idx - 1)
     for (int s = s0; s < s1;) {
       const MarchSeg sg = march_segment(m.geo, s, s1);
       int zc, py0, px0;
       march_tile_origin(a, m, sg.col, zc, py0, px0);
-      const int iy0 = py0 * a.sy - a.py, ix0 = px0 * a.sx - a.px;
+      const int iy0 = m.rm ? 0 : py0 * a.sy - a.py, ix0 = px0 * a.sx - a.px;  // (row march: the plane IS the row, no y padding inside it)
       for (int l = 0; l < sg.nl; ++l) {
         const int idx = L + l;
         int plane, pi;
         march_load_plane(m.geo, sg, l, plane, pi);
-        const int gz = m.geo.KZ == 3 ? plane : zc;
 #ifndef DR_MABL_FREE
-        if (idx >= m.R && !march_wait_released(flags, m.ncw, idx - m.R + 1, m.err, lane)) return;
+        if (idx >= m.R && march_released_now(flags, m.ncw) < idx - m.R + 1) {
+          if (flight) {
+            conv_a_wait_dma();
+            if (lane == 0) flags[pw] = idx;
+            flight = 0;
+          }
+          if (!march_wait_released(flags, m.ncw, idx - m.R + 1, m.err, lane)) return;
+        }
 #endif
         asm volatile("" ::: "memory");
-        const float *pbase = a.in + march_plane_offset(a, gz, iy0, ix0, po * m.geo.NPI + pi, CI);
+        const float *pbase = a.in + march_plane_offset(a, m, zc, plane, iy0, ix0, po * m.geo.NPI + pi, CI);
         float4 *dst = lds4 + (size_t)(idx % m.R) * m.PS;
 #pragma unroll
         for (int it = 0; it < kMarchMaxIt; ++it) {
@@ -309,15 +352,23 @@ __device__ inline void march_producer(const ConvArgs &a, const MarchArgs &m, flo
 #else
           if (it < m.nit) {
 #endif
-            const float *src = march_piece_inside(a, yx[it], iy0, ix0) ? pbase + rel[it] : a.zero16;
+            const float *src = march_piece_inside(a, m, yx[it], iy0, ix0) ? pbase + rel[it] : a.zero16;
             conv_a_dma16(src, march_uniform(conv_a_lds_addr(dst + (it * kMarchProducers + pw) * 64)));
           }
         }
-        conv_a_wait_dma();  // this wave's pieces of load idx (and, first time round, of the weights) have landed
-        if (lane == 0) flags[pw] = idx + 1;
+        ++flight;
+        if (flight >= depth) {  // the oldest load in flight (and, first time round, the weights) has landed once at most (flight - 1) * nit pieces are outstanding
+          march_wait_vmcnt((flight - 1) * m.nit);
+          if (lane == 0) flags[pw] = idx - flight + 2;
+          --flight;
+        }
       }
       L += sg.nl;
       s += sg.zb - sg.za;
+    }
+    if (flight) {
+      conv_a_wait_dma();
+      if (lane == 0) flags[pw] = L;
     }
   }
 }
@@ -344,7 +395,7 @@ __device__ inline void march_producer_fz(const ConvArgs &a, const MarchArgs &m, 
     const MarchSeg sg = march_segment(m.geo, s, s1);
     int zc, py0, px0;
     march_tile_origin(a, m, sg.col, zc, py0, px0);
-    const int iy0 = py0 * a.sy - a.py, ix0 = px0 * a.sx - a.px;
+    const int iy0 = m.rm ? 0 : py0 * a.sy - a.py, ix0 = px0 * a.sx - a.px;
     for (int l = 0; l < sg.nl; ++l) {
       const int idx = L + l;
       int plane, pi;
@@ -367,7 +418,7 @@ __device__ inline void march_producer_fz(const ConvArgs &a, const MarchArgs &m, 
         for (int k = 0; k < kB; ++k) {
           const int pos = p0 + k * 64 + lane;
           const unsigned y = (unsigned)pos / (unsigned)a.TXI, x = (unsigned)pos - y * a.TXI;
-          const int gy = iy0 + (int)y, gx = ix0 + (int)x;
+          const int gy = m.rm ? plane : iy0 + (int)y, gx = ix0 + (int)x;  // image row: the marching index in the row march
           in[k] = pos < m.NP && gy >= 0 && gy < a.inH && gx >= 0 && gx < a.inW;
           up[k] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll

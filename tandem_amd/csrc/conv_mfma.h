@@ -589,6 +589,7 @@ struct ConvLaunch {
 struct DimTaps {               // per-axis decomposition of one parity class
   std::vector<int> t, off;     // kernel index, input offset (>= 0)
   int s = 1, p = 0, om = 1, oo = 0, npos = 0;
+  int par = -1;                // transposed stride-2 axis split into classes: the output parity this class produces (-1: not split)
 };
 
 // Per-axis tap lists.  Normal conv: in = pos*s - pad + t.  Transposed stride 1: out[o] = sum_t x[o+1-t] w[t].
@@ -600,7 +601,10 @@ inline int parity_kernel_index(int parity, int off) {  // -1: this (parity, offs
   if (parity == 0) return off == 0 ? 1 : -1;
   return off == 0 ? 2 : 0;
 }
-inline std::vector<DimTaps> axis_classes(int k, int s, bool transposed, int in_size) {
+// A strided transposed axis comes in two forms.  DENSE: both parities are output ROWS of one class (offsets {0,1}, zero weight
+// where parity 0 does not use offset 1) -- one class, but a quarter of the products per axis are multiplications by zero.
+// SPLIT: one class per parity (parity 0: offset 0 only; parity 1: offsets 0 and 1) -- no zero products, half the rows.
+inline std::vector<DimTaps> axis_classes(int k, int s, bool transposed, int in_size, bool split = false) {
   std::vector<DimTaps> r;
   if (!transposed) {
     DimTaps d;
@@ -614,10 +618,13 @@ inline std::vector<DimTaps> axis_classes(int k, int s, bool transposed, int in_s
     for (int t = 0; t < k; ++t) { d.t.push_back(t); d.off.push_back(2 - t); }
     d.p = 1; d.npos = in_size;
     r.push_back(d);
-  } else {
+  } else if (!split) {
     // dense parity form: input offsets {0,1}; which kernel index a (parity, offset) pair selects is resolved when the
     // weights are packed (parity_kernel_index), the two parities of this axis become separate output ROWS
     DimTaps d; d.t = {0, 1}; d.off = {0, 1}; d.om = 2; d.oo = 0; d.npos = in_size; r.push_back(d);
+  } else {
+    DimTaps e; e.t = {0}; e.off = {0}; e.om = 2; e.oo = 0; e.npos = in_size; e.par = 0; r.push_back(e);
+    DimTaps o; o.t = {0, 1}; o.off = {0, 1}; o.om = 2; o.oo = 1; o.npos = in_size; o.par = 1; r.push_back(o);
   }
   return r;
 }
@@ -662,16 +669,31 @@ inline bool conv_instance_exists(int ci, int ct) {
 inline bool conv_a_instance_exists(int ci, int ct, int pt) {
   return (pt == 2 || pt == 4) && ((ci == 4 && ct == 1) || ((ci == 8 || ci == 16) && (ct == 1 || ct == 2)));
 }
+// k_conv_m instances (CI, NUP, CT, PT, consumer waves).  3-D layers: NUP = 6 (8 channels, XPAIR), 12 (16 channels, XPAIR), 9 (16 channels);
+// row march of 2-D layers: NUP = 2 (8 channels, XPAIR), 4 (16 channels, XPAIR), 3 (16 channels).  CT = 2 with PT = 4 needs more than the
+// 168 registers three waves per SIMD leave; twelve consumer waves leave 128 each.
+#define DR_MARCH_INSTANCES(X)                                                                                         \
+  X(8, 6, 1, 2, 8) X(8, 6, 1, 4, 8) X(8, 6, 1, 1, 12) X(8, 6, 1, 2, 12)                                               \
+  X(16, 12, 1, 2, 8) X(16, 12, 1, 4, 8) X(16, 12, 1, 1, 12) X(16, 12, 1, 2, 12)                                       \
+  X(16, 9, 1, 2, 8) X(16, 9, 1, 4, 8) X(16, 9, 1, 1, 12) X(16, 9, 1, 2, 12) X(16, 9, 2, 2, 8)                         \
+  X(8, 2, 1, 1, 8) X(8, 2, 1, 2, 8) X(8, 2, 1, 4, 8) X(8, 2, 1, 1, 10) X(8, 2, 1, 2, 10)                              \
+  X(16, 4, 1, 1, 8) X(16, 4, 1, 2, 8) X(16, 4, 1, 4, 8) X(16, 4, 1, 1, 10) X(16, 4, 1, 2, 10)                         \
+  X(16, 3, 1, 1, 8) X(16, 3, 1, 2, 8) X(16, 3, 1, 4, 8) X(16, 3, 1, 1, 10) X(16, 3, 1, 2, 10)                         \
+  X(16, 3, 2, 1, 8) X(16, 3, 2, 2, 8) X(16, 3, 2, 1, 10) X(16, 3, 2, 2, 10)
 inline bool conv_m_instance_exists(int ci, int nup, int ct, int pt, int ncw) {
-  const bool family = (ci == 8 && nup == 6) || (ci == 16 && (nup == 12 || nup == 9));
-  if (ncw == 12) return family && ct == 1 && (pt == 1 || pt == 2);  // three consumer waves per SIMD: at most 128 registers each
-  if (ncw != 8 || (pt != 2 && pt != 4)) return false;
-  if (ct == 2) return ci == 16 && nup == 9 && pt == 2;  // (CT = 2, PT = 4 needs more than the 168 registers three waves per SIMD leave)
-  return ct == 1 && family;
+#define DR_X(CI_, NUP_, CT_, PT_, NCW_) if (ci == CI_ && nup == NUP_ && ct == CT_ && pt == PT_ && ncw == NCW_) return true;
+  DR_MARCH_INSTANCES(DR_X)
+#undef DR_X
+  return false;
 }
 // DR_CONV_MARCH: 0 = never plan k_conv_m, 1 = rank it with the other families (default), 2 = prefer it wherever it applies (A/B hook)
 inline int conv_march_policy() {
   if (const char *e = getenv("DR_CONV_MARCH")) return atoi(e);
+  return 1;
+}
+// DR_CONV_ROWMARCH: the same for the row march of 2-D layers (0 = never, 1 = ranked, 2 = preferred)
+inline int conv_rowmarch_policy() {
+  if (const char *e = getenv("DR_CONV_ROWMARCH")) return atoi(e);
   return 1;
 }
 struct MarchShape {  // derived geometry of a k_conv_m candidate
@@ -681,34 +703,45 @@ struct MarchShape {  // derived geometry of a k_conv_m candidate
   int grid;
   bool ok;
 };
-inline MarchShape march_shape(int KZ, int ntp, int Cin, int ci, int ct, int pt, int ty, int txt, int SX, int exy, int exx, int nPD, int nPH, int nPW, int CTtot) {
+// rm (row march of a 2-D layer): KZ is the layer's kd (1), ntp the x taps of ONE row, nPD the images, nPH the rows; ty must be 1.
+inline MarchShape march_shape(int KZ, int ntp, int Cin, int ci, int ct, int pt, int ty, int txt, int SX, int exy, int exx, int nPD, int nPH, int nPW, int CTtot,
+                              bool rm = false) {
   MarchShape m{};
   const int tpc = 16 / ci;
-  if (Cin % ci || ntp % tpc || CTtot % ct || (ty * txt) % pt) return m;
+  if (Cin % ci || ntp % tpc || CTtot % ct || (ty * txt) % pt || (rm && (ty != 1 || KZ != 1))) return m;
   m.ncw = ty * txt / pt;  // one wave per PT position tiles
   m.nup = ntp / tpc;
   if (!conv_m_instance_exists(ci, m.nup, ct, pt, m.ncw)) return m;
-  const int npass = Cin / ci;
+  const int npass = Cin / ci, kz = rm ? 3 : KZ;
   if (npass > 2) return m;
-  m.npi = KZ == 1 ? npass : 1; m.npo = KZ == 1 ? 1 : npass; m.ns = KZ * m.npi;
-  m.tyi = ty - 1 + exy; m.txi = (txt * 16 - 1) * SX + exx; m.np = m.tyi * m.txi;
+  m.npi = KZ == 1 ? npass : 1; m.npo = KZ == 1 ? 1 : npass; m.ns = kz * m.npi;
+  m.tyi = rm ? 1 : ty - 1 + exy; m.txi = (txt * 16 - 1) * SX + exx; m.np = m.tyi * m.txi;
   if (m.np >= 65536) return m;
   m.ps = cdiv(((m.np + 15) & ~15) * (ci / 4), 128) * 128;
   if (m.ps / 128 > kMarchMaxIt) return m;
   m.wbytes = (size_t)m.ns * m.nup * ct * 1024;
   const size_t fixed = m.wbytes + kMarchFlagInts * 4;
   if (fixed >= kConvMaxLds) return m;
-  const int rmin = KZ == 3 ? 3 : m.npi + 1, rmax = KZ == 3 ? 4 : 2 * m.npi + 2;
+  // ring: the planes a step reads, plus what the producers may fetch ahead (rows are small: two whole rows ahead when they fit)
+  const int rmin = kz == 3 ? 3 * m.npi : m.npi + 1, rmax = rm ? 5 * m.npi : (kz == 3 ? 4 : 2 * m.npi + 2);
   m.r = (int)std::min<size_t>(rmax, (kConvMaxLds - fixed) / ((size_t)m.ps * 16));
   if (m.r < rmin) return m;
   m.lds_bytes = (size_t)m.r * m.ps * 16 + fixed;
-  m.steps = (long long)cdiv(nPH, ty) * cdiv(nPW, txt * 16) * nPD;
+  m.steps = (long long)(rm ? 1 : cdiv(nPH, ty)) * cdiv(nPW, txt * 16) * nPD * (rm ? nPH : 1);
   const int split = CTtot / ct;
   m.grid = 8 * cdiv((int)std::min<long long>(m.steps, std::max(8, 256 / split)), 8);
   m.ok = true;
   return m;
 }
 inline size_t conv_a_slots(int np, int ci) { return (size_t)cdiv(((np + 1) & ~1) * (ci / 4), 512) * 512; }
+// Form of a stride-2 transposed layer (see axis_classes): 0 = every strided axis dense (8 * Cout rows, 27 of 64 products useful),
+// 1 = x dense, z and y split (2 * Cout rows in 4 classes, 3 of 4 useful), 2 = every axis split (Cout rows in 8 classes, all
+// useful).  Default by measurement at 640x480 (profiles/r03_experiments.txt): conv11 (Cout 8) 0.076 / 0.073 / 0.126 ms, conv9 (Cout 16)
+// 0.039 / 0.030 / 0.034, conv7 (Cout 32) 0.0265 / 0.0233 / 0.0221 for forms 0 / 1 / 2.  DR_DECONV_FORM overrides (A/B hook).
+inline int conv_deconv_form(int Cout) {
+  if (const char *e = getenv("DR_DECONV_FORM")) return std::max(0, std::min(2, atoi(e)));
+  return Cout >= 32 ? 2 : 1;
+}
 // which kernel family the planner may use: 0 = k_conv only, 1 = k_conv_a only (falls back to k_conv when no async plan
 // fits), 2 = both, ranked together.  DR_CONV_ASYNC overrides (A/B hook).
 inline int conv_async_policy() {
@@ -720,9 +753,10 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
                              float *out, const float *add, int add_mode, DeviceArena &arena, int rank = 0, const ConvFuse *fz = nullptr) {
   // rank: which candidate of the cost model's ranking to build (0 = its choice); used by the engine's autotuner
   if (L.Cin % 4 != 0 || inC < L.Cin) fail(DR_ERR_ARG, "plan_conv: Cin=%d must be a multiple of 4 (tensor C=%d)", L.Cin, inC);
-  auto cz = axis_classes(L.kd, L.sd, L.transposed, inD);
-  auto cy = axis_classes(L.kh, L.sh, L.transposed, inH);
-  auto cx = axis_classes(L.kw, L.sw, L.transposed, inW);
+  const int form = L.transposed ? conv_deconv_form(L.Cout) : 0;
+  auto cz = axis_classes(L.kd, L.sd, L.transposed, inD, form >= 1);
+  auto cy = axis_classes(L.kh, L.sh, L.transposed, inH, form >= 1);
+  auto cx = axis_classes(L.kw, L.sw, L.transposed, inW, form >= 2);
   ConvPlanOut R;
   R.outD = L.transposed ? inD * L.sd : cz[0].npos;
   R.outH = L.transposed ? inH * L.sh : cy[0].npos;
@@ -741,12 +775,13 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   // transposed: parity bits of the strided axes, enumerated (z, y, x) -> par_map holds 3 bits (z<<2|y<<1|x) per parity
   int npar = 1, par_map = 0;
   const bool strided[3] = {L.transposed && L.sd == 2, L.transposed && L.sh == 2, L.transposed && L.sw == 2};
+  const bool dense[3] = {strided[0] && form < 1, strided[1] && form < 1, strided[2] && form < 2};  // parity carried by the output rows
   if (L.transposed) {
     if (mode != CONV_NORMAL) fail(DR_ERR_ARG, "plan_conv: transposed layers use CONV_NORMAL");
-    for (int d = 0; d < 3; ++d) if (strided[d]) npar *= 2;
+    for (int d = 0; d < 3; ++d) if (dense[d]) npar *= 2;
     for (int q = 0; q < npar; ++q) {
       int bits = 0, rem = q;
-      for (int d = 2; d >= 0; --d) if (strided[d]) { bits |= (rem & 1) << (2 - d); rem >>= 1; }
+      for (int d = 2; d >= 0; --d) if (dense[d]) { bits |= (rem & 1) << (2 - d); rem >>= 1; }
       par_map |= bits << (3 * q);
     }
     rows_valid = npar * L.Cout; rows = cdiv(rows_valid, 16) * 16;
@@ -837,6 +872,32 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
             if (fz) cost *= 1.5;  // measured (r3): with a 3-slot ring and two channel passes per tile the fused-skip producers are the bottleneck (0.24 ms against k_conv's 0.214 at 480 x 640)
             if (march_policy >= 2) cost *= 1e-3;
             cands.push_back({cost, ci, pt, ct, 1, ty, txt, L.kd, ms.tyi, ms.txi, 2});
+          }
+        }
+    }
+  }
+  // the row march: 2-D 3x3 stride-1 layers on the same kernel, marching down the rows of each image (async = 3)
+  const bool rowmarch_ok = !fz && conv_rowmarch_policy() >= 1 && ncls == 1 && !L.transposed && mode != CONV_X8 && L.kd == 1 && L.kh == 3 && L.kw == 3 &&
+                           SZ == 1 && SY == 1 && L.sw == 1 && !add;
+  const int row_ntp = rowmarch_ok ? (int)cx[0].t.size() : 0;  // x taps of one row
+  if (rowmarch_ok) {
+    for (int ci : {16, 8}) {
+      if (ci == 8 && L.Cin != 8) continue;
+      for (int ncw : {8, 10})
+        for (int pt : {1, 2, 4}) {
+          const int txt = ncw * pt;
+          if (txt > 1 && (txt / 2) * 16 >= nPW) continue;
+          for (int ct : {2, 1}) {
+            const MarchShape ms = march_shape(L.kd, row_ntp, L.Cin, ci, ct, pt, 1, txt, SX, exy, exx, nPD, nPH, nPW, CTtot, true);
+            if (!ms.ok) continue;
+            const double spw = std::ceil((double)ms.steps / ms.grid);
+            const double waste = (double)cdiv(nPW, txt * 16) * txt * 16 / nPW;  // strips hanging over the end of the row
+            const double unit = ms.ns * ms.nup * 4.0 * ct * pt * 32.0 * (ncw / 4.0) + 300.0;  // MFMA cycles of a step per SIMD + the per-step bookkeeping
+            const double startup = (double)ms.lds_bytes / 16.0 + 3000.0;
+            double cost = spw * unit * 1.02 + startup;
+            (void)waste;
+            if (conv_rowmarch_policy() >= 2) cost *= 1e-3;
+            cands.push_back({cost, ci, pt, ct, 1, 1, txt, 1, 1, ms.txi, 3});
           }
         }
     }
@@ -944,8 +1005,9 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
             const int offs[3] = {tz[tap], ty[tap], tx[tap]};  // for transposed layers DimTaps::t carries the input offset
             int kk[3];
             bool ok = true;
+            const int cpar[3] = {Z.par, Y.par, X.par};
             for (int d = 0; d < 3; ++d) {
-              if (strided[d]) kk[d] = parity_kernel_index((bits >> (2 - d)) & 1, offs[d]);
+              if (strided[d]) kk[d] = parity_kernel_index(dense[d] ? (bits >> (2 - d)) & 1 : cpar[d], offs[d]);
               else kk[d] = offs[d];  // stride-1 axis: DimTaps::t is the kernel index already (k == 1 or the 3-tap flip)
               ok = ok && kk[d] >= 0;
             }
@@ -959,7 +1021,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
         }
         pk[w0 + ((((size_t)p * NU + u) * CTtot + ct) * 64 + l) * 4 + s] = v;
       }
-    if (L.transposed) flops += 2.0 * nPD * nPH * nPW * (double)L.kd * L.kh * L.kw * L.Cin * L.Cout;
+    if (L.transposed) flops += ic == 0 ? 2.0 * nPD * nPH * nPW * (double)L.kd * L.kh * L.kw * L.Cin * L.Cout : 0.0;
     else flops += 2.0 * nPD * nPH * nPW * (mode == CONV_NORMAL ? 1 : shifts) * (double)ntz * nty * (mode == CONV_NORMAL ? ntx : L.kw) * L.Cin * L.Cout;
   }
 
@@ -1013,29 +1075,41 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
     const int want = std::max(1, std::min(ntiles, 256 * wpc / split));
     cl.grid = dim3(8 * cdiv(want, 8), 1, split);
   }
-  if (ASYNC == 2) {
-    const MarchShape ms = march_shape(L.kd, march_ntp, L.Cin, CI, CT, PT, TY, TXT, SX, exy, exx, nPD, nPH, nPW, CTtot);
+  if (ASYNC >= 2) {
+    const bool rm = ASYNC == 3;
+    const MarchShape ms = rm ? march_shape(L.kd, row_ntp, L.Cin, CI, CT, PT, 1, TXT, SX, exy, exx, nPD, nPH, nPW, CTtot, true)
+                             : march_shape(L.kd, march_ntp, L.Cin, CI, CT, PT, TY, TXT, SX, exy, exx, nPD, nPH, nPW, CTtot);
     if (!ms.ok) fail(DR_ERR_ARG, "plan_conv: inconsistent k_conv_m plan");
     cl.async = 2; cl.nup = ms.nup; cl.ncw = ms.ncw;
     a.zero16 = arena.upload(std::vector<float>(4, 0.f));
     a.a_slots = 0; a.a_wbufs = 0;
     MarchArgs &m = cl.march;
+    const int kz = rm ? 3 : L.kd;
     std::vector<int> tap2d((size_t)ms.nup * TPC, 0);
     {
       const DimTaps &Y = *classes[0].y, &X = *classes[0].x;
       int n = 0;
-      for (size_t iy = 0; iy < Y.t.size(); ++iy) for (size_t ix = 0; ix < X.t.size(); ++ix, ++n) tap2d[n] = Y.off[iy] * TXI + X.off[ix];
+      if (rm) for (size_t ix = 0; ix < X.t.size(); ++ix, ++n) tap2d[n] = X.off[ix];  // the y taps are the sections of the step
+      else for (size_t iy = 0; iy < Y.t.size(); ++iy) for (size_t ix = 0; ix < X.t.size(); ++ix, ++n) tap2d[n] = Y.off[iy] * TXI + X.off[ix];
     }
     m.tap2d = arena.upload(tap2d);
-    m.geo.KZ = L.kd; m.geo.NPI = ms.npi; m.geo.Dc = L.kd == 3 ? nPD : 1;
+    m.geo.KZ = kz; m.geo.NPI = ms.npi; m.geo.Dc = rm ? nPH : (L.kd == 3 ? nPD : 1);
     m.NPO = ms.npo;
-    m.colsH = cdiv(nPH, TY); m.colsW = cdiv(nPW, TXT * 16);
+    m.colsH = rm ? 1 : cdiv(nPH, TY); m.colsW = cdiv(nPW, TXT * 16);
     m.ncols = (L.kd == 3 ? 1 : nPD) * m.colsH * m.colsW;
     m.R = ms.r; m.PS = ms.ps; m.NP = ms.np; m.nit = ms.ps / 128;
-    m.wsec = ms.nup * CT * 64; m.NU = L.kd * ms.nup;
+    m.wsec = ms.nup * CT * 64; m.NU = kz * ms.nup;
     m.steps = (int)ms.steps;
     m.ncw = ms.ncw;
+    m.rm = rm ? 1 : 0;
+    const long long iplane = (long long)a.inH * a.inW * a.inC, oplane = (long long)a.outH * a.outW * a.outC;
+    if (iplane * std::max(1, a.inD) >= (1ll << 31) || oplane * std::max(1, a.outD) >= (1ll << 31)) fail(DR_ERR_ARG, "plan_conv: tensor too large for k_conv_m's 32-bit strides");
+    m.i_sv = L.kd == 3 ? 0 : (int)iplane; m.i_sz = rm ? a.inW * a.inC : (L.kd == 3 ? (int)iplane : 0); m.i_sy = rm ? 0 : a.inW * a.inC;
+    m.o_sv = L.kd == 3 ? 0 : (int)oplane; m.o_sz = rm ? a.outW * a.outC : (L.kd == 3 ? (int)oplane : 0); m.o_sy = rm ? 0 : a.outW * a.outC;
+    m.inHp = rm ? 1 : a.inH;
     m.err = arena.err_flag;
+    m.depth = rm ? 3 : 2;  // loads each producer wave keeps in flight (rows are small and steps short: one more)
+    if (const char *e = getenv("DR_MARCH_PDEPTH")) m.depth = std::max(1, std::min(4, atoi(e)));  // A/B hook
     cl.lds_bytes = ms.lds_bytes;
     cl.grid = dim3(ms.grid, 1, CTtot / CT);
   }
@@ -1080,18 +1154,10 @@ inline void launch_conv(const ConvLaunch &c, hipStream_t st) {
     return;
   }
   if (c.async == 2) {
-#define DR_CONV_M_CASE(CI_, NUP_)                                                         \
-  if (c.ci == CI_ && c.nup == NUP_ && c.ct == 1) {                                        \
-    if (c.ncw == 12 && c.pt == 1) { launch_conv_m_inst<CI_, NUP_, 1, 1, 0, 12>(c, st); return; } \
-    if (c.ncw == 12 && c.pt == 2) { launch_conv_m_inst<CI_, NUP_, 1, 2, 0, 12>(c, st); return; } \
-    if (c.ncw == 8 && c.pt == 2) { launch_conv_m_inst<CI_, NUP_, 1, 2>(c, st); return; }  \
-    if (c.ncw == 8 && c.pt == 4) { launch_conv_m_inst<CI_, NUP_, 1, 4>(c, st); return; }  \
-  }
-    DR_CONV_M_CASE(8, 6)
-    DR_CONV_M_CASE(16, 12)
-    DR_CONV_M_CASE(16, 9)
-#undef DR_CONV_M_CASE
-    if (c.ci == 16 && c.nup == 9 && c.ct == 2 && c.pt == 2 && c.ncw == 8) { launch_conv_m_inst<16, 9, 2, 2>(c, st); return; }
+#define DR_X(CI_, NUP_, CT_, PT_, NCW_) \
+  if (c.ci == CI_ && c.nup == NUP_ && c.ct == CT_ && c.pt == PT_ && c.ncw == NCW_) { launch_conv_m_inst<CI_, NUP_, CT_, PT_, 0, NCW_>(c, st); return; }
+    DR_MARCH_INSTANCES(DR_X)
+#undef DR_X
     fail(DR_ERR_ARG, "launch_conv: no marching instance CI=%d NUP=%d CT=%d PT=%d waves=%d", c.ci, c.nup, c.ct, c.pt, c.ncw);
   }
   if (c.async) {

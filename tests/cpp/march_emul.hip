@@ -46,7 +46,7 @@ static bool emulate(const ConvLaunch &c, const float *in, float *out, const floa
             wl[(size_t)e * 64 + lane] = F4{{w.x, w.y, w.z, w.w}};
           }
         // the producer's load list of this pass, in issue order
-        struct Load { int gz, pass, iy0, ix0; };
+        struct Load { int zc, plane, pass, iy0, ix0; };
         std::vector<Load> loads;
         for (int s = s0; s < s1;) {
           const MarchSeg sg = march_segment(m.geo, s, s1);
@@ -55,7 +55,7 @@ static bool emulate(const ConvLaunch &c, const float *in, float *out, const floa
           for (int l = 0; l < sg.nl; ++l) {
             int plane, pi;
             march_load_plane(m.geo, sg, l, plane, pi);
-            loads.push_back({m.geo.KZ == 3 ? plane : zc, po * m.geo.NPI + pi, py0 * a.sy - a.py, px0 * a.sx - a.px});
+            loads.push_back({zc, plane, po * m.geo.NPI + pi, m.rm ? 0 : py0 * a.sy - a.py, px0 * a.sx - a.px});
           }
           s += sg.zb - sg.za;
         }
@@ -63,14 +63,14 @@ static bool emulate(const ConvLaunch &c, const float *in, float *out, const floa
         auto do_load = [&](int i) -> bool {
           if (i >= m.R && released < i - m.R + 1) { printf("emul: load %d would overwrite a slot still in use (released %d, R %d)\n", i, released, m.R); return false; }
           const Load &ld = loads[i - Lpass];
-          const long long pofs = march_plane_offset(a, ld.gz, ld.iy0, ld.ix0, ld.pass, CI);
+          const long long pofs = march_plane_offset(a, m, ld.zc, ld.plane, ld.iy0, ld.ix0, ld.pass, CI);
           for (int pw = 0; pw < kMarchProducers; ++pw)
             for (int it = 0; it < m.nit; ++it)
               for (int lane = 0; lane < 64; ++lane) {
                 int rel; unsigned yx;
                 march_piece_entry<CI>(a, m, pw, it, lane, rel, yx);
                 F4 v{{0.f, 0.f, 0.f, 0.f}};
-                if (march_piece_inside(a, yx, ld.iy0, ld.ix0)) for (int k = 0; k < 4; ++k) v.v[k] = in[pofs + rel + k];
+                if (march_piece_inside(a, m, yx, ld.iy0, ld.ix0)) for (int k = 0; k < 4; ++k) v.v[k] = in[pofs + rel + k];
                 const size_t dst = (size_t)(i % m.R) * m.PS + (size_t)(it * kMarchProducers + pw) * 64 + lane;
                 if (dst >= ring.size() || (it * kMarchProducers + pw) * 64 + lane >= m.PS) { printf("emul: DMA piece outside its ring slot\n"); return false; }
                 ring[dst] = v;
@@ -119,7 +119,6 @@ static bool emulate(const ConvLaunch &c, const float *in, float *out, const floa
                 released = idx + 1;
               }
             }
-            const int qz = m.geo.KZ == 3 ? z : zc;
             for (int wave = 0; wave < m.ncw; ++wave)
               for (int pt = 0; pt < PT; ++pt)
                 for (int lane = 0; lane < 64; ++lane) {
@@ -130,7 +129,7 @@ static bool emulate(const ConvLaunch &c, const float *in, float *out, const floa
                   for (int ct = 0; ct < CT; ++ct) {
                     const int c0 = (ct0 + ct) * 16 + 4 * g;
                     if (c0 >= a.rows_valid) continue;
-                    const size_t ob = march_out_index(a, qz, qy, qx, c0);
+                    const size_t ob = march_out_index(a, m, zc, z, qy, qx, c0);
                     for (int r = 0; r < 4; ++r) {
                       float v = acc[((((size_t)wave * CT + ct) * PT + pt) * 64 + lane) * 4 + r];
                       if (raw == 2) v += out[ob + r];
@@ -199,7 +198,7 @@ static int run_case(const Case &cs, int max_plans) {
     double worst = 0;
     for (size_t i = 0; i < on; ++i) worst = std::max(worst, (double)std::fabs(out[i] - ref[i]) / (1.0 + std::fabs(ref[i])));
     const bool pass = ok && worst < 2e-5;
-    printf("%-22s plan w=%d ci=%d nup=%d ct=%d pt=%d tile %dx%d R=%d PS=%d NPI=%d NPO=%d grid %ux%u steps %d: %s (max rel err %.2e)\n", cs.name, c.ncw, c.ci, c.nup, c.ct, c.pt,
+    printf("%-22s plan %s w=%d ci=%d nup=%d ct=%d pt=%d tile %dx%d R=%d PS=%d NPI=%d NPO=%d grid %ux%u steps %d: %s (max rel err %.2e)\n", cs.name, c.march.rm ? "rows" : "tile", c.ncw, c.ci, c.nup, c.ct, c.pt,
            c.args.TY, c.args.TXT * 16, c.march.R, c.march.PS, c.march.geo.NPI, c.march.NPO, c.grid.x, c.grid.z, c.march.steps, pass ? "ok" : "FAIL", worst);
     ++done;
     if (!pass) ++fails;
@@ -210,6 +209,7 @@ static int run_case(const Case &cs, int max_plans) {
 
 int main(int argc, char **argv) {
   setenv("DR_CONV_MARCH", "2", 1);  // marching candidates first in the planner's ranking
+  setenv("DR_CONV_ROWMARCH", "2", 1);
   const int max_plans = argc > 1 ? atoi(argv[1]) : 3;
   const Case cases[] = {
       {"xpair3d_c16", 5, 20, 40, 16, 8, 3, true, false},   // s2.conv0's type
@@ -220,6 +220,12 @@ int main(int argc, char **argv) {
       {"conv2d_16_16", 3, 19, 33, 16, 16, 1, true, true},  // fn.conv1.x (+ a residual add to cover add_mode 1)
       {"conv2d_32_32", 2, 17, 20, 32, 32, 1, true, false}, // fn.conv2.x: inner channel passes, two row tiles
       {"conv2d_32_16", 2, 16, 32, 32, 16, 1, false, false},// fn.out2: no ReLU
+      // wide enough for the row march (a strip is at least 8 position tiles)
+      {"rows_xpair_c8", 2, 9, 300, 8, 8, 1, true, false},  // fn.conv0.1
+      {"rows_16_16", 2, 7, 170, 16, 16, 1, true, false},   // fn.conv1.x
+      {"rows_32_32", 2, 6, 168, 32, 32, 1, true, false},   // fn.conv2.x: two channel slices per row, two row tiles
+      {"rows_32_16", 3, 5, 330, 32, 16, 1, false, false},  // fn.out2
+      {"rows_xpair_c32", 1, 11, 520, 32, 8, 1, true, false}, // fn.out3's shape without the fused skip
   };
   int fails = 0;
   for (const Case &cs : cases) fails += run_case(cs, max_plans);

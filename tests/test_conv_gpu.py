@@ -141,3 +141,46 @@ def test_marching_kernel_candidates(case, monkeypatch):
     for rank in range(8):  # the marching candidates (tile shapes, PT, CT) lead the ranking; later ranks repeat other families
         monkeypatch.setenv("DR_CONV_RANK", str(rank))
         run_case(case)
+
+
+# ---- the row march: 2-D 3x3 layers on k_conv_m, marching down the rows of each image (DR_CONV_ROWMARCH=2 ranks its candidates
+# first).  Widths as in the pipeline (640 / 320 / 160 columns = 20 / 20 / 10 position tiles, 512-wide = 16) and ragged ones.
+ROWMARCH = [
+    ("rows xpair 3x3 8->8, 7 views", (7, 40, 640), 8, 8, (1, 3, 3), (1, 1, 1), False, True, "none"),
+    ("rows 3x3 16->16, 3 views", (3, 50, 320), 16, 16, (1, 3, 3), (1, 1, 1), False, True, "none"),
+    ("rows 3x3 32->32, 7 views", (7, 30, 160), 32, 32, (1, 3, 3), (1, 1, 1), False, True, "none"),
+    ("rows 3x3 32->16", (2, 37, 320), 32, 16, (1, 3, 3), (1, 1, 1), False, False, "none"),
+    ("rows xpair 3x3 32->8", (2, 33, 640), 32, 8, (1, 3, 3), (1, 1, 1), False, False, "none"),
+    ("rows ragged 3x3 16->16", (3, 21, 300), 16, 16, (1, 3, 3), (1, 1, 1), False, True, "none"),
+    ("rows 3x3 16->16, 256 wide", (2, 20, 256), 16, 16, (1, 3, 3), (1, 1, 1), False, True, "none"),
+    ("rows one-row image 3x3 16->16", (4, 1, 320), 16, 16, (1, 3, 3), (1, 1, 1), False, True, "none"),
+]
+
+
+@pytest.mark.parametrize("case", ROWMARCH, ids=[c[0] for c in ROWMARCH])
+def test_row_march_candidates(case, monkeypatch, capfd):
+    monkeypatch.setenv("DR_CONV_ROWMARCH", "2")
+    monkeypatch.setenv("DR_CONV_PRINT", "1")
+    kinds = []
+    for rank in range(10):
+        monkeypatch.setenv("DR_CONV_RANK", str(rank))
+        run_case(case)
+        kinds += [l.split()[1].split("<")[0] for l in capfd.readouterr().err.splitlines() if l.startswith("debug_conv:")]
+    assert kinds and kinds[0] == "rowmarch" and kinds.count("rowmarch") >= 2, kinds
+
+
+# ---- transposed stride-2 layers: the three parity forms (conv_mfma.h axis_classes: dense rows / x dense + (z, y) classes / one class per
+# parity) compute the same layer; every plan candidate of each form.
+DECONV = [c for c in CASES if c[6]] + [
+    ("deconv 16->8 +skip, wide", (5, 20, 48), 16, 8, (3, 3, 3), (2, 2, 2), True, True, "same"),
+    ("deconv 32->16 no skip", (3, 9, 20), 32, 16, (3, 3, 3), (2, 2, 2), True, False, "none"),
+]
+
+
+@pytest.mark.parametrize("form", [0, 1, 2])
+@pytest.mark.parametrize("case", DECONV, ids=[c[0] for c in DECONV])
+def test_transposed_parity_forms(case, form, monkeypatch):
+    monkeypatch.setenv("DR_DECONV_FORM", str(form))
+    for rank in range(0, 60, 3):
+        monkeypatch.setenv("DR_CONV_RANK", str(rank))
+        run_case(case)

@@ -1,5 +1,5 @@
 """CPU: the marching convolution kernel's planner, index arithmetic and ring protocol (tandem_amd/csrc/conv_march.h,
-march_plan.h) executed on the host by tests/cpp/march_emul.hip -- every k_conv_m plan candidate of eight layer types
+march_plan.h) executed on the host by tests/cpp/march_emul.hip -- every k_conv_m plan candidate (3-D march, 2-D tiles, row march) of thirteen layer shapes
 (CostRegNet conv0 / conv2 module.py:546-552, FeatureNet's 3x3 layers module.py:461-494) against a direct convolution.
 No device code runs here; the GPU side is tests/test_conv_gpu.py."""
 import os
@@ -23,5 +23,5 @@ def test_march_emulation_matches_direct_convolution(tmp_path):
     assert len(lines) >= 30 and all(" ok " in l for l in lines), out.stdout[-4000:]
     # every instance family and both pass structures were exercised
     text = out.stdout
-    for needle in ("ci=8 nup=6", "ci=16 nup=12", "ci=16 nup=9", "ct=2", "pt=4", "pt=1", "w=12", "NPI=2", "NPO=2"):
+    for needle in ("ci=8 nup=6", "ci=16 nup=12", "ci=16 nup=9", "ct=2", "pt=4", "pt=1", "w=12", "NPI=2", "NPO=2", "rows w=10", "rows w=8", "nup=2", "nup=3", "nup=4"):
         assert needle in text, needle
