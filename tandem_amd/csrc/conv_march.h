@@ -194,6 +194,33 @@ __device__ inline void march_kloop(const float4 *tile, const float4 *wp, const i
   if constexpr (CT * PT == 1) acc[0][0] += acc2[0][0];
 }
 
+// The same loop over ALL THREE sections of a step (KZ = 3, one channel slice per plane, no z padding in this step): the operand
+// prefetch runs across the section boundaries, so the pipeline fills once per step instead of once per section (a section of
+// 9-12 chunks otherwise starts with a bare LDS round trip: ~15 % of its MFMA time).  tile[s] / wp + s * wsec are the ring slot and
+// the weight section of section s; `release(s)` is called after the last MFMA that reads section s.
+template <int NUP, int CT, int PT, int DEPTH, class Release>
+__device__ inline void march_kloop3(const float4 *const (&tile)[3], const float4 *wp, int wsec, const int (&sw)[NUP][PT], floatx4 (&acc)[CT][PT], Release release) {
+  constexpr int NS = DEPTH + 1, NT = 3 * NUP;
+  float4 av[NS][CT], bv[NS][PT];
+  floatx4 acc2[CT][PT];
+  if constexpr (CT * PT == 1) acc2[0][0] = floatx4{0.f, 0.f, 0.f, 0.f};
+  const float4 *wps[3] = {wp, wp + wsec, wp + 2 * (size_t)wsec};
+#pragma unroll
+  for (int t = 0; t < DEPTH && t < NT; ++t) march_load<NUP, CT, PT>(tile[t / NUP], wps[t / NUP], sw, t % NUP, av[t % NS], bv[t % NS]);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (t + DEPTH < NT) march_load<NUP, CT, PT>(tile[(t + DEPTH) / NUP], wps[(t + DEPTH) / NUP], sw, (t + DEPTH) % NUP, av[(t + DEPTH) % NS], bv[(t + DEPTH) % NS]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (CT * PT == 1 && (t & 1)) conv_chunk_mfma<CT, PT>(av[t % NS], bv[t % NS], acc2);
+    else conv_chunk_mfma<CT, PT>(av[t % NS], bv[t % NS], acc);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < NT) march_anchor<CT, PT>(av[(t + 1) % NS], bv[(t + 1) % NS]);
+    // every read of section (t - DEPTH) / NUP has returned once the operands of chunk t + 1 (fetched DEPTH chunks ago) are in
+    if (t % NUP == NUP - 1) release(t / NUP);
+  }
+  if constexpr (CT * PT == 1) acc[0][0] += acc2[0][0];
+}
+
 // ---- epilogue of one step; raw: 0 = final, 1 = store raw partial sums, 2 = add the stored partial sums, then final ----
 template <int CT, int PT>
 __device__ inline void march_epilogue(const ConvArgs &a, const MarchArgs &m, floatx4 (&acc)[CT][PT], const float4 (&scv)[CT], const float4 (&biv)[CT], int raw,
@@ -267,6 +294,25 @@ __device__ inline void march_consumer(const ConvArgs &a, const MarchArgs &m, flo
 #pragma unroll
           for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
         int rel = cur.rel0, slot = cur.slot0;
+#if !defined(DR_MARCH_NO_FLAT) && !defined(DR_MABL_NO_KLOOP)
+        if (KZ == 3 && NPI == 1 && z > 0 && z < Dc - 1) {  // all three planes exist: one pipelined pass over the 3 * NUP chunks
+          const int idx0 = L + rel;
+#if !defined(DR_MABL_NO_WAIT) && !defined(DR_MABL_FREE)
+          if (!march_wait_ready<NPW>(flags, idx0 + 2, cached, m.err, lane)) return;  // loads are published in order
+#endif
+          asm volatile("" ::: "memory");
+          const int sl1 = slot + 1 >= R ? slot + 1 - R : slot + 1, sl2 = slot + 2 >= R ? slot + 2 - R : slot + 2;
+          const float4 *const tiles[3] = {lds4 + (size_t)slot * m.PS, lds4 + (size_t)sl1 * m.PS, lds4 + (size_t)sl2 * m.PS};
+          const bool last = z == sg.zb - 1;
+          march_kloop3<NUP, CT, PT, (CT * PT >= 4 ? 1 : (CT * PT == 1 ? DR_MARCH_DEPTH + 1 : DR_MARCH_DEPTH))>(
+              tiles, wp, m.wsec, sw, acc, [&](int sec) {
+                if (sec == 0 || last) {
+                  asm volatile("" ::: "memory");
+                  if (lane == 0) flags[kMarchReleased + wave] = idx0 + sec + 1;
+                }
+              });
+        } else
+#endif
         for (int dz = 0; dz < KZ; ++dz) {
           const int plane = KZ == 3 ? z - 1 + dz : z;
           const bool there = plane >= 0 && plane < Dc;  // else: z padding, the section is skipped

@@ -1073,6 +1073,21 @@ static void inverse4_host(const float *e, float *out) {
   for (int i = 0; i < 16; ++i) out[i] = inv[i] * detr;
 }
 
+// Hands a finished render to the host: both images are written straight into the pinned result buffers by ONE kernel (16-byte
+// stores over PCIe) instead of two copy-engine transfers behind the ray-cast -- each of those costs its own launch and completion
+// latency, which for 2 MB is most of the time (0.14 ms for the pair against 0.05 ms here, DESIGN.md "render hand-off").
+__global__ __launch_bounds__(256) void k_publish(const unsigned char *__restrict__ a, unsigned char *__restrict__ ha, size_t na,
+                                                 const unsigned char *__restrict__ b, unsigned char *__restrict__ hb, size_t nb) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
+  const size_t qa = na >> 4, qb = nb >> 4;
+  for (size_t i = t; i < qa + qb; i += nt) {
+    if (i < qa) reinterpret_cast<uint4 *>(ha)[i] = reinterpret_cast<const uint4 *>(a)[i];
+    else reinterpret_cast<uint4 *>(hb)[i - qa] = reinterpret_cast<const uint4 *>(b)[i - qa];
+  }
+  for (size_t i = (qa << 4) + t; i < na; i += nt) ha[i] = a[i];
+  for (size_t i = (qb << 4) + t; i < nb; i += nt) hb[i] = b[i];
+}
+
 // ------------------------------------------------------------------ engine
 constexpr int kDefaultFusionPriority = 1;  // 0 least (the reference's), 1 normal (measured best in the TandemBackend loop), 2 greatest
 class FusionEngine {
@@ -1144,6 +1159,8 @@ class FusionEngine {
       for (int k = 0; k < 2; ++k) {  // double-buffered host results ("blocked"/"free", tsdf_volume.cu:846-872)
         DR_HIP(hipHostMalloc((void **)&r.h_bgr[k], npix_ * 3, hipHostMallocDefault));
         DR_HIP(hipHostMalloc((void **)&r.h_depth[k], npix_ * 4, hipHostMallocDefault));
+        DR_HIP(hipHostGetDevicePointer((void **)&r.hd_bgr[k], r.h_bgr[k], 0));
+        DR_HIP(hipHostGetDevicePointer((void **)&r.hd_depth[k], r.h_depth[k], 0));
       }
       DR_HIP(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
       DR_HIP(hipEventCreateWithFlags(&r.cast, hipEventDisableTiming));
@@ -1211,6 +1228,17 @@ class FusionEngine {
     else hipLaunchKernelGGL((k_raycast2<false, false, true>), grid, block, 0, st, dv, P, d_bgr, d_depth, d_flag, (unsigned long long *)nullptr);
     hipLaunchKernelGGL(k_raycast_fix, dim3(512), dim3(64), 0, st, d_, P, d_bgr, d_depth, d_flag);
   }
+  // render -> host (k_publish); DR_RENDER_D2H=copy: the two hipMemcpyAsync of round 2 (A/B hook)
+  void publish_render(int i) {
+    auto &r = renders_[i];
+    if (render_copy_) {
+      DR_HIP(hipMemcpyAsync(r.h_bgr[free_slot_], r.d_bgr, npix_ * 3, hipMemcpyDeviceToHost, r.stream));
+      DR_HIP(hipMemcpyAsync(r.h_depth[free_slot_], r.d_depth, npix_ * 4, hipMemcpyDeviceToHost, r.stream));
+      return;
+    }
+    hipLaunchKernelGGL(k_publish, dim3(128), dim3(256), 0, r.stream, (const unsigned char *)r.d_depth, (unsigned char *)r.hd_depth[free_slot_], npix_ * 4,
+                       (const unsigned char *)r.d_bgr, r.hd_bgr[free_slot_], npix_ * 3);
+  }
   // tsdf_volume.cu:634-700
   void render_async(const float *const *poses, int n) {
     expect(kRender, "Please call the functions like IntegrateScanAsync -> RenderAsync -> GetRenderResult.");
@@ -1224,8 +1252,7 @@ class FusionEngine {
       DR_HIP(hipStreamWaitEvent(r.stream, int_done_, 0));
       launch_raycast(r.stream, r.d_bgr, r.d_depth, r.d_flag, P);
       DR_HIP(hipEventRecord(r.cast, r.stream));
-      DR_HIP(hipMemcpyAsync(r.h_bgr[free_slot_], r.d_bgr, npix_ * 3, hipMemcpyDeviceToHost, r.stream));
-      DR_HIP(hipMemcpyAsync(r.h_depth[free_slot_], r.d_depth, npix_ * 4, hipMemcpyDeviceToHost, r.stream));
+      publish_render(i);
       DR_HIP(hipEventRecord(r.done, r.stream));
     }
   }
@@ -1393,8 +1420,7 @@ class FusionEngine {
         launch_raycast(r.stream, r.d_bgr, r.d_depth, r.d_flag, P);
         DR_HIP(hipEventRecord(e[4 + 3 * i], r.stream));
         DR_HIP(hipEventRecord(r.cast, r.stream));
-        DR_HIP(hipMemcpyAsync(r.h_bgr[free_slot_], r.d_bgr, npix_ * 3, hipMemcpyDeviceToHost, r.stream));
-        DR_HIP(hipMemcpyAsync(r.h_depth[free_slot_], r.d_depth, npix_ * 4, hipMemcpyDeviceToHost, r.stream));
+        publish_render(i);
         DR_HIP(hipEventRecord(e[5 + 3 * i], r.stream));
         DR_HIP(hipEventRecord(r.done, r.stream));
       }
@@ -1542,8 +1568,8 @@ class FusionEngine {
 
   struct Render {
     hipStream_t stream;
-    unsigned char *d_bgr, *h_bgr[2];
-    float *d_depth, *h_depth[2];
+    unsigned char *d_bgr, *h_bgr[2], *hd_bgr[2];   // hd_*: the pinned result buffers as the device addresses them
+    float *d_depth, *h_depth[2], *hd_depth[2];
     int *d_flag;  // pixels the fast ray-caster handed to the literal pass
     hipEvent_t done, cast;  // result on the host / ray-cast kernels finished (the volume may be written again)
   };
@@ -1561,6 +1587,7 @@ class FusionEngine {
   bool raycast_v1_ = getenv("DR_RAYCAST_V1") != nullptr;  // A/B hook: the literal first-generation ray-caster
   bool raycast_no_skip_ = getenv("DR_RAYCAST_NO_SKIP") != nullptr;  // A/B hook: no empty-space skip in k_raycast2
   bool raycast_unstaged_ = getenv("DR_RAYCAST_UNSTAGED") != nullptr;
+  bool render_copy_ = getenv("DR_RENDER_D2H") && !strcmp(getenv("DR_RENDER_D2H"), "copy");
   bool raycast_stats_ = getenv("DR_RAYCAST_STATS") != nullptr;     // measuring hook: iteration statistics of k_raycast2 on stderr
   unsigned long long *d_rstats_ = nullptr;
   std::vector<Render> renders_;

@@ -165,6 +165,17 @@ struct Rccl {
   }
 };
 
+// The four result maps of a window go to the pinned host block in ONE kernel (16-byte stores over PCIe) instead of four
+// copy-engine transfers: 4 x (launch + completion latency) is most of the time those take for 1.2 MB each.
+__global__ __launch_bounds__(256) void k_publish4(const float4 *__restrict__ a, const float4 *__restrict__ b, const float4 *__restrict__ c,
+                                                  const float4 *__restrict__ d, float4 *__restrict__ host, size_t n4) {
+  const size_t nt = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < 4 * n4; i += nt) {
+    const size_t k = i / n4, j = i - k * n4;
+    host[i] = (k == 0 ? a : (k == 1 ? b : (k == 2 ? c : d)))[j];
+  }
+}
+
 class MvsEngine {
  public:
   MvsEngine(const char *path, int device) : device_(device), blob_(load_blob(path)) {
@@ -457,10 +468,15 @@ class MvsEngine {
           DR_HIP(hipSetDevice(device_));
           forward(nullptr);
           const size_t n = (size_t)H_ * W_ * 4;
-          DR_HIP(hipMemcpyAsync(h_out_, T("depth").d, n, hipMemcpyDeviceToHost, stream_));
-          DR_HIP(hipMemcpyAsync(h_out_ + n / 4, T("confidence").d, n, hipMemcpyDeviceToHost, stream_));
-          DR_HIP(hipMemcpyAsync(h_out_ + 2 * (n / 4), T("depth3").d, n, hipMemcpyDeviceToHost, stream_));
-          DR_HIP(hipMemcpyAsync(h_out_ + 3 * (n / 4), T("conf3").d, n, hipMemcpyDeviceToHost, stream_));
+          if (out_copy_) {  // DR_MVS_D2H=copy: the four copy-engine transfers of round 2 (A/B hook)
+            DR_HIP(hipMemcpyAsync(h_out_, T("depth").d, n, hipMemcpyDeviceToHost, stream_));
+            DR_HIP(hipMemcpyAsync(h_out_ + n / 4, T("confidence").d, n, hipMemcpyDeviceToHost, stream_));
+            DR_HIP(hipMemcpyAsync(h_out_ + 2 * (n / 4), T("depth3").d, n, hipMemcpyDeviceToHost, stream_));
+            DR_HIP(hipMemcpyAsync(h_out_ + 3 * (n / 4), T("conf3").d, n, hipMemcpyDeviceToHost, stream_));
+          } else {  // (H and W are multiples of 32: whole float4s)
+            hipLaunchKernelGGL(k_publish4, dim3(256), dim3(256), 0, stream_, (const float4 *)T("depth").d, (const float4 *)T("confidence").d,
+                               (const float4 *)T("depth3").d, (const float4 *)T("conf3").d, (float4 *)h_out_dev_, n / 16);
+          }
           DR_HIP(hipStreamSynchronize(stream_));
           check_march();
           has_output_ = true;
@@ -613,6 +629,7 @@ class MvsEngine {
     if (h_out_) { (void)hipHostFree(h_out_); h_out_ = nullptr; }
     if (h_in_) { (void)hipHostFree(h_in_); h_in_ = nullptr; }
     DR_HIP(hipHostMalloc((void **)&h_out_, (size_t)H * W * 16, hipHostMallocDefault));
+    DR_HIP(hipHostGetDevicePointer((void **)&h_out_dev_, h_out_, 0));
     DR_HIP(hipHostMalloc((void **)&h_in_, (size_t)V * H * W * 3, hipHostMallocDefault));
     d_bgr_ = dalloc<uint8_t>((size_t)V * H * W * 3); misc_.push_back(d_bgr_);
     d_state_ = dalloc<unsigned>(8); misc_.push_back(d_state_);
@@ -952,7 +969,8 @@ class MvsEngine {
   CostVolArgs cv_[3];
   RegressArgs rg_[3];
   uint8_t *d_bgr_ = nullptr, *h_in_ = nullptr;
-  float *h_out_ = nullptr;
+  float *h_out_ = nullptr, *h_out_dev_ = nullptr;  // pinned result block (4 maps) and the address the device uses for it
+  bool out_copy_ = getenv("DR_MVS_D2H") && !strcmp(getenv("DR_MVS_D2H"), "copy");
   unsigned *d_state_ = nullptr, *d_hist_ = nullptr;
   unsigned filter_rank_ = 0;
   int H_ = 0, W_ = 0, V_ = 0;
