@@ -155,7 +155,11 @@ def mvsnet_leg(args, rank, dev, world):
         res["roofline"] = dict(bound="mfma", kernel=name, launches_per_step=dom["n"],
                                avg_launch_ms=dom["ms"] / dom["n"], flops_per_launch=dom["flops"] / dom["n"],
                                achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_FP32_MFMA_TFLOPS,
-                               traffic=pmc_traffic(name))
+                               traffic=pmc_traffic(name),
+                               # the next instances by time in the same forward (same definitions), so that one line shows where the
+                               # pipeline stands, not only its single largest entry
+                               top=[dict(kernel=k, launches=v["n"], ms=round(v["ms"], 4), frac=round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4))
+                                    for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])[:8] if v["flops"] > 0])
         step_s = res["ms_per_step"] * 1e-3
         res["pipeline"] = dict(gflop_per_depth_map=flops / 1e9, gb_per_depth_map=nbytes / 1e9,
                                tflops=flops / step_s / 1e12, frac_mfma=flops / step_s / 1e12 / PEAK_FP32_MFMA_TFLOPS,

@@ -870,6 +870,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
             const double startup = (double)ms.lds_bytes / 16.0 + 3000.0;
             double cost = ms.npo * (spw * unit * 1.02 + startup);
             if (fz) cost *= 1.5;  // measured (r3): with a 3-slot ring and two channel passes per tile the fused-skip producers are the bottleneck (0.24 ms against k_conv's 0.214 at 480 x 640)
+            else if (L.kd == 1) cost *= 1.6;  // 2-D layers: one step per tile, the whole halo per step -- measured 1.1-1.25x k_conv_a's time where the model says 0.6x (profiles/r03_experiments.txt, 8)
             if (march_policy >= 2) cost *= 1e-3;
             cands.push_back({cost, ci, pt, ct, 1, ty, txt, L.kd, ms.tyi, ms.txi, 2});
           }
@@ -894,7 +895,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
             const double waste = (double)cdiv(nPW, txt * 16) * txt * 16 / nPW;  // strips hanging over the end of the row
             const double unit = ms.ns * ms.nup * 4.0 * ct * pt * 32.0 * (ncw / 4.0) + 300.0;  // MFMA cycles of a step per SIMD + the per-step bookkeeping
             const double startup = (double)ms.lds_bytes / 16.0 + 3000.0;
-            double cost = spw * unit * 1.02 + startup;
+            double cost = (spw * unit * 1.02 + startup) * 1.5;  // measured 1.05-1.15x k_conv_a's time at 6-13 steps per workgroup: the model has no term for the ring fill
             (void)waste;
             if (conv_rowmarch_policy() >= 2) cost *= 1e-3;
             cands.push_back({cost, ci, pt, ct, 1, 1, txt, 1, 1, ms.txi, 3});

@@ -421,10 +421,9 @@ class MvsEngine {
       char kn[64] = "misc";
       if (o.kind == Op::CONV && o.conv.async == 2) snprintf(kn, sizeof kn, "k_conv_m<%d,%d,%d,%d,%d,%d>", o.conv.ci, o.conv.nup, o.conv.ct, o.conv.pt, o.conv.fz, o.conv.ncw);  // rocprofv3's spelling of the instance
       else if (o.kind == Op::CONV && o.conv.async) snprintf(kn, sizeof kn, "k_conv_a<%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt);
-      else if (o.kind == Op::CONV && o.conv.fz) snprintf(kn, sizeof kn, "k_conv<%d,%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt, o.conv.fz);
-      else if (o.kind == Op::CONV) snprintf(kn, sizeof kn, "k_conv<%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt);
-      else if (o.kind == Op::COSTVOL) snprintf(kn, sizeof kn, "k_costvol<%d>", 32 >> (o.stage - 1));
-      else if (o.kind == Op::PROB) snprintf(kn, sizeof kn, "k_prob");
+      else if (o.kind == Op::CONV) snprintf(kn, sizeof kn, "k_conv<%d,%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt, o.conv.fz);
+      else if (o.kind == Op::COSTVOL) snprintf(kn, sizeof kn, costvol_v1_ ? "k_costvol<%d>" : "k_costvol2<%d>", 32 >> (o.stage - 1));
+      else if (o.kind == Op::PROB) snprintf(kn, sizeof kn, getenv("DR_PROB_V1") ? "k_prob" : "k_prob2");
       else if (o.kind == Op::REGRESS) snprintf(kn, sizeof kn, "k_regress");
       else if (o.kind == Op::PREPROCESS) snprintf(kn, sizeof kn, "k_preprocess");
       else if (o.kind == Op::SKIPUP) snprintf(kn, sizeof kn, "k_skip_up<%d>", o.stage);
