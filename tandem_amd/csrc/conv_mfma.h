@@ -196,6 +196,21 @@ __device__ inline void conv_kloop(const float *lds, const float4 *wl, const int 
 // FZ > 0: fused FeatureNet skip -- the staged tile is computed (1x1 conv of an FZ-channel tensor + bias + nearest
 // upsample of the coarser level) instead of copied; the arithmetic is k_skip_up's, so the result is bit-identical to
 // running that kernel first and this one on its output.
+// One LDS-DMA piece: every lane fetches 16 bytes from its own global address, the wave's 1 KiB lands at LDS byte address
+// `lds_dst` (wave-uniform) + lane * 16.  Issued from inline asm on purpose: given the builtin, hipcc orders every later
+// LDS read behind the DMA with s_waitcnt vmcnt(0) -- directly in front of the K loop, which serialises the very overlap
+// this kernel exists for.  The asm statement is invisible to hipcc's counters; k_conv_a waits for it itself
+// (conv_a_wait_dma) before the barrier that publishes the buffer.  M0 is saved and restored around the instruction.
+__device__ inline void conv_a_dma16(const void *gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ inline void conv_a_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ inline unsigned conv_a_lds_addr(const void *p) {
+  return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char *)p;
+}
+
 template <int CI, int CT, int PT, int FZ = 0>
 __global__ __launch_bounds__(kConvThreads) void k_conv(const ConvArgs a) {
   extern __shared__ float4 lds4[];
@@ -239,7 +254,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv(const ConvArgs a) {
   float4 *wl = lds4 + ((size_t)NP * CIS) / 4;                           // [NU][CT][64] packed weights of the current pass
   int *tapl = reinterpret_cast<int *>(wl + (size_t)a.nuMax * CT * 64);  // [NU*TPC] tap offsets (floats)
   for (int i = tid; i < NU * TPC; i += kConvThreads) tapl[i] = a.tapoff[cls.tap_base + i] * CIS;
-  const unsigned n_w = (unsigned)NU * CT * 64;
+  [[maybe_unused]] const unsigned n_w = (unsigned)NU * CT * 64;
   const int *tp = tapl + sub;
   const unsigned total = (unsigned)NP * C4;
   for (int p = 0; p < a.npass; ++p) {
@@ -247,6 +262,20 @@ __global__ __launch_bounds__(kConvThreads) void k_conv(const ConvArgs a) {
     // sooner this workgroup can feed the MFMA pipe; the K loop of the neighbour fills the remaining issue slots.
     // (The opposite assignment -- priority to the K loop -- measured 6 % slower.)
     __builtin_amdgcn_s_setprio(2);
+    // This pass's packed weights go to LDS by LDS-DMA, requested BEFORE the tile is staged: the round trip to L2 for the
+    // weights runs beside the tile's instead of after it, and costs no registers.  (For the coarse layers, whose tiles are
+    // small and whose weights are 28-110 KB per pass, the weight fetch was half of the staging step.)  The K loop of the
+    // previous pass has left `wl` (barrier at the end of the pass); the pieces have landed at conv_a_wait_dma() below.
+    const float4 *wsrc = a.wpk + cls.w_base + ((size_t)p * NU * a.ctTot + ct0) * 64;
+#ifndef DR_CONV_NO_WEIGHT_DMA
+#ifdef DR_ABL_NO_STAGE
+    if (a.npass < 0)
+#endif
+    for (int e = wave; e < NU * CT; e += kConvThreads / 64) {  // piece e = u * CT + ct: 64 lanes x 16 B, contiguous on both sides
+      const int u = e / CT, ct = e - u * CT;
+      conv_a_dma16(wsrc + ((size_t)u * a.ctTot + ct) * 64 + lane, __builtin_amdgcn_readfirstlane(conv_a_lds_addr(wl + (size_t)e * 64)));
+    }
+#endif
     // ---- stage CI channels of the input halo tile into LDS (zero outside the tensor).  Loads are issued in
     // batches of kStageBatch per lane BEFORE the first LDS write so their HBM/L2 latencies overlap. ----
     constexpr int kStageBatch = CT >= 4 ? 6 : 12;  // normally the whole stage: one exposed HBM/L2 latency per pass
@@ -328,8 +357,10 @@ __global__ __launch_bounds__(kConvThreads) void k_conv(const ConvArgs a) {
       for (int k = 0; k < kStageBatch; ++k)
         if (dst[k] >= 0) *reinterpret_cast<float4 *>(lds + dst[k]) = v[k];
     }
-    {  // this pass's packed weights -> LDS, so that the K loop below touches no global memory
-      const float4 *wsrc = a.wpk + cls.w_base + ((size_t)p * NU * a.ctTot + ct0) * 64;
+#ifndef DR_CONV_NO_WEIGHT_DMA
+    conv_a_wait_dma();
+#else
+    {  // (A/B build: the weights through registers, after the tile)
       constexpr int kWB = 8;
 #ifdef DR_ABL_NO_STAGE
       if (a.npass < 0)
@@ -350,6 +381,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv(const ConvArgs a) {
         }
       }
     }
+#endif
     __builtin_amdgcn_s_setprio(0);
     __syncthreads();
 #ifndef DR_ABL_NO_KLOOP
@@ -387,21 +419,6 @@ __host__ __device__ inline void conv_a_slot(int s, int &pos, int &c4) {  // inve
   if constexpr (CI == 4) { pos = s; c4 = 0; }
   else if constexpr (CI == 8) { const int pp = s >> 1; pos = pp ^ ((pp >> 3) & 1); c4 = s & 1; }
   else { const int pp = s >> 2; pos = pp ^ ((pp >> 3) & 1); c4 = (s & 3) ^ ((pos >> 1) & 3); }
-}
-
-// One LDS-DMA piece: every lane fetches 16 bytes from its own global address, the wave's 1 KiB lands at LDS byte address
-// `lds_dst` (wave-uniform) + lane * 16.  Issued from inline asm on purpose: given the builtin, hipcc orders every later
-// LDS read behind the DMA with s_waitcnt vmcnt(0) -- directly in front of the K loop, which serialises the very overlap
-// this kernel exists for.  The asm statement is invisible to hipcc's counters; k_conv_a waits for it itself
-// (conv_a_wait_dma) before the barrier that publishes the buffer.  M0 is saved and restored around the instruction.
-__device__ inline void conv_a_dma16(const void *gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ inline void conv_a_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ inline unsigned conv_a_lds_addr(const void *p) {
-  return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char *)p;
 }
 
 template <int CI, int CT>
