@@ -910,7 +910,15 @@ class MvsEngine {
         }
         case Op::REGRESS: {
           const RegressArgs &r = rg_[o.stage - 1];
-          if (!idle_stage) hipLaunchKernelGGL(k_regress, dim3(cdiv(r.h * r.w, 256)), dim3(256), 0, stream_, r);
+          if (!idle_stage) {
+            const dim3 grid(cdiv(r.h * r.w, 256)), block(256);
+            const int D = regress_generic_ ? 0 : r.planes.D;  // DR_REGRESS_GENERIC=1: the three-pass kernel for every plane count (A/B and parity hook)
+            if (D == 48) hipLaunchKernelGGL(k_regress_r<48>, grid, block, 0, stream_, r);
+            else if (D == 32) hipLaunchKernelGGL(k_regress_r<32>, grid, block, 0, stream_, r);
+            else if (D == 8) hipLaunchKernelGGL(k_regress_r<8>, grid, block, 0, stream_, r);
+            else if (D == 4) hipLaunchKernelGGL(k_regress_r<4>, grid, block, 0, stream_, r);
+            else hipLaunchKernelGGL(k_regress, grid, block, 0, stream_, r);
+          }
           if (rooted) {  // the stage's depth map goes back to every rank: stage s + 1 centres its hypotheses on it; stage 3's
             Rccl &c = Rccl::get();  // depth and confidence are the result (the edge filter then runs on every rank: 0.08 ms)
             const DevTensor &dep = T("depth" + std::to_string(o.stage));
@@ -948,6 +956,7 @@ class MvsEngine {
   bool side_enabled_ = true;
   // channels per lane of k_costvol for C >= 16 (measured: stage 2 0.210 -> 0.194 ms, stage 1 0.146 -> 0.143 ms with 4)
   bool costvol_v1_ = getenv("DR_COSTVOL_V1") != nullptr;
+  bool regress_generic_ = getenv("DR_REGRESS_GENERIC") != nullptr;
   int cpl_wide_ = getenv("DR_COSTVOL_CPL") ? (atoi(getenv("DR_COSTVOL_CPL")) == 8 ? 8 : 4) : 4;
   size_t fork_lo_ = 0, fork_hi_ = 0, feat2_op_ = 0;  // ops [fork_lo_, fork_hi_) = fn.skip2 .. fn.out3
 

@@ -500,6 +500,19 @@ __global__ __launch_bounds__(256) void k_prob2(const float *__restrict__ x, cons
 }
 
 // ------------------------------------------------------------------ regression
+// expf whose result cannot be fused into its consumer: with -ffp-contract=fast hipcc folds the exponential's last multiply into
+// `sum += ...` where the value has a single use and cannot where it is reused, so two spellings of the same regression would
+// differ in the last bit.  Both kernels below use this form and are bit-identical to each other.
+__device__ inline float expf_value(float x) {
+  float r = expf(x);
+  asm volatile("" : "+v"(r));
+  return r;
+}
+// The hypothesis of plane k and the two running sums, spelled with explicit fused multiply-adds: left to -ffp-contract=fast, hipcc
+// contracts the unrolled register kernel and the looping kernel differently (1 ulp in 1 % of the stage-2 pixels).
+__device__ inline float regress_plane(const PixelPlanes &pp, const PlaneArgs &p, int k) {
+  return pp.uniform ? __builtin_fmaf(p.interval, (float)k, p.dmin) : __builtin_fmaf(pp.rng, (float)k * pp.invD, pp.lo);
+}
 struct RegressArgs {
   const float *logits;  // (D,h,w)
   float *depth, *conf;  // (h,w)
@@ -515,18 +528,55 @@ __global__ __launch_bounds__(256) void k_regress(const RegressArgs a) {
   float mx = -INFINITY;
   for (int k = 0; k < D; ++k) mx = fmaxf(mx, a.logits[(size_t)k * hw + n]);
   float sum = 0.f;
-  for (int k = 0; k < D; ++k) sum += expf(a.logits[(size_t)k * hw + n] - mx);
+  for (int k = 0; k < D; ++k) sum += expf_value(a.logits[(size_t)k * hw + n] - mx);
   float dep = 0.f, ek = 0.f;
   for (int k = 0; k < D; ++k) {
-    const float p = expf(a.logits[(size_t)k * hw + n] - mx) / sum;
-    dep += p * pp.at(a.planes, k);
-    ek += p * (float)k;
+    const float p = expf_value(a.logits[(size_t)k * hw + n] - mx) / sum;
+    dep = __builtin_fmaf(p, regress_plane(pp, a.planes, k), dep);
+    ek = __builtin_fmaf(p, (float)k, ek);
   }
   int idx = (int)ek;  // .long() truncation, module.py:1131
   idx = min(max(idx, 0), D - 1);
   float c = 0.f;
   for (int k = idx - 1; k <= idx + 2; ++k)
-    if (k >= 0 && k < D) c += expf(a.logits[(size_t)k * hw + n] - mx) / sum;
+    if (k >= 0 && k < D) c += expf_value(a.logits[(size_t)k * hw + n] - mx) / sum;
+  a.depth[n] = dep;
+  a.conf[n] = c;
+}
+
+// The same regression with the pixel's D logits held in registers (D known at compile time: the plane counts the models use):
+// one round of loads, issued back to back, instead of three dependent passes over global memory plus the confidence window.
+// The arithmetic and its order are k_regress's.
+template <int D>
+__global__ __launch_bounds__(256) void k_regress_r(const RegressArgs a) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x, hw = a.h * a.w;
+  if (n >= hw) return;
+  const int y = n / a.w, x = n - y * a.w;
+  float v[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) v[k] = a.logits[(size_t)k * hw + n];
+  const PixelPlanes pp = make_planes(a.planes, y, x);
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < D; ++k) mx = fmaxf(mx, v[k]);
+#pragma unroll
+  for (int k = 0; k < D; ++k) v[k] = expf_value(v[k] - mx);  // (the three-pass kernel recomputes this value in every pass)
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < D; ++k) sum += v[k];
+  float dep = 0.f, ek = 0.f;
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    const float p = v[k] / sum;
+    dep = __builtin_fmaf(p, regress_plane(pp, a.planes, k), dep);
+    ek = __builtin_fmaf(p, (float)k, ek);
+  }
+  int idx = (int)ek;  // .long() truncation, module.py:1131
+  idx = min(max(idx, 0), D - 1);
+  float c = 0.f;
+#pragma unroll
+  for (int k = 0; k < D; ++k)  // the four planes idx-1 .. idx+2, in ascending order as k_regress adds them
+    if (k >= idx - 1 && k <= idx + 2) c += v[k] / sum;
   a.depth[n] = dep;
   a.conf[n] = c;
 }

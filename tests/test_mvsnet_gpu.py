@@ -333,3 +333,40 @@ def test_fused_skip_on_the_marching_kernel(trained_blob, monkeypatch):
     for (fa, ka), (fb, kb) in zip(*feats):
         assert "k_conv_m" in ka and "k_conv_m" not in kb, (ka, kb)
         assert np.abs(fa - fb).max() <= 2e-5 * np.abs(fb).max()
+
+
+def test_register_regression_equals_the_three_pass_kernel(trained_blob, tmp_path, monkeypatch):
+    """Round 3's k_regress_r<D> (the pixel's logits in registers, one round of loads) against the three-pass k_regress: same
+    expressions in the same order -- at plane counts with a register instance (48/32/8, 48/4/4) and without (16/8/8: the generic
+    kernel either way): all four output maps equal bit for bit (both kernels take the exponential through expf_value(), which
+    keeps hipcc from fusing its last multiply into one spelling's sum and not the other's)."""
+    from synth import scene
+    from tandem_amd import weights as Wt
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    _, tens = Wt.read_blob(trained_blob)
+    blobs = [trained_blob]
+    for planes in ((48, 4, 4), (16, 8, 8)):
+        b = str(tmp_path / ("w_%d_%d_%d.tdmw" % planes))
+        Wt.write_blob(b, tens, depth_num=planes)
+        blobs.append(b)
+    for blob in blobs:
+        outs = []
+        for old in (False, True):
+            if old:
+                monkeypatch.setenv("DR_REGRESS_GENERIC", "1")
+            m = DrMvsnet(blob)
+            res = []
+            for rep, (h, w, v) in enumerate(((96, 160, 4), (128, 224, 3))):
+                win = scene.make_window(h, w, v, seed=7 + rep)
+                m.CallAsync(h, w, v, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), 0.5, 5.0, 10.0)
+                res.append(m.GetResult())
+            outs.append(res)
+            m.close()
+            if old:
+                monkeypatch.delenv("DR_REGRESS_GENERIC")
+        for a, b in zip(*outs):
+            dd = np.abs(a.depth_dense - b.depth_dense) / np.maximum(np.abs(b.depth_dense), 1e-3)
+            dc = np.abs(a.confidence_dense - b.confidence_dense)
+            print("regress A/B:", os.path.basename(blob), "max rel depth diff %.3e, conf diff > 1e-5 at %.2e of pixels, max %.3e" % (dd.max(), (dc > 1e-5).mean(), dc.max()))
+            assert np.array_equal(a.depth_dense, b.depth_dense) and np.array_equal(a.confidence_dense, b.confidence_dense)
+            assert np.array_equal(a.depth, b.depth) and np.array_equal(a.confidence, b.confidence)
