@@ -936,7 +936,7 @@ class MvsEngine {
           hipLaunchKernelGGL(k_edge, dim3(cdiv(H_ * W_, 256)), dim3(256), 0, stream_, T("depth3").d, T("edge").d, H_, W_);
           break;
         case Op::HIST:
-          hipLaunchKernelGGL(k_hist, dim3(std::min(cdiv(H_ * W_, 256), 512)), dim3(256), 0, stream_, T("edge").d, H_ * W_, o.shift, o.bits, d_state_, d_hist_);
+          hipLaunchKernelGGL(k_hist, dim3(std::min(cdiv(H_ * W_, 256), hist_blocks_)), dim3(256), 0, stream_, T("edge").d, H_ * W_, o.shift, o.bits, d_state_, d_hist_);
           break;
         case Op::SCAN:
           hipLaunchKernelGGL(k_scan, dim3(1), dim3(256), 0, stream_, d_state_, d_hist_, o.shift, o.bits);
@@ -957,6 +957,7 @@ class MvsEngine {
   // channels per lane of k_costvol for C >= 16 (measured: stage 2 0.210 -> 0.194 ms, stage 1 0.146 -> 0.143 ms with 4)
   bool costvol_v1_ = getenv("DR_COSTVOL_V1") != nullptr;
   bool regress_generic_ = getenv("DR_REGRESS_GENERIC") != nullptr;
+  int hist_blocks_ = getenv("DR_HIST_BLOCKS") ? std::max(1, atoi(getenv("DR_HIST_BLOCKS"))) : 128;  // workgroups of a histogram level (each flushes its bins with atomics on a few hot addresses)
   int cpl_wide_ = getenv("DR_COSTVOL_CPL") ? (atoi(getenv("DR_COSTVOL_CPL")) == 8 ? 8 : 4) : 4;
   size_t fork_lo_ = 0, fork_hi_ = 0, feat2_op_ = 0;  // ops [fork_lo_, fork_hi_) = fn.skip2 .. fn.out3
 

@@ -433,7 +433,8 @@ __global__ __launch_bounds__(256) void k_prob(const float *__restrict__ x, const
 // marches along z: one input plane of the tile (6 x 66 positions, two float4 halves kept in separate arrays so that
 // consecutive lanes read consecutive 16-byte slots) is staged ONCE per plane -- global -> registers while the previous
 // plane is being consumed, registers -> the other LDS buffer afterwards, one barrier per plane -- and serves the nine
-// taps of all 256 lanes and the three output planes it contributes to.  Arithmetic and summation order are k_prob's.
+// taps of all 256 lanes and the three output planes it contributes to.  The products are k_prob's; they are summed in two
+// interleaved chains (even and odd channels) instead of one.
 constexpr int kProbTY = 4, kProbTX = 64, kProbPos = (kProbTY + 2) * (kProbTX + 2);  // 396 staged positions per plane
 __global__ __launch_bounds__(256) void k_prob2(const float *__restrict__ x, const float *__restrict__ wt /*[27][8]*/,
                                                float *__restrict__ out, int D, int h, int w, int zchunk, int gx, int gy, int gz, int nwg) {
@@ -470,7 +471,11 @@ __global__ __launch_bounds__(256) void k_prob2(const float *__restrict__ x, cons
     for (int k = 0; k < 2; ++k)
       if (spos[k] >= 0) { lds[b][0][spos[k]] = r[k][0]; lds[b][1][spos[k]] = r[k][1]; }
   };
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f;  // output planes zz-1, zz, zz+1 while input plane zz is being consumed
+  // output planes zz-1, zz, zz+1 while input plane zz is being consumed.  Each accumulator is a PAIR (even / odd channels, added at
+  // the end): the 8-channel dot product of a tap is then four packed fmas (v_pk_fma_f32: two fp32 fmas per lane and instruction)
+  // instead of eight scalar ones -- the kernel is bound by vector-ALU issue (216 MACs per voxel).
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
   fetch(z0 - 1);
   stash(0);
   int b = 0;
@@ -485,16 +490,18 @@ __global__ __launch_bounds__(256) void k_prob2(const float *__restrict__ x, cons
         for (int kw = 0; kw < 3; ++kw) {
           const int p = (ty + kh) * (kProbTX + 2) + tx + kw;
           const float4 lo = lds[b][0][p], hi = lds[b][1][p];
-          const float *w2 = wt + ((2 * 3 + kh) * 3 + kw) * 8, *w1 = wt + ((1 * 3 + kh) * 3 + kw) * 8, *w0 = wt + ((0 * 3 + kh) * 3 + kw) * 8;
-#define DR_DOT8(A, WK) A += lo.x * WK[0] + lo.y * WK[1] + lo.z * WK[2] + lo.w * WK[3] + hi.x * WK[4] + hi.y * WK[5] + hi.z * WK[6] + hi.w * WK[7]
+          const f2 x01 = {lo.x, lo.y}, x23 = {lo.z, lo.w}, x45 = {hi.x, hi.y}, x67 = {hi.z, hi.w};
+          const f2 *w2 = reinterpret_cast<const f2 *>(wt + ((2 * 3 + kh) * 3 + kw) * 8), *w1 = reinterpret_cast<const f2 *>(wt + ((1 * 3 + kh) * 3 + kw) * 8),
+                   *w0 = reinterpret_cast<const f2 *>(wt + ((0 * 3 + kh) * 3 + kw) * 8);
+#define DR_DOT8(A, WK) A = __builtin_elementwise_fma(x01, WK[0], A); A = __builtin_elementwise_fma(x23, WK[1], A); A = __builtin_elementwise_fma(x45, WK[2], A); A = __builtin_elementwise_fma(x67, WK[3], A)
           DR_DOT8(a0, w2); DR_DOT8(a1, w1); DR_DOT8(a2, w0);
 #undef DR_DOT8
         }
       }
     }
     const int zo = zz - 1;
-    if (zo >= z0 && zo < z1 && xo < w && yo < h) out[((size_t)zo * h + yo) * w + xo] = a0;
-    a0 = a1; a1 = a2; a2 = 0.f;
+    if (zo >= z0 && zo < z1 && xo < w && yo < h) out[((size_t)zo * h + yo) * w + xo] = a0.x + a0.y;
+    a0 = a1; a1 = a2; a2 = f2{0.f, 0.f};
     if (zz + 1 <= z1) stash(b ^ 1);
   }
 }
@@ -597,6 +604,7 @@ __global__ __launch_bounds__(256) void k_edge(const float *__restrict__ depth, f
       const float nb = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? depth[yy * w + xx] : 0.f;
       v[(dy + 2) * 5 + dx + 2] = fabsf(nb - c);
     }
+#ifdef DR_EDGE_RANK_COUNT  // round 1-2: rank by counting, 1250 compares per pixel (A/B build)
   float kth = 0.f;
 #pragma unroll
   for (int i = 0; i < 25; ++i) {
@@ -609,6 +617,24 @@ __global__ __launch_bounds__(256) void k_edge(const float *__restrict__ depth, f
     if (less <= 14 && leq > 14) kth = v[i];  // k = 15 (1-based), module.py:1336,1343
   }
   edge[n] = kth;
+#else
+  // the same order statistic from a sorting network: Knuth's merge exchange (TAOCP 5.2.2 M) for 25 inputs has 138 comparators,
+  // the 113 below are the ones element 14 of the sorted order depends on (of which the compiler drops the unused min or max
+  // halves).  A k-th smallest VALUE does not depend on how it is found, so the result is the counting form's bit for bit.
+#define CE(A, B) { const float lo_ = fminf(v[A], v[B]), hi_ = fmaxf(v[A], v[B]); v[A] = lo_; v[B] = hi_; }
+  CE(0,16) CE(1,17) CE(2,18) CE(3,19) CE(4,20) CE(5,21) CE(6,22) CE(7,23) CE(8,24) CE(0,8) CE(1,9) CE(2,10)
+  CE(3,11) CE(4,12) CE(5,13) CE(6,14) CE(7,15) CE(16,24) CE(8,16) CE(9,17) CE(10,18) CE(11,19) CE(12,20) CE(13,21)
+  CE(14,22) CE(15,23) CE(0,4) CE(1,5) CE(2,6) CE(3,7) CE(8,12) CE(9,13) CE(10,14) CE(11,15) CE(16,20) CE(17,21)
+  CE(18,22) CE(19,23) CE(4,16) CE(5,17) CE(6,18) CE(7,19) CE(12,24) CE(4,8) CE(5,9) CE(6,10) CE(7,11) CE(12,16)
+  CE(13,17) CE(14,18) CE(15,19) CE(20,24) CE(0,2) CE(1,3) CE(4,6) CE(5,7) CE(8,10) CE(9,11) CE(12,14) CE(13,15)
+  CE(16,18) CE(17,19) CE(20,22) CE(21,23) CE(2,16) CE(3,17) CE(6,20) CE(7,21) CE(10,24) CE(2,8) CE(3,9) CE(6,12)
+  CE(7,13) CE(10,16) CE(11,17) CE(14,20) CE(15,21) CE(18,24) CE(2,4) CE(3,5) CE(6,8) CE(7,9) CE(10,12) CE(11,13)
+  CE(14,16) CE(15,17) CE(18,20) CE(19,21) CE(22,24) CE(0,1) CE(2,3) CE(4,5) CE(6,7) CE(8,9) CE(10,11) CE(12,13)
+  CE(14,15) CE(16,17) CE(18,19) CE(20,21) CE(22,23) CE(1,16) CE(3,18) CE(5,20) CE(7,22) CE(9,24) CE(7,14) CE(9,16)
+  CE(11,18) CE(13,20) CE(11,14) CE(13,16) CE(13,14)
+#undef CE
+  edge[n] = v[14];  // k = 15 (1-based), module.py:1336,1343
+#endif
 }
 
 // Exact k-th smallest of non-negative floats by a 3-level radix select on the bit pattern
