@@ -580,6 +580,10 @@ struct ConvLayer {  // logical description (torch semantics)
   int kd = 1, kh = 1, kw = 1;
   int sd = 1, sh = 1, sw = 1;
   bool transposed = false;          // ConvTranspose3d(k=3, pad=1, output_padding = stride-1)
+  int up2 = 0;                      // 1 + py: Conv2d(k=3, pad=1) applied to the nearest x2 upsampling (in H and W) of the input, which is given
+                                    // at HALF resolution and never upsampled in memory; this launch produces the output rows 2Y + py.  Output
+                                    // pixel (2Y+py, 2X+px) reads 2 x 2 input pixels, the kernel rows / columns that fall on the same input
+                                    // pixel summed (weight (Cout,Cin,1,3,3)); both px are rows of the launch (2 * Cout rows)
   const float *weight = nullptr;    // (Cout,Cin,kd,kh,kw) or transposed (Cin,Cout,kd,kh,kw)
   std::vector<float> scale, bias;   // per Cout (folded BN / conv bias); empty -> 1 / 0
   bool relu = false;
@@ -621,6 +625,22 @@ inline int parity_kernel_index(int parity, int off) {  // -1: this (parity, offs
 // A strided transposed axis comes in two forms.  DENSE: both parities are output ROWS of one class (offsets {0,1}, zero weight
 // where parity 0 does not use offset 1) -- one class, but a quarter of the products per axis are multiplications by zero.
 // SPLIT: one class per parity (parity 0: offset 0 only; parity 1: offsets 0 and 1) -- no zero products, half the rows.
+// An up2 axis (ConvLayer::up2): output 2m + par of the 3-tap kernel over the upsampled signal reads input {m-1, m} (par 0: kernel
+// index 0 | indices 1 and 2 summed) or {m, m+1} (par 1: indices 0 and 1 summed | index 2); offsets are relative to m - 1 (pad 1).
+inline std::vector<DimTaps> axis_classes_up2(int in_size, bool split) {
+  std::vector<DimTaps> r;
+  if (!split) { DimTaps d; d.t = {0, 1, 2}; d.off = {0, 1, 2}; d.p = 1; d.om = 2; d.npos = in_size; r.push_back(d); return r; }
+  DimTaps e; e.t = {0, 1}; e.off = {0, 1}; e.p = 1; e.om = 2; e.oo = 0; e.npos = in_size; e.par = 0; r.push_back(e);
+  DimTaps o; o.t = {1, 2}; o.off = {1, 2}; o.p = 1; o.om = 2; o.oo = 1; o.npos = in_size; o.par = 1; r.push_back(o);
+  return r;
+}
+// kernel indices that (parity, input offset) of an up2 axis sums; returns the count (0: the pair carries no weight)
+inline int up2_kernel_set(int parity, int off, int (&k)[2]) {
+  if (parity == 0) { if (off == 0) { k[0] = 0; return 1; } if (off == 1) { k[0] = 1; k[1] = 2; return 2; } return 0; }
+  if (off == 1) { k[0] = 0; k[1] = 1; return 2; }
+  if (off == 2) { k[0] = 2; return 1; }
+  return 0;
+}
 inline std::vector<DimTaps> axis_classes(int k, int s, bool transposed, int in_size, bool split = false) {
   std::vector<DimTaps> r;
   if (!transposed) {
@@ -771,13 +791,20 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   // rank: which candidate of the cost model's ranking to build (0 = its choice); used by the engine's autotuner
   if (L.Cin % 4 != 0 || inC < L.Cin) fail(DR_ERR_ARG, "plan_conv: Cin=%d must be a multiple of 4 (tensor C=%d)", L.Cin, inC);
   const int form = L.transposed ? conv_deconv_form(L.Cout) : 0;
+  if (L.up2 && (L.transposed || L.kd != 1 || L.kh != 3 || L.kw != 3 || L.sd != 1 || L.sh != 1 || L.sw != 1 || mode != CONV_NORMAL))
+    fail(DR_ERR_ARG, "plan_conv: up2 is a plain 3x3 stride-1 2-D layer over the upsampled input");
   auto cz = axis_classes(L.kd, L.sd, L.transposed, inD, form >= 1);
   auto cy = axis_classes(L.kh, L.sh, L.transposed, inH, form >= 1);
   auto cx = axis_classes(L.kw, L.sw, L.transposed, inW, form >= 2);
+  if (L.up2) {  // one y parity per launch (a single class: the persistent kernels apply), both x parities as rows
+    cy = {axis_classes_up2(inH, true)[L.up2 - 1]};
+    cx = axis_classes_up2(inW, false);
+  }
+  const bool parity_layer = L.transposed || L.up2;
   ConvPlanOut R;
   R.outD = L.transposed ? inD * L.sd : cz[0].npos;
-  R.outH = L.transposed ? inH * L.sh : cy[0].npos;
-  R.outW = L.transposed ? inW * L.sw : cx[0].npos;
+  R.outH = L.transposed ? inH * L.sh : (L.up2 ? 2 * inH : cy[0].npos);
+  R.outW = L.transposed ? inW * L.sw : (L.up2 ? 2 * inW : cx[0].npos);
   int rows, rows_valid, outWv = R.outW, outCv;
   if (mode == CONV_XPAIR) {
     if (L.transposed || L.sw != 1 || L.Cout != 8 || (R.outW & 1)) fail(DR_ERR_ARG, "XPAIR needs Cout=8, stride 1, even W");
@@ -791,9 +818,9 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   }
   // transposed: parity bits of the strided axes, enumerated (z, y, x) -> par_map holds 3 bits (z<<2|y<<1|x) per parity
   int npar = 1, par_map = 0;
-  const bool strided[3] = {L.transposed && L.sd == 2, L.transposed && L.sh == 2, L.transposed && L.sw == 2};
-  const bool dense[3] = {strided[0] && form < 1, strided[1] && form < 1, strided[2] && form < 2};  // parity carried by the output rows
-  if (L.transposed) {
+  const bool strided[3] = {L.transposed && L.sd == 2, (L.transposed && L.sh == 2) || L.up2, (L.transposed && L.sw == 2) || L.up2};
+  const bool dense[3] = {strided[0] && form < 1, strided[1] && form < 1 && !L.up2, strided[2] && (L.up2 || form < 2)};  // parity carried by the output rows
+  if (parity_layer) {
     if (mode != CONV_NORMAL) fail(DR_ERR_ARG, "plan_conv: transposed layers use CONV_NORMAL");
     for (int d = 0; d < 3; ++d) if (dense[d]) npar *= 2;
     for (int q = 0; q < npar; ++q) {
@@ -867,7 +894,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   // (a fused FeatureNet skip runs on it in exactly one form: 8-channel source, 32 -> 8 XPAIR 3x3 layer, producers compute the tile)
   const bool march_fz_ok = !fz || (fz->cin == 8 && L.Cin == 32 && L.kd == 1 && mode == CONV_XPAIR && !getenv("DR_FZ_NO_MARCH"));
   const int march_policy = march_fz_ok ? conv_march_policy() : 0;
-  const bool march_ok = march_policy >= 1 && ncls == 1 && !L.transposed && mode != CONV_X8 && L.kh == 3 && L.kw == 3 && (L.kd == 1 || L.kd == 3) &&
+  const bool march_ok = march_policy >= 1 && ncls == 1 && !L.transposed && !L.up2 && mode != CONV_X8 && L.kh == 3 && L.kw == 3 && (L.kd == 1 || L.kd == 3) &&
                         SZ == 1 && SY == 1 && L.sw == 1;
   const int march_ntp = march_ok ? 3 * (int)cx[0].t.size() : 0;  // taps per input plane
   if (march_ok) {
@@ -895,7 +922,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
     }
   }
   // the row march: 2-D 3x3 stride-1 layers on the same kernel, marching down the rows of each image (async = 3)
-  const bool rowmarch_ok = !fz && conv_rowmarch_policy() >= 1 && ncls == 1 && !L.transposed && mode != CONV_X8 && L.kd == 1 && L.kh == 3 && L.kw == 3 &&
+  const bool rowmarch_ok = !fz && conv_rowmarch_policy() >= 1 && ncls == 1 && !L.transposed && !L.up2 && mode != CONV_X8 && L.kd == 1 && L.kh == 3 && L.kw == 3 &&
                            SZ == 1 && SY == 1 && L.sw == 1 && !add;
   const int row_ntp = rowmarch_ok ? (int)cx[0].t.size() : 0;  // x taps of one row
   if (rowmarch_ok) {
@@ -962,7 +989,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
     if (rank == 0 && !getenv("DR_CONV_NO_TUNED")) {  // a measured plan for exactly this layer moves to the front
       for (const ConvTuned &t : kConvTuned) {
         if (t.Cin != L.Cin || t.Cout != L.Cout || t.kd != L.kd || t.kh != L.kh || t.kw != L.kw || t.sd != L.sd || t.sh != L.sh || t.sw != L.sw ||
-            t.transposed != (L.transposed ? 1 : 0) || t.mode != (int)mode || t.inD != inD || t.inH != inH || t.inW != inW) continue;
+            t.transposed != (L.transposed ? 1 : (L.up2 ? 1 + L.up2 : 0)) || t.mode != (int)mode || t.inD != inD || t.inH != inH || t.inW != inW) continue;
         for (size_t i = 0; i < cands.size(); ++i) {
           const Cand &k = cands[i];
           if (k.ci == t.ci && k.ct == t.ct && k.pt == t.pt && k.tz == t.tz && k.ty == t.ty && k.txt == t.txt && k.async == t.async_) { std::swap(cands[0], cands[i]); break; }
@@ -980,7 +1007,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   // per-row epilogue affine
   std::vector<float> sc(rows, 1.f), bi(rows, 0.f);
   for (int r = 0; r < rows_valid; ++r) {
-    const int c = L.transposed ? r % L.Cout : (mode == CONV_NORMAL ? r : (mode == CONV_XPAIR ? (r & 7) : 0));
+    const int c = parity_layer ? r % L.Cout : (mode == CONV_NORMAL ? r : (mode == CONV_XPAIR ? (r & 7) : 0));
     if (!L.scale.empty()) sc[r] = L.scale[c];
     if (!L.bias.empty()) bi[r] = L.bias[c];
   }
@@ -1018,7 +1045,14 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
         const int tap = u * TPC + k16 / CI, cin = p * CI + k16 % CI, row = ct * 16 + i;
         float v = 0.f;
         if (tap < ntaps && row < rows_valid) {
-          if (L.transposed) {
+          if (L.up2) {  // sum of the kernel entries that fall on this (parity, input offset) pair, per axis
+            const int q = row / L.Cout, co = row % L.Cout, bits = (par_map >> (3 * q)) & 7;
+            int ky[2], kx[2];
+            const int ny = up2_kernel_set(Y.par, ty[tap], ky), nx = up2_kernel_set(bits & 1, tx[tap], kx);
+            double acc = 0;
+            for (int iy = 0; iy < ny; ++iy) for (int ix = 0; ix < nx; ++ix) acc += weight_at(co, cin, 0, ky[iy], kx[ix]);
+            v = (float)acc;
+          } else if (L.transposed) {
             const int q = row / L.Cout, co = row % L.Cout, bits = (par_map >> (3 * q)) & 7;
             const int offs[3] = {tz[tap], ty[tap], tx[tap]};  // for transposed layers DimTaps::t carries the input offset
             int kk[3];
@@ -1039,7 +1073,8 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
         }
         pk[w0 + ((((size_t)p * NU + u) * CTtot + ct) * 64 + l) * 4 + s] = v;
       }
-    if (L.transposed) flops += ic == 0 ? 2.0 * nPD * nPH * nPW * (double)L.kd * L.kh * L.kw * L.Cin * L.Cout : 0.0;
+    if (L.up2) flops += ic == 0 ? 2.0 * nPD * nPH * nPW * 16.0 * L.Cin * L.Cout : 0.0;  // 4 output pixels x (2 x 2 input pixels) per input position
+    else if (L.transposed) flops += ic == 0 ? 2.0 * nPD * nPH * nPW * (double)L.kd * L.kh * L.kw * L.Cin * L.Cout : 0.0;
     else flops += 2.0 * nPD * nPH * nPW * (mode == CONV_NORMAL ? 1 : shifts) * (double)ntz * nty * (mode == CONV_NORMAL ? ntx : L.kw) * L.Cin * L.Cout;
   }
 
@@ -1057,7 +1092,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   a.nPD = nPD; a.nPH = nPH; a.nPW = nPW;
   a.sz = SZ; a.sy = SY; a.sx = SX; a.pz = PZ; a.py = PY; a.px = PX;
   a.omz = cz[0].om; a.omy = cy[0].om; a.omx = cx[0].om;
-  a.par_rows = L.transposed ? L.Cout : 0; a.par_map = par_map;
+  a.par_rows = parity_layer ? L.Cout : 0; a.par_map = par_map;
   a.TZ = TZ; a.TY = TY; a.TXT = TXT; a.TZI = TZI; a.TYI = TYI; a.TXI = TXI;
   a.magicX = TXI == 1 ? 0u : (unsigned)((0x100000000ull + TXI - 1) / TXI);
   a.magicY = TYI == 1 ? 0u : (unsigned)((0x100000000ull + TYI - 1) / TYI);

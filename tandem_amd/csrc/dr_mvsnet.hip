@@ -110,7 +110,7 @@ struct DevTensor {
 };
 
 struct Op {
-  enum Kind { PREPROCESS, CONV, SKIPUP, PROB, COSTVOL, REGRESS, EDGE, HIST, SCAN, APPLY } kind;
+  enum Kind { PREPROCESS, CONV, SKIPUP, PROB, COSTVOL, REGRESS, EDGE, HIST, SCAN, APPLY, BORDERFIX } kind;
   const float *p0 = nullptr, *p1 = nullptr, *p3 = nullptr, *p4 = nullptr;
   float *p2 = nullptr;
   int d0 = 0, d1 = 0, d2 = 0;
@@ -427,6 +427,7 @@ class MvsEngine {
       else if (o.kind == Op::REGRESS) snprintf(kn, sizeof kn, "k_regress");
       else if (o.kind == Op::PREPROCESS) snprintf(kn, sizeof kn, "k_preprocess");
       else if (o.kind == Op::SKIPUP) snprintf(kn, sizeof kn, "k_skip_up<%d>", o.stage);
+      else if (o.kind == Op::BORDERFIX) snprintf(kn, sizeof kn, "k_out3_border");
       else snprintf(kn, sizeof kn, "k_filter");
       char line[256];
       snprintf(line, sizeof line, "%s\t%s\t%.6e\t%.6e\n", o.name.c_str(), kn, o.flops, o.bytes);
@@ -563,14 +564,21 @@ class MvsEngine {
       P0.outD = transposed ? in.D * sd : cz[0].npos; P0.outH = transposed ? in.H * sh : cy[0].npos; P0.outW = transposed ? in.W * sw : cx[0].npos;
     }
     DevTensor &out = alloc(outname, P0.outD, P0.outH, P0.outW, c_out, out_pad);
+    emit_conv(opname, L, mode, in, out, add ? add->d : nullptr, add_mode, add ? (add_mode == 2 ? add->n() : out.n()) : 0, fz);
+    return out;
+  }
+  // Plans layer L (in -> out, both existing tensors) and appends its launch(es) to the op list.
+  void emit_conv(const std::string &opname, const ConvLayer &L, ConvMode mode, const DevTensor &in, DevTensor &out, const float *add_d, int add_mode,
+                 size_t add_n, const ConvFuse *fz = nullptr) {
+    const int k3d = L.kd, kh = L.kh, kw = L.kw;
     ConvFuse fzc{};
     if (fz) fzc = *fz;
     const bool fused = fz != nullptr;
-    ConvPlanOut P = plan_conv(L, mode, in.d, in.D, in.H, in.W, in.C, out.interior(), add ? add->d : nullptr, add_mode, *plan_arena_, 0, fz);
+    ConvPlanOut P = plan_conv(L, mode, in.d, in.D, in.H, in.W, in.C, out.interior(), add_d, add_mode, *plan_arena_, 0, fz);
     // the autotuner re-plans this layer with another candidate of the cost model's ranking (weights are kept alive)
     auto keep = std::make_shared<std::vector<float>>(L.weight, L.weight + (size_t)L.Cout * L.Cin * k3d * kh * kw);
     ConvLayer Lc = L;
-    const float *in_d = in.d, *add_d = add ? add->d : nullptr;
+    const float *in_d = in.d;
     float *out_d = out.interior();
     const int iD = in.D, iH = in.H, iW = in.W, iC = in.C, ncand = P.ncand;
     auto replan = [this, keep, Lc, mode, in_d, iD, iH, iW, iC, out_d, add_d, add_mode, fzc, fused](int rank) mutable {
@@ -583,16 +591,16 @@ class MvsEngine {
       if (P.launches.size() == 1) {
         o.replan = replan; o.ncand = ncand;
         char sig[160];
-        snprintf(sig, sizeof sig, "%d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d", L.Cin, L.Cout, k3d, kh, kw, sd, sh, sw, transposed ? 1 : 0, (int)mode + (fused ? 8 : 0), iD, iH, iW);
+        snprintf(sig, sizeof sig, "%d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d", L.Cin, L.Cout, k3d, kh, kw, L.sd, L.sh, L.sw, L.transposed ? 1 : (L.up2 ? 1 + L.up2 : 0),
+                 (int)mode + (fused ? 8 : 0), iD, iH, iW);
         o.sig = sig;
       }
       o.flops = cl.flops;
-      if (idx == 0) o.bytes = 4.0 * ((fused ? in.n() / in.C * fzc.cin + in.n() / 4 : in.n()) + out.n() + (add ? (add_mode == 2 ? add->n() : out.n()) : 0));
+      if (idx == 0) o.bytes = 4.0 * ((fused ? in.n() / in.C * fzc.cin + in.n() / 4 : in.n()) + out.n() + add_n);
       if (fused) o.flops += 2.0 * fzc.cin * in.C * (in.n() / in.C);
       ops_.push_back(o);
       ++idx;
     }
-    return out;
   }
   DevTensor &cbr2(const std::string &name, const std::string &p, const DevTensor &in, int k, int s, ConvMode m) {
     return add_conv(name, p + ".conv", p + ".bn", false, true, in, name, 1, k, k, 1, s, s, false, m, nullptr, 0);
@@ -656,6 +664,41 @@ class MvsEngine {
     // stage 3: skip.stage3 (1x1, 8 -> 32, + upsampled inter2) is computed inside out.stage3's staging step -- the
     // 32-channel full-resolution tensor between them (275 MB at 640x480x7) is never written or read.  DR_NO_SKIP_FUSION=1: the two-kernel path.
     const HostTensor &w3 = blob_.at(fn + "skip.stage3.weight");
+    const HostTensor &wo3 = blob_.at(fn + "out.stage3.weight");
+    // out.stage3 is linear in inter3 = up(inter2) + skip.stage3(c3) (no BatchNorm, no ReLU, no bias: module.py:480-485,524-529), so it
+    // is evaluated as   conv3x3(c3; Wout . Wskip)  +  conv3x3(up(inter2); Wout)  +  (Wout . bskip, corrected at the image border):
+    // an 8 -> 8 XPAIR layer at full resolution (composed weights), two 2 x 3-tap phase layers over inter2 at HALF resolution that
+    // add their rows in place (ConvLayer::up2: the upsampled tensor never exists), and a border kernel.  11.0 GFLOP become 6.9, the
+    // 275 MB inter3 and the skip staging disappear, and all three convolutions run on the persistent kernels (0.22 -> 0.13 ms).
+    // feat3 then differs from the literal order by fp32 reassociation (2e-6 of its range).  DR_OUT3_FOLDED=0: the fused-skip form.
+    const char *fold_env = getenv("DR_OUT3_FOLDED");
+    if ((!fold_env || atoi(fold_env) != 0) && !getenv("DR_NO_SKIP_FUSION") && !getenv("DR_SKIP_ON_CONV") && w3.dims[0] == 32 && w3.dims[1] == 8 && c3.C == 8 &&
+        i2.C == 32 && wo3.dims[0] == 8 && wo3.dims[1] == 32 && i2.H * 2 == c3.H && i2.W * 2 == c3.W) {
+      const std::vector<float> &b3 = blob_.at(fn + "skip.stage3.bias").data;
+      std::vector<float> wa((size_t)8 * 8 * 9), T(9 * 8), bint(8, 0.f);
+      for (int co = 0; co < 8; ++co)
+        for (int t = 0; t < 9; ++t) {
+          for (int c8 = 0; c8 < 8; ++c8) {
+            double acc = 0;
+            for (int c = 0; c < 32; ++c) acc += (double)wo3.data[((size_t)co * 32 + c) * 9 + t] * (double)w3.data[(size_t)c * 8 + c8];
+            wa[((size_t)co * 8 + c8) * 9 + t] = (float)acc;
+          }
+          double tb = 0;
+          for (int c = 0; c < 32; ++c) tb += (double)wo3.data[((size_t)co * 32 + c) * 9 + t] * (double)b3[c];
+          T[t * 8 + co] = (float)tb;
+        }
+      for (int co = 0; co < 8; ++co) { double b = 0; for (int t = 0; t < 9; ++t) b += (double)T[t * 8 + co]; bint[co] = (float)b; }
+      DevTensor &f3 = alloc("feat3", c3.D, c3.H, c3.W, 8, fpad);
+      ConvLayer LA; LA.Cin = 8; LA.Cout = 8; LA.kd = 1; LA.kh = 3; LA.kw = 3; LA.weight = wa.data(); LA.bias = bint; LA.out_pad = fpad;
+      emit_conv("fn.out3a", LA, CONV_XPAIR, c3, f3, nullptr, 0, 0);
+      for (int py = 0; py < 2; ++py) {
+        ConvLayer LB; LB.Cin = 32; LB.Cout = 8; LB.kd = 1; LB.kh = 3; LB.kw = 3; LB.weight = wo3.data.data(); LB.up2 = 1 + py; LB.out_pad = fpad;
+        emit_conv(py ? "fn.out3c" : "fn.out3b", LB, CONV_NORMAL, i2, f3, f3.interior(), 1, f3.n() / 2);
+      }
+      Op o; o.kind = Op::BORDERFIX; o.name = "fn.out3d"; o.p2 = f3.interior(); o.p1 = plan_arena_->upload(T); o.d0 = c3.D; o.d1 = c3.H; o.d2 = c3.W;
+      o.stage = fpad; o.bytes = 64.0 * c3.D * (c3.H + c3.W);
+      ops_.push_back(o);
+    } else
     if (!getenv("DR_NO_SKIP_FUSION") && !getenv("DR_SKIP_ON_CONV") && w3.dims[0] == 32 && w3.dims[1] == 8 && c3.C == 8 && i2.C == 32 &&
         i2.H * 2 == c3.H && i2.W * 2 == c3.W) {
       ConvFuse fz{c3.d, plan_arena_->upload(w3.data), plan_arena_->upload(blob_.at(fn + "skip.stage3.bias").data), i2.d, 8};
@@ -840,6 +883,12 @@ class MvsEngine {
           if (on_side && i - 1 == feat2_op_) DR_HIP(hipEventRecord(ev_feat2_, side_));
           if (on_side && i - 1 == fork_hi_ - 1) DR_HIP(hipEventRecord(ev_feat3_, side_));
           break;
+        case Op::BORDERFIX: {
+          const int per = 2 * (o.d1 + o.d2) - 4, n = o.d0 * per * 8;
+          const int rs = (o.d2 + 2 * o.stage) * 8;
+          hipLaunchKernelGGL(k_out3_border, dim3(cdiv(n, 256)), dim3(256), 0, stream_, o.p2, o.p1, o.d0, o.d1, o.d2, rs, (size_t)(o.d1 + 2 * o.stage) * rs);
+          break;
+        }
         case Op::SKIPUP: {
           const size_t npix = (size_t)o.d0 * o.d1 * o.d2;
           const dim3 grid((unsigned)std::min<size_t>((npix + 31) / 32, 8192));
@@ -1103,12 +1152,13 @@ int drm_debug_conv(int device, const float *in, int D, int H, int W, int Cin, co
     arena.err_flag = arena.upload(std::vector<int>(1, 0));
     ConvLayer L;
     L.Cin = Cin; L.Cout = Cout; L.kd = kd; L.kh = kh; L.kw = kw; L.sd = sd; L.sh = sh; L.sw = sw;
-    L.transposed = transposed != 0; L.weight = weight; L.relu = relu != 0;
+    L.transposed = transposed == 1; L.weight = weight; L.relu = relu != 0;
+    const bool up2 = transposed == 2;  // test hook for ConvLayer::up2: both row parities, one launch each
     if (scale) L.scale.assign(scale, scale + Cout);
     if (bias) L.bias.assign(bias, bias + Cout);
     const ConvMode mode = (!transposed && sw == 1 && Cout == 8) ? CONV_XPAIR : ((!transposed && sw == 1 && Cout == 1) ? CONV_X8 : CONV_NORMAL);
     auto cz = axis_classes(kd, sd, L.transposed, D), cy = axis_classes(kh, sh, L.transposed, H), cx = axis_classes(kw, sw, L.transposed, W);
-    const int oD = L.transposed ? D * sd : cz[0].npos, oH = L.transposed ? H * sh : cy[0].npos, oW = L.transposed ? W * sw : cx[0].npos;
+    const int oD = L.transposed ? D * sd : cz[0].npos, oH = L.transposed ? H * sh : (up2 ? 2 * H : cy[0].npos), oW = L.transposed ? W * sw : (up2 ? 2 * W : cx[0].npos);
     std::vector<float> hin(in, in + (size_t)D * H * W * Cin);
     float *d_in = arena.upload(hin);
     const size_t on = (size_t)oD * oH * oW * Cout;
@@ -1122,8 +1172,12 @@ int drm_debug_conv(int device, const float *in, int D, int H, int W, int Cin, co
     }
     // DR_CONV_RANK (test hook): build the rank-th candidate of the planner's ranking instead of its first choice
     const char *rk = getenv("DR_CONV_RANK");
-    ConvPlanOut P = plan_conv(L, mode, d_in, D, H, W, Cin, d_out, d_add, add_up2 ? 2 : 1, arena, rk ? atoi(rk) : 0);
-    for (auto &cl : P.launches) launch_conv(cl, nullptr);
+    ConvPlanOut P;
+    for (int py = 0; py < (up2 ? 2 : 1); ++py) {
+      L.up2 = up2 ? 1 + py : 0;
+      P = plan_conv(L, mode, d_in, D, H, W, Cin, d_out, d_add, add_up2 ? 2 : 1, arena, rk ? atoi(rk) : 0);
+      for (auto &cl : P.launches) launch_conv(cl, nullptr);
+    }
     DR_HIP(hipDeviceSynchronize());
     DR_HIP(hipGetLastError());
     int march_err = 0;

@@ -506,6 +506,33 @@ __global__ __launch_bounds__(256) void k_prob2(const float *__restrict__ x, cons
   }
 }
 
+// ------------------------------------------------------------------ folded out.stage3: border term
+// out.stage3(up(inter2) + skip3(c3)) is linear, so it is evaluated as conv3x3(c3; Wout . Wskip) + conv3x3(up(inter2); Wout) + B with
+// B[co] = sum over the 9 taps of T[tap][co], T[tap][co] = sum_c Wout[co][c][tap] * bskip[c].  B is exact for interior pixels; at the
+// image border the taps that fall outside see the ZERO padding of inter3, not the bias, so their T is taken out again here
+// (one lane per (border pixel, channel); 2 (H + W) - 4 pixels per view).
+__global__ __launch_bounds__(256) void k_out3_border(float *__restrict__ out, const float *__restrict__ T /*[9][8]*/, int V, int H, int W, int rowstride,
+                                                     size_t planestride) {
+  const int per = 2 * (H + W) - 4, n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= V * per * 8) return;
+  const int co = n & 7, b = (n >> 3) % per, v = (n >> 3) / per;
+  int y, x;
+  if (b < W) { y = 0; x = b; }
+  else if (b < 2 * W) { y = H - 1; x = b - W; }
+  else if (b < 2 * W + H - 2) { y = b - 2 * W + 1; x = 0; }
+  else { y = b - (2 * W + H - 2) + 1; x = W - 1; }
+  float corr = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int yy = y + ky - 1, xx = x + kx - 1;
+      if (yy < 0 || yy >= H || xx < 0 || xx >= W) corr += T[(ky * 3 + kx) * 8 + co];
+    }
+  float *p = out + (size_t)v * planestride + (size_t)y * rowstride + (size_t)x * 8 + co;
+  *p -= corr;
+}
+
 // ------------------------------------------------------------------ regression
 // expf whose result cannot be fused into its consumer: with -ffp-contract=fast hipcc folds the exponential's last multiply into
 // `sum += ...` where the value has a single use and cannot where it is reused, so two spellings of the same regression would

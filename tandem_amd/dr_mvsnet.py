@@ -172,15 +172,18 @@ class DrMvsnet:
 
 def debug_conv(x, weight, stride=(1, 1, 1), transposed=False, scale=None, bias=None, relu=False, add=None,
                add_up2=False, device=0):
-    """Kernel unit-test hook: x (D,H,W,Cin) channels-last, weight in torch layout; returns (Do,Ho,Wo,Cout)."""
+    """Kernel unit-test hook: x (D,H,W,Cin) channels-last, weight in torch layout; returns (Do,Ho,Wo,Cout).
+    transposed: False / True, or "up2": a 3x3 stride-1 layer over the nearest x2 upsampling (H, W) of x (ConvLayer::up2)."""
     x = np.ascontiguousarray(x, np.float32)
     w = np.ascontiguousarray(weight, np.float32)
     D, H, W, Cin = x.shape
-    Cout = w.shape[1] if transposed else w.shape[0]
+    up2 = transposed == "up2"
+    transposed = 2 if up2 else int(bool(transposed))
+    Cout = w.shape[1] if transposed == 1 else w.shape[0]
     kd, kh, kw = w.shape[2:]
     sd, sh, sw = stride
-    oD, oH, oW = ((D * sd, H * sh, W * sw) if transposed else
-                  ((D + 2 * (kd // 2) - kd) // sd + 1, (H + 2 * (kh // 2) - kh) // sh + 1, (W + 2 * (kw // 2) - kw) // sw + 1))
+    oD, oH, oW = ((D * sd, H * sh, W * sw) if transposed == 1 else ((D, 2 * H, 2 * W) if up2 else
+                  ((D + 2 * (kd // 2) - kd) // sd + 1, (H + 2 * (kh // 2) - kh) // sh + 1, (W + 2 * (kw // 2) - kw) // sw + 1)))
     out = np.empty((oD, oH, oW, Cout), np.float32)
     dims = (C.c_int * 3)()
     opt = lambda a: fptr(np.ascontiguousarray(a, np.float32)) if a is not None else None

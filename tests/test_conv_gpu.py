@@ -184,3 +184,32 @@ def test_transposed_parity_forms(case, form, monkeypatch):
     for rank in range(0, 60, 3):
         monkeypatch.setenv("DR_CONV_RANK", str(rank))
         run_case(case)
+
+
+# ---- ConvLayer::up2: a 3x3 layer over the nearest x2 upsampling of its (half-resolution) input, as 2 x 2-tap phase convolutions
+# with summed kernel entries (conv_mfma.h axis_classes_up2) -- the second half of the folded out.stage3 (FeatureNet).
+UP2 = [
+    ("up2 32->8", (2, 24, 40), 32, 8),
+    ("up2 32->8, 7 views", (7, 30, 80), 32, 8),
+    ("up2 16->16 ragged", (3, 11, 23), 16, 16),
+    ("up2 one row", (2, 1, 64), 32, 8),
+]
+
+
+@pytest.mark.parametrize("case", UP2, ids=[c[0] for c in UP2])
+def test_conv_over_upsampled_input(case, monkeypatch):
+    from tandem_amd.dr_mvsnet import debug_conv
+    name, dims, cin, cout = case
+    rng = np.random.RandomState(abs(hash(name)) % (2 ** 31))
+    x = rng.randn(*dims, cin).astype(np.float32)
+    w = (rng.randn(cout, cin, 1, 3, 3) / np.sqrt(cin * 9)).astype(np.float32)
+    bias = (0.2 * rng.randn(cout)).astype(np.float32)
+    add = rng.randn(dims[0], 2 * dims[1], 2 * dims[2], cout).astype(np.float32)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2)  # (D, C, h, w)
+    up = F.interpolate(xt, scale_factor=2, mode="nearest")
+    ref = F.conv2d(up, torch.from_numpy(w[:, :, 0]), torch.from_numpy(bias), 1, 1).permute(0, 2, 3, 1).numpy() + add
+    for rank in range(0, 40, 3):
+        monkeypatch.setenv("DR_CONV_RANK", str(rank))
+        got = debug_conv(x, w, (1, 1, 1), "up2", None, bias, False, add, False)
+        err = np.abs(got - ref).max()
+        assert got.shape == ref.shape and err <= 2e-5 * max(1.0, np.abs(ref).max()), f"{name} rank {rank}: max|err| {err:.3e}"

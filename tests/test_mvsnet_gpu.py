@@ -291,6 +291,7 @@ def test_fused_skip_equals_the_two_kernel_path(trained_blob, monkeypatch):
     bit-for-bit what k_skip_up followed by the plain convolution gives (a second shape with partial tiles)."""
     from synth import scene
     from tandem_amd.dr_mvsnet import DrMvsnet
+    monkeypatch.setenv("DR_OUT3_FOLDED", "0")  # (the default since round 3 is the folded form, tested below)
     outs = []
     for unfused in (False, True):
         if unfused:
@@ -314,6 +315,7 @@ def test_fused_skip_on_the_marching_kernel(trained_blob, monkeypatch):
     feat3 agrees to fp32 reassociation at most (tolerance 2e-5 of the tensor's range; observed: bit-identical)."""
     from synth import scene
     from tandem_amd.dr_mvsnet import DrMvsnet
+    monkeypatch.setenv("DR_OUT3_FOLDED", "0")
     feats = []
     for env in ({"DR_CONV_MARCH": "2", "DR_CONV_NO_TUNED": "1"}, {"DR_FZ_NO_MARCH": "1", "DR_CONV_NO_TUNED": "1"}):
         for k, v in env.items():
@@ -370,3 +372,32 @@ def test_register_regression_equals_the_three_pass_kernel(trained_blob, tmp_path
             print("regress A/B:", os.path.basename(blob), "max rel depth diff %.3e, conf diff > 1e-5 at %.2e of pixels, max %.3e" % (dd.max(), (dc > 1e-5).mean(), dc.max()))
             assert np.array_equal(a.depth_dense, b.depth_dense) and np.array_equal(a.confidence_dense, b.confidence_dense)
             assert np.array_equal(a.depth, b.depth) and np.array_equal(a.confidence, b.confidence)
+
+
+def test_folded_out_stage3_equals_the_literal_order(trained_blob, monkeypatch):
+    """Round 3's default for FeatureNet's stage-3 head: out.stage3(up(inter2) + skip.stage3(c3)) evaluated as conv3x3(c3; Wout.Wskip)
+    + conv3x3 over the upsampled inter2 at half resolution (ConvLayer::up2) + a border-corrected bias, against the fused-skip form
+    that follows the reference's order (module.py:524-529).  Linear algebra only, so feat3 agrees to fp32 reassociation:
+    2e-5 of its range, everywhere incl. the image border and partial tiles; the depth maps agree within the pipeline's tolerance."""
+    from synth import scene
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    res = []
+    for folded in ("1", "0"):
+        monkeypatch.setenv("DR_OUT3_FOLDED", folded)
+        m = DrMvsnet(trained_blob)
+        out = []
+        for (h, w, v) in ((96, 160, 4), (224, 352, 3), (64, 96, 2)):
+            win = scene.make_window(h, w, v, seed=6)
+            m.upload(h, w, v, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), 0.5, 5.0, 2.5)
+            m.forward(1)
+            ops = [r["op"] for r in m.profile()]
+            out.append((m.tensor("feat3").copy(), m.download().depth_dense.copy(), ops))
+        res.append(out)
+        m.close()
+    for (fa, da, oa), (fb, db, ob) in zip(*res):
+        assert "fn.out3a" in oa and "fn.out3d" in oa and "fn.out3" in ob, (oa, ob)
+        scale = np.abs(fb).max()
+        assert np.abs(fa - fb).max() <= 2e-5 * scale, np.abs(fa - fb).max() / scale
+        for sl in (np.s_[:, 0], np.s_[:, -1], np.s_[:, :, 0], np.s_[:, :, -1]):  # the four image borders
+            assert np.abs(fa[sl] - fb[sl]).max() <= 2e-5 * scale
+        assert np.abs(da - db).mean() < 1e-4 and np.abs(da - db).max() < 5e-2
