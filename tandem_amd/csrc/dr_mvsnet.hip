@@ -422,7 +422,7 @@ class MvsEngine {
       if (o.kind == Op::CONV && o.conv.async == 2) snprintf(kn, sizeof kn, "k_conv_m<%d,%d,%d,%d,%d,%d>", o.conv.ci, o.conv.nup, o.conv.ct, o.conv.pt, o.conv.fz, o.conv.ncw);  // rocprofv3's spelling of the instance
       else if (o.kind == Op::CONV && o.conv.async) snprintf(kn, sizeof kn, "k_conv_a<%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt);
       else if (o.kind == Op::CONV) snprintf(kn, sizeof kn, "k_conv<%d,%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt, o.conv.fz);
-      else if (o.kind == Op::COSTVOL) snprintf(kn, sizeof kn, costvol_v1_ ? "k_costvol<%d>" : "k_costvol2<%d>", 32 >> (o.stage - 1));
+      else if (o.kind == Op::COSTVOL) snprintf(kn, sizeof kn, costvol_v1_ ? "k_costvol<%d>" : (costvol_v2_ ? "k_costvol2<%d>" : "k_costvol3<%d>"), 32 >> (o.stage - 1));
       else if (o.kind == Op::PROB) snprintf(kn, sizeof kn, getenv("DR_PROB_V1") ? "k_prob" : "k_prob2");
       else if (o.kind == Op::REGRESS) snprintf(kn, sizeof kn, "k_regress");
       else if (o.kind == Op::PREPROCESS) snprintf(kn, sizeof kn, "k_preprocess");
@@ -938,7 +938,12 @@ class MvsEngine {
           if (a.fpad) {  // bordered feature maps: 4 channels per lane, no per-tap validity logic
             b.gx = cdiv(a.w, 1024 / C); b.nwg = b.gx * b.gz * a.h;
             grid = dim3(8 * cdiv(b.nwg, 8));
-            if (C == 32) hipLaunchKernelGGL((k_costvol2<32>), grid, dim3(256), 0, stream_, b);
+            // k_costvol3 (the lanes of a pixel share the per-sample set-up) needs whole batches of 4 iterations per depth chunk
+            const bool v3 = !costvol_v2_ && a.dchunk % 4 == 0 && a.planes.D % 4 == 0;
+            if (v3 && C == 32) hipLaunchKernelGGL((k_costvol3<32>), grid, dim3(256), 0, stream_, b);
+            else if (v3 && C == 16) hipLaunchKernelGGL((k_costvol3<16>), grid, dim3(256), 0, stream_, b);
+            else if (v3) hipLaunchKernelGGL((k_costvol3<8>), grid, dim3(256), 0, stream_, b);
+            else if (C == 32) hipLaunchKernelGGL((k_costvol2<32>), grid, dim3(256), 0, stream_, b);
             else if (C == 16) hipLaunchKernelGGL((k_costvol2<16>), grid, dim3(256), 0, stream_, b);
             else hipLaunchKernelGGL((k_costvol2<8>), grid, dim3(256), 0, stream_, b);
           } else
@@ -1005,6 +1010,7 @@ class MvsEngine {
   bool side_enabled_ = true;
   // channels per lane of k_costvol for C >= 16 (measured: stage 2 0.210 -> 0.194 ms, stage 1 0.146 -> 0.143 ms with 4)
   bool costvol_v1_ = getenv("DR_COSTVOL_V1") != nullptr;
+  bool costvol_v2_ = getenv("DR_COSTVOL_V2") != nullptr;  // k_costvol2 instead of k_costvol3 (A/B and parity hook)
   bool regress_generic_ = getenv("DR_REGRESS_GENERIC") != nullptr;
   int hist_blocks_ = getenv("DR_HIST_BLOCKS") ? std::max(1, atoi(getenv("DR_HIST_BLOCKS"))) : 128;  // workgroups of a histogram level (each flushes its bins with atomics on a few hot addresses)
   int cpl_wide_ = getenv("DR_COSTVOL_CPL") ? (atoi(getenv("DR_COSTVOL_CPL")) == 8 ? 8 : 4) : 4;

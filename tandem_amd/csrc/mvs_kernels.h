@@ -111,6 +111,12 @@ __device__ inline PixelPlanes make_planes(const PlaneArgs &p, int y, int x) {
   return r;
 }
 
+// The hypothesis of plane k spelled with an explicit fused multiply-add (PixelPlanes::at leaves the contraction to the compiler, which
+// decides differently from one kernel to the next: kernels that must agree bit for bit use this form).
+__device__ inline float plane_depth(const PixelPlanes &pp, const PlaneArgs &p, int k) {
+  return pp.uniform ? __builtin_fmaf(p.interval, (float)k, p.dmin) : __builtin_fmaf(pp.rng, (float)k * pp.invD, pp.lo);
+}
+
 // ------------------------------------------------------------------ cost volume
 struct CostVolArgs {
   const float *feat;  // (V,h,w,C) channels-last, view 0 = reference
@@ -268,6 +274,34 @@ __device__ inline float cv_dpp_add(float s, int ctrl) {  // s + s[dpp permutatio
   if (ctrl == 1) return s + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
   return s + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0x141, 0xF, 0xF, true));                // row_half_mirror: lane i <-> 7 - i
 }
+// The arithmetic of one (plane, view) sample, shared by k_costvol2 and k_costvol3 with every multiply-add spelled out: the two
+// kernels then agree bit for bit whatever the compiler would have contracted in either context.
+struct CvProj { int o; float w00, w01, w10, w11; };
+__device__ __forceinline__ CvProj cv_project(const float *m, float depth, float xf, float yf, float fw, float fh, int wp, int C) {
+  const float rx = __builtin_fmaf(m[0], xf, __builtin_fmaf(m[1], yf, m[2])), ry = __builtin_fmaf(m[4], xf, __builtin_fmaf(m[5], yf, m[6])),
+              rz = __builtin_fmaf(m[8], xf, __builtin_fmaf(m[9], yf, m[10]));
+  const float px = __builtin_fmaf(rx, depth, m[3]), py = __builtin_fmaf(ry, depth, m[7]), pz = __builtin_fmaf(rz, depth, m[11]);
+  const float rcp = __builtin_amdgcn_rcpf(pz);
+  const float u = px * rcp, vv = py * rcp;
+  const bool inside = pz >= 0.001f && u > -1.f && u < fw && vv > -1.f && vv < fh;  // module.py:861,887; NaN fails too
+  const float uc = inside ? u : -1.f, vc = inside ? vv : -1.f;
+  const float fx0 = floorf(uc), fy0 = floorf(vc);
+  const float ax = uc - fx0, ay = vc - fy0, bx = 1.f - ax, by = 1.f - ay;
+  CvProj r;
+  r.w00 = bx * by; r.w01 = ax * by; r.w10 = bx * ay; r.w11 = ax * ay;
+  r.o = ((int)fy0 * wp + (int)fx0) * C;
+  return r;
+}
+__device__ __forceinline__ float cv_tap4(float t00, float t01, float t10, float t11, const CvTaps &T) {
+  return __builtin_fmaf(t11, T.w11, __builtin_fmaf(t10, T.w10, __builtin_fmaf(t01, T.w01, t00 * T.w00)));
+}
+__device__ __forceinline__ float4 cv_warp(const CvTaps &T) {
+  return make_float4(cv_tap4(T.t00.x, T.t01.x, T.t10.x, T.t11.x, T), cv_tap4(T.t00.y, T.t01.y, T.t10.y, T.t11.y, T),
+                     cv_tap4(T.t00.z, T.t01.z, T.t10.z, T.t11.z, T), cv_tap4(T.t00.w, T.t01.w, T.t10.w, T.t11.w, T));
+}
+__device__ __forceinline__ float cv_gate_dot(const float4 &gw, const float4 &d2) {
+  return __builtin_fmaf(gw.w, d2.w, __builtin_fmaf(gw.z, d2.z, __builtin_fmaf(gw.y, d2.y, gw.x * d2.x)));
+}
 template <int C>
 __global__ __launch_bounds__(256) void k_costvol2(const CostVolArgs a) {
   constexpr int LPV = C / 4;            // lanes per pixel, 4 channels each
@@ -293,18 +327,9 @@ __global__ __launch_bounds__(256) void k_costvol2(const CostVolArgs a) {
   const float *f00 = a.feat + ((size_t)wp + 1) * C + q * 4;  // pixel (0, 0) of view 0, this lane's channels
 
   auto issue = [&](int d, int v, CvTaps &T) {
-    const float *m = a.M[v];  // wave-uniform: scalar loads
-    const float depth = pp.at(a.planes, d);
-    const float rx = m[0] * xf + m[1] * yf + m[2], ry = m[4] * xf + m[5] * yf + m[6], rz = m[8] * xf + m[9] * yf + m[10];
-    const float px = rx * depth + m[3], py = ry * depth + m[7], pz = rz * depth + m[11];
-    const float rcp = __builtin_amdgcn_rcpf(pz);
-    const float u = px * rcp, vv = py * rcp;
-    const bool inside = pz >= 0.001f && u > -1.f && u < fw && vv > -1.f && vv < fh;  // module.py:861,887; NaN fails too
-    const float uc = inside ? u : -1.f, vc = inside ? vv : -1.f;
-    const float fx0 = floorf(uc), fy0 = floorf(vc);
-    const float ax = uc - fx0, ay = vc - fy0, bx = 1.f - ax, by = 1.f - ay;
-    T.w00 = bx * by; T.w01 = ax * by; T.w10 = bx * ay; T.w11 = ax * ay;
-    const int o = ((int)fy0 * wp + (int)fx0) * C;
+    const CvProj P = cv_project(a.M[v] /* wave-uniform: scalar loads */, plane_depth(pp, a.planes, d), xf, yf, fw, fh, wp, C);
+    T.w00 = P.w00; T.w01 = P.w01; T.w10 = P.w10; T.w11 = P.w11;
+    const int o = P.o;
     const float *r0 = f00 + (size_t)(v + 1) * vplane, *r1 = r0 + (size_t)wp * C;  // wave-uniform bases: rows y0 and y0 + 1
     T.t00 = ld4(r0 + o); T.t01 = ld4(r0 + o + C); T.t10 = ld4(r1 + o); T.t11 = ld4(r1 + o + C);
   };
@@ -314,31 +339,26 @@ __global__ __launch_bounds__(256) void k_costvol2(const CostVolArgs a) {
       acc = a.view_aggregation ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(ref.x * ref.x, ref.y * ref.y, ref.z * ref.z, ref.w * ref.w);
       s1 = ref;
     }
-    float4 wv;
-    wv.x = T.t00.x * T.w00 + T.t01.x * T.w01 + T.t10.x * T.w10 + T.t11.x * T.w11;
-    wv.y = T.t00.y * T.w00 + T.t01.y * T.w01 + T.t10.y * T.w10 + T.t11.y * T.w11;
-    wv.z = T.t00.z * T.w00 + T.t01.z * T.w01 + T.t10.z * T.w10 + T.t11.z * T.w11;
-    wv.w = T.t00.w * T.w00 + T.t01.w * T.w01 + T.t10.w * T.w10 + T.t11.w * T.w11;
+    const float4 wv = cv_warp(T);
     if (a.view_aggregation) {
       const float4 df = make_float4(wv.x - ref.x, wv.y - ref.y, wv.z - ref.z, wv.w - ref.w);
       const float4 d2 = make_float4(df.x * df.x, df.y * df.y, df.z * df.z, df.w * df.w);
-      float s = 0.f;
-      s += gw.x * d2.x + gw.y * d2.y + gw.z * d2.z + gw.w * d2.w;
+      float s = cv_gate_dot(gw, d2);
       if constexpr (LPV >= 2) s = cv_dpp_add(s, 0);
       if constexpr (LPV >= 4) s = cv_dpp_add(s, 1);
       if constexpr (LPV >= 8) s = cv_dpp_add(s, 2);
-      const float g1 = fmaxf(a.gA1 * s + a.gB1, 0.f);
-      const float g = fmaxf(a.gA2 * g1 + a.gB2, 0.f) + 1.f;
-      acc.x += g * d2.x; acc.y += g * d2.y; acc.z += g * d2.z; acc.w += g * d2.w;
+      const float g1 = fmaxf(__builtin_fmaf(a.gA1, s, a.gB1), 0.f);
+      const float g = fmaxf(__builtin_fmaf(a.gA2, g1, a.gB2), 0.f) + 1.f;
+      acc.x = __builtin_fmaf(g, d2.x, acc.x); acc.y = __builtin_fmaf(g, d2.y, acc.y); acc.z = __builtin_fmaf(g, d2.z, acc.z); acc.w = __builtin_fmaf(g, d2.w, acc.w);
     } else {  // plain variance incl. the reference view (module.py:1074-1075,1094-1096,1110)
       s1.x += wv.x; s1.y += wv.y; s1.z += wv.z; s1.w += wv.w;
-      acc.x += wv.x * wv.x; acc.y += wv.y * wv.y; acc.z += wv.z * wv.z; acc.w += wv.w * wv.w;
+      acc.x = __builtin_fmaf(wv.x, wv.x, acc.x); acc.y = __builtin_fmaf(wv.y, wv.y, acc.y); acc.z = __builtin_fmaf(wv.z, wv.z, acc.z); acc.w = __builtin_fmaf(wv.w, wv.w, acc.w);
     }
     if (v == nsrc - 1) {
       float4 o4 = make_float4(acc.x * rcp_n, acc.y * rcp_n, acc.z * rcp_n, acc.w * rcp_n);
       if (!a.view_aggregation) {
         const float4 mu = make_float4(s1.x * rcp_n, s1.y * rcp_n, s1.z * rcp_n, s1.w * rcp_n);
-        o4 = make_float4(o4.x - mu.x * mu.x, o4.y - mu.y * mu.y, o4.z - mu.z * mu.z, o4.w - mu.w * mu.w);
+        o4 = make_float4(__builtin_fmaf(-mu.x, mu.x, o4.x), __builtin_fmaf(-mu.y, mu.y, o4.y), __builtin_fmaf(-mu.z, mu.z, o4.z), __builtin_fmaf(-mu.w, mu.w, o4.w));
       }
       if (live) *reinterpret_cast<float4 *>(a.vol + ((size_t)d * h * w + (size_t)y * w + x) * C + q * 4) = o4;
     }
@@ -360,6 +380,122 @@ __global__ __launch_bounds__(256) void k_costvol2(const CostVolArgs a) {
     issue(dn, vn, A);
     consume(d, v, B);
     d = dn; v = vn;
+  }
+}
+
+// k_costvol3: k_costvol2 with the per-sample set-up SHARED by the lanes of a pixel.  In k_costvol2 the C / 4 lanes that hold a
+// pixel's channels all compute the same homography, inside test, bilinear weights and tap offset for every (plane, view) --
+// 45 of the ~95 vector instructions of an iteration, and vector-ALU issue is what bounds the kernel (87 M wave-instructions
+// at stage 2 = 0.14 of its 0.16 ms).  Here the lanes of a pixel take DIFFERENT iterations: lane q sets up iteration
+// base + (q mod LPB) of a batch of LPB = 4 (2 for C = 8) consecutive iterations, and the five results (tap offset, four
+// weights) reach the other lanes through DPP quad permutations when their iteration comes up.  Per iteration the set-up is
+// then 45 / LPB + 5 instructions.  Products, sums and their order are k_costvol2's: the volume is bit-identical.
+// Requires (d1 - d0) * nsrc to be a multiple of LPB for every depth chunk (dchunk and D multiples of 4: the host checks).
+__device__ __forceinline__ int cv_bcast_i(int x, int lpb, int j) {  // value of lane j of this lane's pixel group (lpb = 4: the quad; 2: the pair)
+  if (lpb == 4) {
+    switch (j) {
+      case 0: return __builtin_amdgcn_mov_dpp(x, 0x00, 0xF, 0xF, true);
+      case 1: return __builtin_amdgcn_mov_dpp(x, 0x55, 0xF, 0xF, true);
+      case 2: return __builtin_amdgcn_mov_dpp(x, 0xAA, 0xF, 0xF, true);
+      default: return __builtin_amdgcn_mov_dpp(x, 0xFF, 0xF, 0xF, true);
+    }
+  }
+  return j == 0 ? __builtin_amdgcn_mov_dpp(x, 0xA0, 0xF, 0xF, true) : __builtin_amdgcn_mov_dpp(x, 0xF5, 0xF, 0xF, true);  // [0,0,2,2] / [1,1,3,3]
+}
+__device__ __forceinline__ float cv_bcast_f(float x, int lpb, int j) { return __builtin_bit_cast(float, cv_bcast_i(__builtin_bit_cast(int, x), lpb, j)); }
+
+template <int C>
+__global__ __launch_bounds__(256) void k_costvol3(const CostVolArgs a) {
+  constexpr int LPV = C / 4;            // lanes per pixel, 4 channels each
+  constexpr int PXB = 256 / LPV;        // pixels per block
+  constexpr int LPB = LPV >= 4 ? 4 : 2; // iterations per batch = lanes of a pixel (within one quad) that share their set-up
+  __shared__ float sM[kMaxSrc * 12];    // the views' matrices: a lane needs the one of ITS iteration's view (not wave-uniform any more)
+  const int tid = threadIdx.x, q = tid % LPV, qb = q & (LPB - 1);
+  for (int i = tid; i < kMaxSrc * 12; i += 256) sM[i] = a.M[i / 12][i % 12];
+  __syncthreads();
+  const int per = (a.nwg + 7) >> 3;     // XCD-aware order, as k_costvol
+  const int nid = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+  if (nid >= a.nwg) return;
+  const int bz = nid % a.gz, bxy = nid / a.gz;
+  const int x = (bxy % a.gx) * PXB + tid / LPV, y = bxy / a.gx;
+  const int d0 = bz * a.dchunk, d1 = min(a.planes.D, d0 + a.dchunk);
+  const bool live = x < a.w;
+  const int xc = live ? x : a.w - 1;    // dead lanes keep running for the cross-lane gate sum
+  const int h = a.h, w = a.w, nsrc = a.V - 1, wp = w + 2;
+  const size_t vplane = (size_t)(h + 2) * wp * C;  // floats per padded view
+  const float fw = (float)w, fh = (float)h, xf = (float)xc, yf = (float)y;
+
+  const float4 ref = ld4(a.feat + ((size_t)(y + 1) * wp + xc + 1) * C + q * 4);
+  const float4 gw = make_float4(a.gw[q * 4], a.gw[q * 4 + 1], a.gw[q * 4 + 2], a.gw[q * 4 + 3]);
+  const PixelPlanes pp = make_planes(a.planes, y, xc);
+  const float inv_n = a.view_aggregation ? a.nsrc_f : a.nsrc_f + 1.f;
+  const float rcp_n = 1.f / inv_n;
+  const float *f00 = a.feat + ((size_t)wp + 1) * C + q * 4;  // pixel (0, 0) of view 0, this lane's channels
+
+  auto project = [&](int d, int v) {  // k_costvol2's `issue` up to the tap offset and weights, for this lane's own (plane, view)
+    return cv_project(sM + 12 * v, plane_depth(pp, a.planes, d), xf, yf, fw, fh, wp, C);
+  };
+  auto gather = [&](const CvProj &P, int j, int v, CvTaps &T) {  // iteration j of the batch: lane j's set-up, view v (uniform)
+    const int o = cv_bcast_i(P.o, LPB, j);
+    T.w00 = cv_bcast_f(P.w00, LPB, j); T.w01 = cv_bcast_f(P.w01, LPB, j); T.w10 = cv_bcast_f(P.w10, LPB, j); T.w11 = cv_bcast_f(P.w11, LPB, j);
+    const float *r0 = f00 + (size_t)(v + 1) * vplane, *r1 = r0 + (size_t)wp * C;  // wave-uniform bases: rows y0 and y0 + 1
+    T.t00 = ld4(r0 + o); T.t01 = ld4(r0 + o + C); T.t10 = ld4(r1 + o); T.t11 = ld4(r1 + o + C);
+  };
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), s1 = acc;
+  auto consume = [&](int d, int v, const CvTaps &T) {
+    if (v == 0) {
+      acc = a.view_aggregation ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(ref.x * ref.x, ref.y * ref.y, ref.z * ref.z, ref.w * ref.w);
+      s1 = ref;
+    }
+    const float4 wv = cv_warp(T);
+    if (a.view_aggregation) {
+      const float4 df = make_float4(wv.x - ref.x, wv.y - ref.y, wv.z - ref.z, wv.w - ref.w);
+      const float4 d2 = make_float4(df.x * df.x, df.y * df.y, df.z * df.z, df.w * df.w);
+      float s = cv_gate_dot(gw, d2);
+      if constexpr (LPV >= 2) s = cv_dpp_add(s, 0);
+      if constexpr (LPV >= 4) s = cv_dpp_add(s, 1);
+      if constexpr (LPV >= 8) s = cv_dpp_add(s, 2);
+      const float g1 = fmaxf(__builtin_fmaf(a.gA1, s, a.gB1), 0.f);
+      const float g = fmaxf(__builtin_fmaf(a.gA2, g1, a.gB2), 0.f) + 1.f;
+      acc.x = __builtin_fmaf(g, d2.x, acc.x); acc.y = __builtin_fmaf(g, d2.y, acc.y); acc.z = __builtin_fmaf(g, d2.z, acc.z); acc.w = __builtin_fmaf(g, d2.w, acc.w);
+    } else {  // plain variance incl. the reference view (module.py:1074-1075,1094-1096,1110)
+      s1.x += wv.x; s1.y += wv.y; s1.z += wv.z; s1.w += wv.w;
+      acc.x = __builtin_fmaf(wv.x, wv.x, acc.x); acc.y = __builtin_fmaf(wv.y, wv.y, acc.y); acc.z = __builtin_fmaf(wv.z, wv.z, acc.z); acc.w = __builtin_fmaf(wv.w, wv.w, acc.w);
+    }
+    if (v == nsrc - 1) {
+      float4 o4 = make_float4(acc.x * rcp_n, acc.y * rcp_n, acc.z * rcp_n, acc.w * rcp_n);
+      if (!a.view_aggregation) {
+        const float4 mu = make_float4(s1.x * rcp_n, s1.y * rcp_n, s1.z * rcp_n, s1.w * rcp_n);
+        o4 = make_float4(__builtin_fmaf(-mu.x, mu.x, o4.x), __builtin_fmaf(-mu.y, mu.y, o4.y), __builtin_fmaf(-mu.z, mu.z, o4.z), __builtin_fmaf(-mu.w, mu.w, o4.w));
+      }
+      if (live) *reinterpret_cast<float4 *>(a.vol + ((size_t)d * h * w + (size_t)y * w + x) * C + q * 4) = o4;
+    }
+  };
+  const int n = (d1 - d0) * nsrc;  // a multiple of LPB (host)
+  if (n <= 0) return;
+  // this lane's own iteration of the current batch, advanced by LPB per batch
+  int dq = d0, vq = qb;
+  while (vq >= nsrc) { vq -= nsrc; ++dq; }
+  auto advance_own = [&]() { vq += LPB; while (vq >= nsrc) { vq -= nsrc; ++dq; } };
+  CvProj P = project(dq, vq);
+  advance_own();
+  CvTaps TA, TB;
+  int d = d0, v = 0;        // the iteration being consumed (uniform)
+  int vn = 0;               // view of the iteration whose taps are being gathered (uniform), one ahead of v
+  gather(P, 0, vn, TA);
+  for (int base = 0; base < n; base += LPB) {
+    const CvProj Pn = project(dq, vq);  // the next batch's set-up (past the end in the last batch: a harmless extra sample)
+    advance_own();
+#pragma unroll
+    for (int j = 0; j < LPB; ++j) {
+      if (++vn == nsrc) vn = 0;
+      CvTaps &cur = (j & 1) ? TB : TA, &nxt = (j & 1) ? TA : TB;
+      if (j + 1 < LPB) gather(P, j + 1, vn, nxt);
+      else gather(Pn, 0, vn, nxt);  // LPB is even: iteration 0 of a batch always lands in TA
+      consume(d, v, cur);
+      if (++v == nsrc) { v = 0; ++d; }
+    }
+    P = Pn;
   }
 }
 
@@ -543,11 +679,7 @@ __device__ inline float expf_value(float x) {
   asm volatile("" : "+v"(r));
   return r;
 }
-// The hypothesis of plane k and the two running sums, spelled with explicit fused multiply-adds: left to -ffp-contract=fast, hipcc
-// contracts the unrolled register kernel and the looping kernel differently (1 ulp in 1 % of the stage-2 pixels).
-__device__ inline float regress_plane(const PixelPlanes &pp, const PlaneArgs &p, int k) {
-  return pp.uniform ? __builtin_fmaf(p.interval, (float)k, p.dmin) : __builtin_fmaf(pp.rng, (float)k * pp.invD, pp.lo);
-}
+// (plane depth and the two running sums are spelled with explicit fused multiply-adds, see plane_depth)
 struct RegressArgs {
   const float *logits;  // (D,h,w)
   float *depth, *conf;  // (h,w)
@@ -567,7 +699,7 @@ __global__ __launch_bounds__(256) void k_regress(const RegressArgs a) {
   float dep = 0.f, ek = 0.f;
   for (int k = 0; k < D; ++k) {
     const float p = expf_value(a.logits[(size_t)k * hw + n] - mx) / sum;
-    dep = __builtin_fmaf(p, regress_plane(pp, a.planes, k), dep);
+    dep = __builtin_fmaf(p, plane_depth(pp, a.planes, k), dep);
     ek = __builtin_fmaf(p, (float)k, ek);
   }
   int idx = (int)ek;  // .long() truncation, module.py:1131
@@ -603,7 +735,7 @@ __global__ __launch_bounds__(256) void k_regress_r(const RegressArgs a) {
 #pragma unroll
   for (int k = 0; k < D; ++k) {
     const float p = v[k] / sum;
-    dep = __builtin_fmaf(p, regress_plane(pp, a.planes, k), dep);
+    dep = __builtin_fmaf(p, plane_depth(pp, a.planes, k), dep);
     ek = __builtin_fmaf(p, (float)k, ek);
   }
   int idx = (int)ek;  // .long() truncation, module.py:1131

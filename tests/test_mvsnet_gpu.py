@@ -401,3 +401,38 @@ def test_folded_out_stage3_equals_the_literal_order(trained_blob, monkeypatch):
         for sl in (np.s_[:, 0], np.s_[:, -1], np.s_[:, :, 0], np.s_[:, :, -1]):  # the four image borders
             assert np.abs(fa[sl] - fb[sl]).max() <= 2e-5 * scale
         assert np.abs(da - db).mean() < 1e-4 and np.abs(da - db).max() < 5e-2
+
+
+@pytest.mark.parametrize("views", [2, 3, 4, 6, 7])
+def test_shared_setup_cost_volume_is_bit_identical(trained_blob, tmp_path, monkeypatch, views):
+    """k_costvol3 (the lanes of a pixel take different (plane, view) samples of a batch, set them up once and hand the tap offset
+    and weights round by DPP) against k_costvol2 (every lane sets up every sample): same products in the same order, so the
+    three cost volumes are equal bit for bit -- 1 to 6 source views (batches that straddle planes), view aggregation and plain
+    variance, two shapes (partial pixel blocks)."""
+    from synth import scene
+    from tandem_amd import weights as Wt
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    meta, tens = Wt.read_blob(trained_blob)
+    plain = str(tmp_path / "plain.tdmw")
+    Wt.write_blob(plain, {k: v for k, v in tens.items() if not k.startswith("volume_gates.")}, depth_num=(16, 8, 4), view_aggregation=False)
+    for blob in (trained_blob, plain):
+        vols = []
+        for old in (False, True):
+            if old:
+                monkeypatch.setenv("DR_COSTVOL_V2", "1")
+            m = DrMvsnet(blob)
+            res = []
+            for (h, w) in ((96, 160), (64, 224)):
+                win = scene.make_window(h, w, views, seed=11)
+                m.upload(h, w, views, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), 0.5, 5.0, 2.5)
+                m.forward(1)
+                kern = {r["op"]: r["kernel"] for r in m.profile()}
+                res.append(([m.tensor("volume%d" % s).copy() for s in (1, 2, 3)], kern["s2.costvol"]))
+            vols.append(res)
+            m.close()
+            if old:
+                monkeypatch.delenv("DR_COSTVOL_V2")
+        for (va, ka), (vb, kb) in zip(*vols):
+            assert ka.startswith("k_costvol3") and kb.startswith("k_costvol2"), (ka, kb)
+            for a, b in zip(va, vb):
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), np.abs(a - b).max()
