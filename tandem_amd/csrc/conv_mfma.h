@@ -211,8 +211,16 @@ __device__ inline unsigned conv_a_lds_addr(const void *p) {
   return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char *)p;
 }
 
+// Four waves per SIMD (128 VGPRs) for the one-row-tile instances without the fused skip: they need 129-135 registers when left alone,
+// i.e. three workgroups per CU instead of four, and the layers they run (transposed, strided, coarse: a few microseconds of
+// work per workgroup between three memory round trips) are bound by exactly that occupancy.  DR_CONV_WAVES3 = the old bound (A/B build).
+#ifdef DR_CONV_WAVES3
+#define DR_KCONV_MIN_WAVES(CT, FZ) 1
+#else
+#define DR_KCONV_MIN_WAVES(CT, FZ) ((CT) == 1 && (FZ) == 0 ? 4 : 1)
+#endif
 template <int CI, int CT, int PT, int FZ = 0>
-__global__ __launch_bounds__(kConvThreads) void k_conv(const ConvArgs a) {
+__global__ __launch_bounds__(kConvThreads, DR_KCONV_MIN_WAVES(CT, FZ)) void k_conv(const ConvArgs a) {
   extern __shared__ float4 lds4[];
   float *lds = reinterpret_cast<float *>(lds4);
   constexpr int CIS = CI + 4;  // LDS floats per staged position (+4: spreads b128 reads over bank slots)

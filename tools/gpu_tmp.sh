@@ -1,5 +1,10 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests/test_mvsnet_gpu.py -q --no-header -p no:cacheprovider -m gpu --maxfail=5 -k "shared_setup or golden or full_size" > gpurun_out/r3q_mvs.log 2>&1; grep -E "passed|failed|^FAILED|^ERROR|Error" gpurun_out/r3q_mvs.log | tail -8
-for v in 3 2 3 2; do E=""; [ $v = 2 ] && E="DR_COSTVOL_V2=1"; echo "--- costvol$v $(env $E DR_MVS_NO_SIDE_STREAM=1 timeout 300 python tools/profile_ops.py 'costvol' 2>&1 | grep -v amdgpu.ids | tail -1)"; done
+for cfg in "3 0" "3 1" "4 1" "2 1" "4 0"; do
+  set -- $cfg
+  E=""; [ $2 = 1 ] && E="DR_MVS_NO_SIDE_STREAM=1"
+  env $E timeout 300 python bench.py --steps 60 --warmup 10 --engines $1 --no-cpu --no-tsdf --no-boundary --no-loop 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('engines $1 no_side_stream $2: value', round(d['value'],1), 'ms_per_step', round(d['ms_per_step'],4), d['single_engine']['ms_per_depth_map'])"
+done
