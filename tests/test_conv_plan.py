@@ -1,0 +1,42 @@
+"""CPU: the convolution planner (tandem_amd/csrc/conv_mfma.h plan_conv: tap tables, packed weights incl. the XPAIR / X8 shifts, the
+three parity forms of the transposed layers, the summed kernel entries of ConvLayer::up2, classes and row groups) through a host
+emulation of the generic kernel's data flow (tests/cpp/conv_emul.hip) against direct evaluations of the layers' definitions -- every
+layer type of the depth pipeline (FeatureNet module.py:461-531, CostRegNet module.py:546-600), several plan candidates each.  No device
+code runs here; the persistent kernels have their own emulation (tests/test_march_plan.py), the GPU side is tests/test_conv_gpu.py."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.fixture(scope="module")
+def conv_emul(tmp_path_factory):
+    if not (os.path.exists(HIPCC) or shutil.which("hipcc")):
+        pytest.skip("needs hipcc to compile the host emulation")
+    exe = tmp_path_factory.mktemp("conv_emul") / "conv_emul"
+    subprocess.check_call([HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-Wno-unused-function",
+                           "-Wno-pass-failed", "-Wno-unused-result", os.path.join(ROOT, "tests", "cpp", "conv_emul.hip"), "-o", str(exe)])
+    return str(exe)
+
+
+@pytest.mark.parametrize("form", ["default", "0", "1", "2"])
+def test_generic_kernel_emulation_matches_the_layer_definitions(conv_emul, form):
+    env = dict(os.environ)
+    env.pop("DR_DECONV_FORM", None)
+    if form != "default":
+        env["DR_DECONV_FORM"] = form
+    out = subprocess.run([conv_emul, "12"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if " plan rank " in l]
+    assert len(lines) >= 60 and all(": ok " in l for l in lines), out.stdout[-4000:]
+    text = out.stdout
+    for needle in ("conv2d_5x5_s2_8_16", "xpair2d_4_8", "x8_prob_8_1", "deconv_16_8_skip", "deconv_64_32_s122", "up2_32_8_inplace_add", "classes 1 rows 32"):
+        assert needle in text, needle
+    if form in ("1", "2"):  # split parities really became classes
+        assert ("classes 4" in text) or ("classes 8" in text)
+    if form == "0":
+        assert "classes 4" not in text and "classes 8" not in text
