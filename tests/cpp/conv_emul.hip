@@ -1,4 +1,4 @@
-// conv_emul.hip -- host emulation of k_conv (tandem_amd/csrc/conv_mfma.h), run by tests/test_conv_plan.py on the CPU.
+// conv_emul.hip -- host emulation of k_conv and k_conv_a (tandem_amd/csrc/conv_mfma.h), run by tests/test_conv_plan.py on the CPU.
 //
 // There is no GPU where the CPU suite runs, so this program executes the generic kernel's DATA FLOW on the host for every layer
 // type the planner knows: plan_conv builds the real launch (host-only arena: packed weights, tap tables, parity classes,
@@ -105,6 +105,100 @@ static bool emulate(const ConvLaunch &c, const float *in, float *out, const floa
   return true;
 }
 
+// The persistent LDS-DMA kernel k_conv_a: the tile image every DMA piece produces (conv_a_slot: slot -> staged element, zeros from the
+// zero buffer), the workgroups' tile lists (XCD ranges, round-robin inside), operands through conv_a_unit, 8 waves of PT position tiles.
+template <int CI>
+static bool emulate_async(const ConvLaunch &c, const float *in, float *out, const float *add, long long *tiles_seen) {
+  const ConvArgs &a = c.args;
+  const ConvClass &cls = a.cls[0];
+  const int CT = c.ct, PT = c.pt, TPC = 16 / CI, NP = a.TZI * a.TYI * a.TXI, NU = cls.NU;
+  const int ntiles = a.tilesD * a.tilesH * a.tilesW, per_xcd = (ntiles + 7) >> 3;
+  std::vector<float> image((size_t)a.a_slots * 4);
+  for (unsigned bz = 0; bz < c.grid.z; ++bz) {
+    const int ct0 = (int)bz * CT;
+    for (unsigned blk = 0; blk < c.grid.x; ++blk) {
+      const int xcd = blk & 7, wi = blk >> 3, nw = c.grid.x >> 3;
+      const int t_lo = xcd * per_xcd, t_hi = std::min(ntiles, t_lo + per_xcd);
+      const int my_tiles = t_lo + wi < t_hi ? (t_hi - t_lo - wi + nw - 1) / nw : 0;
+      for (int k = 0; k < my_tiles; ++k) {
+        int b = t_lo + wi + k * nw;
+        if (bz == 0) ++*tiles_seen;
+        const int tw = b % a.tilesW;
+        b /= a.tilesW;
+        const int pz0 = (b / a.tilesH) * a.TZ, py0 = (b % a.tilesH) * a.TY, px0 = tw * a.TXT * 16;
+        const int iz0 = pz0 * a.sz - a.pz, iy0 = py0 * a.sy - a.py, ix0 = px0 * a.sx - a.px;
+        std::vector<float> acc((size_t)8 * CT * PT * 64 * 4, 0.f);
+        for (int p = 0; p < a.npass; ++p) {
+          for (int s = 0; s < a.a_slots; ++s) {
+            int pos, c4;
+            conv_a_slot<CI>(s, pos, c4);
+            const int x = pos % a.TXI, y = (pos / a.TXI) % a.TYI, z = pos / (a.TXI * a.TYI);
+            const int gz = iz0 + z, gy = iy0 + y, gx = ix0 + x;
+            const bool inside = pos < NP && gz >= 0 && gz < a.inD && gy >= 0 && gy < a.inH && gx >= 0 && gx < a.inW;
+            for (int r = 0; r < 4; ++r)
+              image[(size_t)s * 4 + r] = inside ? in[(((size_t)gz * a.inH + gy) * a.inW + gx) * a.inC + p * CI + c4 * 4 + r] : (pos < NP ? 0.f : NAN);
+          }
+          for (int wave = 0; wave < 8; ++wave)
+            for (int u = 0; u < NU; ++u)
+              for (int ct = 0; ct < CT; ++ct)
+                for (int pt = 0; pt < PT; ++pt) {
+                  float av[64][4], bv[64][4];
+                  for (int lane = 0; lane < 64; ++lane) {
+                    const int j = lane & 15, g = lane >> 4, c4 = ((4 * g) % CI) / 4;
+                    const float4 w = a.wpk[cls.w_base + (((size_t)p * NU + u) * a.ctTot + ct0 + ct) * 64 + lane];
+                    av[lane][0] = w.x; av[lane][1] = w.y; av[lane][2] = w.z; av[lane][3] = w.w;
+                    const int tau = wave * PT + pt, xt = tau % a.TXT, yt = (tau / a.TXT) % a.TY, zt = tau / (a.TXT * a.TY);
+                    const int bpos = ((zt * a.sz) * a.TYI + yt * a.sy) * a.TXI + (xt * 16 + j) * a.sx;
+                    const int tpos = bpos + a.tapoff[cls.tap_base + u * TPC + (4 * g) / CI];
+                    const int slot = tpos >= 0 ? conv_a_unit<CI>(tpos, c4) : -1;
+                    for (int r = 0; r < 4; ++r) bv[lane][r] = (slot >= 0 && slot < a.a_slots) ? image[(size_t)slot * 4 + r] : NAN;
+                  }
+                  for (int col = 0; col < 16; ++col)
+                    for (int row = 0; row < 16; ++row) {
+                      float &d = acc[((((size_t)wave * CT + ct) * PT + pt) * 64 + ((row >> 2) * 16 + col)) * 4 + (row & 3)];
+                      for (int r = 0; r < 4; ++r)
+                        for (int g = 0; g < 4; ++g) {
+                          const float wv = av[g * 16 + row][r];
+                          if (wv != 0.f) d = std::fmaf(wv, bv[g * 16 + col][r], d);
+                        }
+                    }
+                }
+        }
+        for (int wave = 0; wave < 8; ++wave)
+          for (int pt = 0; pt < PT; ++pt)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int j = lane & 15, g = lane >> 4;
+              const int tau = wave * PT + pt, xt = tau % a.TXT, yt = (tau / a.TXT) % a.TY, zt = tau / (a.TXT * a.TY);
+              const int qz = pz0 + zt, qy = py0 + yt, qx = px0 + xt * 16 + j;
+              if (qz >= a.nPD || qy >= a.nPH || qx >= a.nPW) continue;
+              for (int ct = 0; ct < CT; ++ct) {
+                const int c0 = (ct0 + ct) * 16 + 4 * g;
+                if (c0 >= a.rows_valid) continue;
+                int oz = qz * a.omz + cls.ooz, oy = qy * a.omy + cls.ooy, ox = qx * a.omx + cls.oox, ch = c0;
+                if (a.par_rows) {
+                  const int q = c0 / a.par_rows, bits = (a.par_map >> (3 * q)) & 7;
+                  ch = c0 - q * a.par_rows;
+                  oz += (bits >> 2) & 1; oy += (bits >> 1) & 1; ox += bits & 1;
+                }
+                const size_t ob = (((size_t)oz * a.outH + oy) * a.outW + ox) * a.outC + ch;
+                size_t ab = ob;
+                if (a.add_mode == 2) ab = (((size_t)oz * a.addH + (oy >> 1)) * a.addW + (ox >> 1)) * a.outC + ch;
+                for (int r = 0; r < 4; ++r) {
+                  float v = acc[((((size_t)wave * CT + ct) * PT + pt) * 64 + lane) * 4 + r];
+                  v = v * a.scale[c0 + r] + a.bias[c0 + r];
+                  if (a.relu) v = std::max(v, 0.f);
+                  if (a.add_mode) v += add[ab + r];
+                  if (std::isnan(v)) { printf("emul: an operand outside the staged image reached a non-zero weight\n"); return false; }
+                  out[ob + r] = v;
+                }
+              }
+            }
+      }
+    }
+  }
+  return true;
+}
+
 // kind: 0 conv (any stride), 1 ConvTranspose3d(k=3, pad=1, output_padding = stride - 1), 2 Conv2d 3x3 over the nearest x2 upsampling
 struct Case { const char *name; int kind, D, H, W, Cin, Cout, kd, kh, kw, sd, sh, sw; bool relu; int add; /* 0 none, 1 same, 2 up2 */ };
 
@@ -159,7 +253,7 @@ static int run_case(const Case &cs, int max_plans) {
   L.Cin = cs.Cin; L.Cout = cs.Cout; L.kd = cs.kd; L.kh = cs.kh; L.kw = cs.kw; L.sd = cs.sd; L.sh = cs.sh; L.sw = cs.sw;
   L.transposed = cs.kind == 1; L.weight = w.data(); L.scale = sc; L.bias = bi; L.relu = cs.relu;
   const ConvMode mode = (cs.kind == 0 && cs.sw == 1 && cs.Cout == 8) ? CONV_XPAIR : ((cs.kind == 0 && cs.sw == 1 && cs.Cout == 1) ? CONV_X8 : CONV_NORMAL);
-  int done = 0, fails = 0;
+  int done = 0, fails = 0, n_async = 0;
   for (int rank = 0; rank < 400 && done < max_plans; rank += 3) {
     std::vector<float> out(on, -777.f);
     DeviceArena arena;
@@ -172,14 +266,20 @@ static int run_case(const Case &cs, int max_plans) {
       ConvPlanOut P = plan_conv(L, mode, in.data(), cs.D, cs.H, cs.W, cs.Cin, out.data(), cs.add ? add.data() : nullptr, cs.add == 2 ? 2 : 1, arena, rank);
       ncand = P.ncand;
       c = P.launches.at(0);
-      if (c.async) { ok = false; printf("%-26s rank %d: expected a k_conv plan\n", cs.name, rank); break; }
-      ok = emulate(c, in.data(), out.data(), add.data());
+      if (c.async == 2) { ok = false; printf("%-26s rank %d: unexpected k_conv_m plan\n", cs.name, rank); break; }
+      if (c.async == 1) {
+        long long seen = 0;
+        ok = c.ci == 4 ? emulate_async<4>(c, in.data(), out.data(), add.data(), &seen)
+                       : (c.ci == 8 ? emulate_async<8>(c, in.data(), out.data(), add.data(), &seen) : emulate_async<16>(c, in.data(), out.data(), add.data(), &seen));
+        if (ok && seen != (long long)c.args.tilesD * c.args.tilesH * c.args.tilesW) { ok = false; printf("emul: the workgroups' tile lists cover %lld of %d tiles\n", seen, c.args.tilesD * c.args.tilesH * c.args.tilesW); }
+        ++n_async;
+      } else ok = emulate(c, in.data(), out.data(), add.data());
     }
     if (rank >= ncand) break;
     double worst = 0;
     for (size_t i = 0; i < on; ++i) worst = std::max(worst, (double)std::fabs(out[i] - ref[i]) / (1.0 + std::fabs(ref[i])));
     const bool pass = ok && worst < 2e-5;
-    printf("%-26s plan rank %3d ci=%d ct=%d pt=%d tile %dx%dx%d classes %u rows %d: %s (max rel err %.2e)\n", cs.name, rank, c.ci, c.ct, c.pt, c.args.TZ, c.args.TY,
+    printf("%-26s plan rank %3d %s ci=%d ct=%d pt=%d tile %dx%dx%d classes %u rows %d: %s (max rel err %.2e)\n", cs.name, rank, c.async ? "k_conv_a" : "k_conv", c.ci, c.ct, c.pt, c.args.TZ, c.args.TY,
            c.args.TXT * 16, c.grid.y, c.args.rows_valid, pass ? "ok" : "FAIL", worst);
     ++done;
     if (!pass) ++fails;
@@ -189,7 +289,9 @@ static int run_case(const Case &cs, int max_plans) {
 }
 
 int main(int argc, char **argv) {
-  setenv("DR_CONV_ASYNC", "0", 1);  // k_conv plans only (the persistent kernels have their own emulation: march_emul.hip)
+  // argv[2] = "async": rank the persistent LDS-DMA kernel's plans first (layers no k_conv_a plan fits fall back to k_conv); default: k_conv only.
+  // (k_conv_m has its own emulation: march_emul.hip)
+  setenv("DR_CONV_ASYNC", argc > 2 && !strcmp(argv[2], "async") ? "1" : "0", 1);
   setenv("DR_CONV_MARCH", "0", 1);
   setenv("DR_CONV_ROWMARCH", "0", 1);
   setenv("DR_CONV_NO_TUNED", "1", 1);
@@ -209,6 +311,11 @@ int main(int argc, char **argv) {
       {"deconv_64_32_s122", 1, 1, 4, 6, 64, 32, 3, 3, 3, 1, 2, 2, true, 1},           // conv7 at D = 4 stages
       {"up2_32_8_inplace_add", 2, 2, 7, 19, 32, 8, 1, 3, 3, 1, 1, 1, false, 1},       // the folded out.stage3's phase layers
       {"up2_16_16", 2, 1, 5, 33, 16, 16, 1, 3, 3, 1, 1, 1, true, 0},
+      // large enough for the persistent kernel's tiles (8 waves x 2-4 position tiles)
+      {"conv2d_3x3_16_16", 0, 2, 24, 48, 16, 16, 1, 3, 3, 1, 1, 1, true, 0},           // fn.conv1.x
+      {"conv2d_3x3_32_16", 0, 2, 16, 40, 32, 16, 1, 3, 3, 1, 1, 1, false, 0},          // fn.out2: two channel passes
+      {"conv3d_16_16_skip", 0, 6, 12, 32, 16, 16, 3, 3, 3, 1, 1, 1, true, 1},          // conv2 (+ a residual add)
+      {"xpair3d_16_8", 0, 5, 10, 70, 16, 8, 3, 3, 3, 1, 1, 1, true, 0},                // conv0
   };
   int fails = 0;
   for (const Case &cs : cases) fails += run_case(cs, max_plans);

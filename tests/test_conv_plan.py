@@ -40,3 +40,18 @@ def test_generic_kernel_emulation_matches_the_layer_definitions(conv_emul, form)
         assert ("classes 4" in text) or ("classes 8" in text)
     if form == "0":
         assert "classes 4" not in text and "classes 8" not in text
+
+
+def test_persistent_kernel_emulation_matches_the_layer_definitions(conv_emul):
+    """The same layers with k_conv_a's plans ranked first (DR_CONV_ASYNC=1 inside the program): the swizzled LDS image every DMA
+    piece produces (conv_a_slot / conv_a_unit), zeros for staged elements outside the tensor, the workgroups' tile lists (XCD
+    ranges, round-robin inside: every tile exactly once), 8 waves x PT position tiles; layers no persistent plan fits (stride-2
+    tiles, several classes) fall back to k_conv and are emulated as such."""
+    out = subprocess.run([conv_emul, "12", "async"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if " plan rank " in l]
+    assert all(": ok " in l for l in lines), out.stdout[-4000:]
+    a = [l for l in lines if " k_conv_a " in l]
+    assert len(a) >= 25, len(a)
+    for needle in ("xpair2d_4_8", "conv2d_1x1_16_32_up2add", "conv3d_64_64", "up2_32_8_inplace_add"):  # CI = 4, an upsample-add epilogue, 4 passes, the phase layers
+        assert any(needle in l for l in a), needle
