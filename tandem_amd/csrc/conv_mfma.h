@@ -430,7 +430,7 @@ __host__ __device__ inline void conv_a_slot(int s, int &pos, int &c4) {  // inve
 }
 
 template <int CI, int CT>
-__device__ inline void conv_a_issue(const ConvArgs &a, float4 *tile, float4 *wbuf, bool with_weights, int NP, int ncls, int p, int ct0,
+__device__ inline void conv_a_issue(const ConvArgs &a, float4 *tile, float4 *wbuf, bool with_weights, int NP, int NU, int p, int ct0, int w_base,
                                     int iz0, int iy0, int ix0, int wave, int lane) {
   for (int s0 = wave * 64; s0 < a.a_slots; s0 += kConvAThreads) {  // s0 is wave-uniform
     int pos, c4;
@@ -443,15 +443,11 @@ __device__ inline void conv_a_issue(const ConvArgs &a, float4 *tile, float4 *wbu
       src = a.in + (((size_t)gz * a.inH + gy) * a.inW + gx) * a.inC + p * CI + c4 * 4;
     conv_a_dma16(src, __builtin_amdgcn_readfirstlane(conv_a_lds_addr(tile + s0)));
   }
-  if (with_weights) {  // packed weights of this pass and row group, class after class: [u][CT][64] float4, lane-linear as they are in memory
-    for (int ic = 0; ic < ncls; ++ic) {
-      const int NU = a.cls[ic].NU;
-      const float4 *wsrc = a.wpk + a.cls[ic].w_base + ((size_t)p * NU * a.ctTot + ct0) * 64;
-      for (int e0 = wave * 64; e0 < NU * CT * 64; e0 += kConvAThreads) {
-        const int u = e0 / (CT * 64), r = e0 - u * (CT * 64);
-        conv_a_dma16(wsrc + (size_t)u * a.ctTot * 64 + r + lane, __builtin_amdgcn_readfirstlane(conv_a_lds_addr(wbuf + e0)));
-      }
-      wbuf += (size_t)NU * CT * 64;
+  if (with_weights) {  // packed weights of this pass and row group: [u][CT][64] float4, lane-linear as they are in memory
+    const float4 *wsrc = a.wpk + w_base + ((size_t)p * NU * a.ctTot + ct0) * 64;
+    for (int e0 = wave * 64; e0 < NU * CT * 64; e0 += kConvAThreads) {
+      const int u = e0 / (CT * 64), r = e0 - u * (CT * 64);
+      conv_a_dma16(wsrc + (size_t)u * a.ctTot * 64 + r + lane, __builtin_amdgcn_readfirstlane(conv_a_lds_addr(wbuf + e0)));
     }
   }
 }
@@ -489,29 +485,20 @@ __device__ inline void conv_a_kloop(const float4 *tile, const float4 *wl, const 
 }
 
 // grid = (persistent workgroups (multiple of 8), 1, output-row groups); 8 waves, PT position tiles per wave.
-// NC > 1: the launch's NC parity classes (transposed layers with split parities, ConvLayer::up2 with both row parities) are all computed
-// from ONE staged tile per unit -- they read the same input neighbourhood, so what k_conv stages once per class is staged once here --
-// each with its own weights, tap list, accumulators and output offset.
-template <int CI, int CT, int PT, int NC = 1>
+template <int CI, int CT, int PT>
 __global__ __launch_bounds__(kConvAThreads) void k_conv_a(const ConvArgs a) {
   extern __shared__ float4 lds4[];
   constexpr int TPC = 16 / CI;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, g = lane >> 4;
+  const ConvClass cls = a.cls[0];
   const int ct0 = blockIdx.z * CT;
-  const int NP = a.TZI * a.TYI * a.TXI;
-  int NUc[NC], woff[NC], toff[NC];  // per class: K chunks, float4 offset of its weights inside a pass's buffer, offset of its tap list
-  int nu_sum = 0;
-#pragma unroll
-  for (int ic = 0; ic < NC; ++ic) { NUc[ic] = a.cls[ic].NU; woff[ic] = nu_sum * CT * 64; toff[ic] = nu_sum * TPC; nu_sum += NUc[ic]; }
-  const int n_w = nu_sum * CT * 64;
+  const int NP = a.TZI * a.TYI * a.TXI, NU = cls.NU, n_w = NU * CT * 64;
 
-  // LDS: [tile 0][tile 1][weights 0][weights 1 (multi-pass layers)][tap tables]
+  // LDS: [tile 0][tile 1][weights 0][weights 1 (multi-pass layers)][tap table]
   float4 *tile0 = lds4, *tile1 = lds4 + a.a_slots;
   float4 *wb0 = lds4 + 2 * (size_t)a.a_slots;  // weight buffer of pass p: wb0 + (p % a_wbufs) * n_w
   int *tapl = reinterpret_cast<int *>(wb0 + (size_t)a.a_wbufs * n_w);
-#pragma unroll
-  for (int ic = 0; ic < NC; ++ic)
-    for (int i = tid; i < NUc[ic] * TPC; i += kConvAThreads) tapl[toff[ic] + i] = a.tapoff[a.cls[ic].tap_base + i];
+  for (int i = tid; i < NU * TPC; i += kConvAThreads) tapl[i] = a.tapoff[cls.tap_base + i];
   const int *tp = tapl + (4 * g) / CI;
   const int c4 = ((4 * g) % CI) / 4;
 
@@ -541,32 +528,18 @@ __global__ __launch_bounds__(kConvAThreads) void k_conv_a(const ConvArgs a) {
     int pz0, py0, px0;
     tile_origin(k, pz0, py0, px0);
     // weight buffer = pass % buffers: when every pass has its own buffer it is fetched once per workgroup
-    conv_a_issue<CI, CT>(a, (unit & 1) ? tile1 : tile0, wb0 + (size_t)(p % a.a_wbufs) * n_w, unit < a.npass || a.npass > a.a_wbufs, NP, NC, p, ct0,
+    conv_a_issue<CI, CT>(a, (unit & 1) ? tile1 : tile0, wb0 + (size_t)(p % a.a_wbufs) * n_w, unit < a.npass || a.npass > a.a_wbufs, NP, NU, p, ct0, cls.w_base,
                          pz0 * a.sz - a.pz, py0 * a.sy - a.py, px0 * a.sx - a.px, wave, lane);
   };
 
-  floatx4 acc[NC][CT][PT];
+  floatx4 acc[CT][PT];
 #pragma unroll
-  for (int ic = 0; ic < NC; ++ic)
+  for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-      for (int pt = 0; pt < PT; ++pt) acc[ic][ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
 
   float4 scv[CT], biv[CT];  // folded BatchNorm of this lane's rows: fetched once, not per tile
   conv_load_affine<CT>(a, g, ct0, scv, biv);
-  auto epilogue = [&](int tile_k) {
-    int pz0, py0, px0;
-    tile_origin(tile_k, pz0, py0, px0);
-#pragma unroll
-    for (int ic = 0; ic < NC; ++ic) {
-      conv_epilogue<CT, PT>(a, a.cls[ic], acc[ic], scv, biv, wave, j, g, ct0, pz0, py0, px0);
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) acc[ic][ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
-    }
-  };
   if (n_units > 0) issue(0);
   int done_tile = -1;  // tile whose accumulators are complete and not yet written
   for (int i = 0; i < n_units; ++i) {
@@ -577,21 +550,28 @@ __global__ __launch_bounds__(kConvAThreads) void k_conv_a(const ConvArgs a) {
 #else
     if (done_tile >= 0) {  // epilogue of the previous tile: its stores retire under the K loop below
 #endif
-      epilogue(done_tile);
+      int pz0, py0, px0;
+      tile_origin(done_tile, pz0, py0, px0);
+      conv_epilogue<CT, PT>(a, cls, acc, scv, biv, wave, j, g, ct0, pz0, py0, px0);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
       done_tile = -1;
     }
 #ifndef DR_ABL_NO_STAGE
     if (i + 1 < n_units) issue(i + 1);
 #endif
 #ifndef DR_ABL_NO_KLOOP
-#pragma unroll
-    for (int ic = 0; ic < NC; ++ic)
-      conv_a_kloop<CI, CT, PT>((i & 1) ? tile1 : tile0, wb0 + (size_t)((i % a.npass) % a.a_wbufs) * n_w + woff[ic], tp + toff[ic], TPC, NUc[ic], lane, c4, bpos,
-                               acc[ic]);
+    conv_a_kloop<CI, CT, PT>((i & 1) ? tile1 : tile0, wb0 + (size_t)((i % a.npass) % a.a_wbufs) * n_w, tp, TPC, NU, lane, c4, bpos, acc);
 #endif
     if ((i + 1) % a.npass == 0) done_tile = i / a.npass;
   }
-  if (done_tile >= 0) epilogue(done_tile);
+  if (done_tile >= 0) {
+    int pz0, py0, px0;
+    tile_origin(done_tile, pz0, py0, px0);
+    conv_epilogue<CT, PT>(a, cls, acc, scv, biv, wave, j, g, ct0, pz0, py0, px0);
+  }
 }
 
 }  // namespace dr
@@ -608,8 +588,8 @@ struct ConvLayer {  // logical description (torch semantics)
   int kd = 1, kh = 1, kw = 1;
   int sd = 1, sh = 1, sw = 1;
   bool transposed = false;          // ConvTranspose3d(k=3, pad=1, output_padding = stride-1)
-  int up2 = 0;                      // 1 + py (3: both py, as two classes): Conv2d(k=3, pad=1) applied to the nearest x2 upsampling (in H and W) of the
-                                    // input, which is given at HALF resolution and never upsampled in memory; this launch produces the output rows 2Y + py.  Output
+  int up2 = 0;                      // 1 + py: Conv2d(k=3, pad=1) applied to the nearest x2 upsampling (in H and W) of the input, which is given
+                                    // at HALF resolution and never upsampled in memory; this launch produces the output rows 2Y + py.  Output
                                     // pixel (2Y+py, 2X+px) reads 2 x 2 input pixels, the kernel rows / columns that fall on the same input
                                     // pixel summed (weight (Cout,Cin,1,3,3)); both px are rows of the launch (2 * Cout rows)
   const float *weight = nullptr;    // (Cout,Cin,kd,kh,kw) or transposed (Cin,Cout,kd,kh,kw)
@@ -627,7 +607,6 @@ struct ConvLaunch {
   ConvArgs args;
   int ci, ct, pt, fz = 0;
   int async = 0;  // 1: k_conv_a (persistent, LDS-DMA staged, 512 threads); 2: k_conv_m (marching, 8 consumer + 2 producer waves)
-  int nc = 1;     // k_conv_a: parity classes computed from one staged tile (1, 2 or 4)
   MarchArgs march{};
   int nup = 0;    // k_conv_m: K chunks per input plane
   int ncw = 8;    // k_conv_m: consumer waves (8 or 12)
@@ -732,9 +711,8 @@ struct ConvTuned {
 inline bool conv_instance_exists(int ci, int ct) {
   return (ci == 4 && ct == 1) || ((ci == 8 || ci == 16) && (ct == 1 || ct == 2 || ct == 4));
 }
-inline bool conv_a_instance_exists(int ci, int ct, int pt, int ncls = 1) {
-  if (ncls == 2 || ncls == 4) return (pt == 2 || pt == 4) && ci == 16 && ct == 1;  // several parity classes from one staged tile
-  return ncls == 1 && (pt == 2 || pt == 4) && ((ci == 4 && ct == 1) || ((ci == 8 || ci == 16) && (ct == 1 || ct == 2)));
+inline bool conv_a_instance_exists(int ci, int ct, int pt) {
+  return (pt == 2 || pt == 4) && ((ci == 4 && ct == 1) || ((ci == 8 || ci == 16) && (ct == 1 || ct == 2)));
 }
 // k_conv_m instances (CI, NUP, CT, PT, consumer waves).  3-D layers: NUP = 6 (8 channels, XPAIR), 12 (16 channels, XPAIR), 9 (16 channels);
 // row march of 2-D layers: NUP = 2 (8 channels, XPAIR), 4 (16 channels, XPAIR), 3 (16 channels).  CT = 2 with PT = 4 needs more than the
@@ -826,9 +804,8 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   auto cz = axis_classes(L.kd, L.sd, L.transposed, inD, form >= 1);
   auto cy = axis_classes(L.kh, L.sh, L.transposed, inH, form >= 1);
   auto cx = axis_classes(L.kw, L.sw, L.transposed, inW, form >= 2);
-  if (L.up2) {  // both x parities as rows; one y parity per launch (up2 = 1, 2) or both as the two classes of one launch (up2 = 3)
-    cy = axis_classes_up2(inH, true);
-    if (L.up2 < 3) cy = {cy[L.up2 - 1]};
+  if (L.up2) {  // one y parity per launch (a single class: the persistent kernels apply), both x parities as rows
+    cy = {axis_classes_up2(inH, true)[L.up2 - 1]};
     cx = axis_classes_up2(inW, false);
   }
   const bool parity_layer = L.transposed || L.up2;
@@ -890,12 +867,10 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   struct Cand { double cost; int ci, pt, ct, tz, ty, txt, tzi, tyi, txi, async; };
   std::vector<Cand> cands;
   const int policy = fz ? 0 : conv_async_policy();
-  if (policy >= 1 && (ncls == 1 || ((ncls == 2 || ncls == 4) && !getenv("DR_CONV_A_ONE_CLASS")))) {  // k_conv_a: 8 waves, 8*pt position tiles per workgroup, two tile buffers
+  if (policy >= 1 && ncls == 1) {  // k_conv_a: 8 waves, 8*pt position tiles per workgroup, two tile buffers
     for (int ci : {16, 8, 4}) {
       if (L.Cin % ci || (ci == 4 && L.Cin != 4)) continue;
-      const int npass = L.Cin / ci, tpc = 16 / ci;
-      int nu = 0;  // K chunks per pass, all classes of the launch
-      for (auto &cc : classes) nu += cdiv(cc.ntaps, tpc);
+      const int npass = L.Cin / ci, tpc = 16 / ci, nu = cdiv(classes[0].ntaps, tpc);
       if (npass > 2 && (npass & 1)) continue;  // weight buffers alternate with the pass parity
       for (int pt : {2, 4})
         for (int tz = 1; tz <= 8 * pt; tz *= 2)
@@ -906,7 +881,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
             if ((size_t)tzi * tyi * txi >= 65536) continue;
             const double tiles = (double)cdiv(nPD, tz) * cdiv(nPH, ty) * cdiv(nPW, txt * 16);
             for (int ct : {2, 1}) {
-              if (CTtot % ct || !conv_a_instance_exists(ci, ct, pt, ncls)) continue;
+              if (CTtot % ct || !conv_a_instance_exists(ci, ct, pt)) continue;
               const size_t slots = conv_a_slots(tzi * tyi * txi, ci);
               size_t bytes = 2 * slots * 16 + (size_t)npass * nu * ct * 1024 + (size_t)nu * tpc * 4 + 64;  // all passes' weights resident ...
               if (bytes > kConvMaxLds) bytes = 2 * slots * 16 + (size_t)std::min(npass, 2) * nu * ct * 1024 + (size_t)nu * tpc * 4 + 64;  // ... or two in flight
@@ -917,9 +892,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
               const double unit = wpc * std::max(mfma_unit, stage_unit) + 700.0;
               // x 1.1: the two families' cost models are not calibrated against each other; an untuned shape only
               // moves to the persistent kernel when its model says so with some margin
-              // several classes per staged tile: measured 1.1-1.3x the time of k_conv with the classes in grid.y (s2.conv11 0.072 against 0.066 ms,
-              // the folded out.stage3's phase layer 0.124 against 0.097) -- the classes' K loops run back to back in one workgroup
-              const double cost = (ncls > 1 ? 1.45 : 1.1) * std::ceil(tiles * split / (256.0 * wpc)) * npass * unit;
+              const double cost = 1.1 * std::ceil(tiles * split / (256.0 * wpc)) * npass * unit;
               cands.push_back({cost, ci, pt, ct, tz, ty, txt, tzi, tyi, txi, 1});
             }
           }
@@ -1149,9 +1122,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   cl.lds_bytes = (size_t)TZI * TYI * TXI * CIS * 4 + (size_t)nu_max * CT * 1024 + (size_t)nu_max * TPC * 4 + 64;
   a.zero16 = nullptr; a.a_slots = 0; a.a_wbufs = 1;
   if (ASYNC == 1) {
-    cl.async = 1; cl.nc = ncls;
-    nu_max = 0;
-    for (auto &c : cls) nu_max += c.NU;  // every class's weights and tap list are resident: the sizes below are sums over the classes
+    cl.async = 1;
     a.zero16 = arena.upload(std::vector<float>(4, 0.f));
     a.a_slots = (int)conv_a_slots(TZI * TYI * TXI, CI);
     a.a_wbufs = npass;
@@ -1224,11 +1195,11 @@ inline void launch_conv_inst(const ConvLaunch &c, hipStream_t st) {
   conv_allow_big_lds(reinterpret_cast<const void *>(&k_conv<CI, CT, PT, FZ>), done, c.lds_bytes);
   hipLaunchKernelGGL((k_conv<CI, CT, PT, FZ>), c.grid, dim3(kConvThreads), c.lds_bytes, st, c.args);
 }
-template <int CI, int CT, int PT, int NC = 1>
+template <int CI, int CT, int PT>
 inline void launch_conv_a_inst(const ConvLaunch &c, hipStream_t st) {
   static std::atomic<unsigned long long> done{0};
-  conv_allow_big_lds(reinterpret_cast<const void *>(&k_conv_a<CI, CT, PT, NC>), done, c.lds_bytes);
-  hipLaunchKernelGGL((k_conv_a<CI, CT, PT, NC>), c.grid, dim3(kConvAThreads), c.lds_bytes, st, c.args);
+  conv_allow_big_lds(reinterpret_cast<const void *>(&k_conv_a<CI, CT, PT>), done, c.lds_bytes);
+  hipLaunchKernelGGL((k_conv_a<CI, CT, PT>), c.grid, dim3(kConvAThreads), c.lds_bytes, st, c.args);
 }
 template <int CI, int NUP, int CT, int PT, int FZ = 0, int NCW = 8>
 inline void launch_conv_m_inst(const ConvLaunch &c, hipStream_t st) {
@@ -1249,12 +1220,6 @@ inline void launch_conv(const ConvLaunch &c, hipStream_t st) {
     DR_MARCH_INSTANCES(DR_X)
 #undef DR_X
     fail(DR_ERR_ARG, "launch_conv: no marching instance CI=%d NUP=%d CT=%d PT=%d waves=%d", c.ci, c.nup, c.ct, c.pt, c.ncw);
-  }
-  if (c.async && c.nc > 1) {
-    if (c.ci != 16 || c.ct != 1 || (c.pt != 2 && c.pt != 4) || (c.nc != 2 && c.nc != 4)) fail(DR_ERR_ARG, "launch_conv: no multi-class async instance CI=%d CT=%d PT=%d classes=%d", c.ci, c.ct, c.pt, c.nc);
-    if (c.nc == 2) { if (c.pt == 4) launch_conv_a_inst<16, 1, 4, 2>(c, st); else launch_conv_a_inst<16, 1, 2, 2>(c, st); }
-    else { if (c.pt == 4) launch_conv_a_inst<16, 1, 4, 4>(c, st); else launch_conv_a_inst<16, 1, 2, 4>(c, st); }
-    return;
   }
   if (c.async) {
 #define DR_CONV_A_CASE(CI_, CT_)                                                \

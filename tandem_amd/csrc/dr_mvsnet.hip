@@ -420,8 +420,7 @@ class MvsEngine {
       const Op &o = ops_[i];
       char kn[64] = "misc";
       if (o.kind == Op::CONV && o.conv.async == 2) snprintf(kn, sizeof kn, "k_conv_m<%d,%d,%d,%d,%d,%d>", o.conv.ci, o.conv.nup, o.conv.ct, o.conv.pt, o.conv.fz, o.conv.ncw);  // rocprofv3's spelling of the instance
-      else if (o.kind == Op::CONV && o.conv.async && o.conv.nc > 1) snprintf(kn, sizeof kn, "k_conv_a<%d,%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt, o.conv.nc);
-      else if (o.kind == Op::CONV && o.conv.async) snprintf(kn, sizeof kn, "k_conv_a<%d,%d,%d,1>", o.conv.ci, o.conv.ct, o.conv.pt);
+      else if (o.kind == Op::CONV && o.conv.async) snprintf(kn, sizeof kn, "k_conv_a<%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt);
       else if (o.kind == Op::CONV) snprintf(kn, sizeof kn, "k_conv<%d,%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt, o.conv.fz);
       else if (o.kind == Op::COSTVOL) snprintf(kn, sizeof kn, costvol_v1_ ? "k_costvol<%d>" : (costvol_v2_ ? "k_costvol2<%d>" : "k_costvol3<%d>"), 32 >> (o.stage - 1));
       else if (o.kind == Op::PROB) snprintf(kn, sizeof kn, getenv("DR_PROB_V1") ? "k_prob" : "k_prob2");
@@ -692,11 +691,7 @@ class MvsEngine {
       DevTensor &f3 = alloc("feat3", c3.D, c3.H, c3.W, 8, fpad);
       ConvLayer LA; LA.Cin = 8; LA.Cout = 8; LA.kd = 1; LA.kh = 3; LA.kw = 3; LA.weight = wa.data(); LA.bias = bint; LA.out_pad = fpad;
       emit_conv("fn.out3a", LA, CONV_XPAIR, c3, f3, nullptr, 0, 0);
-      if (!getenv("DR_OUT3_TWO_LAUNCHES")) {  // both row parities as the two classes of ONE launch: inter2's tile is staged once for both
-        ConvLayer LB; LB.Cin = 32; LB.Cout = 8; LB.kd = 1; LB.kh = 3; LB.kw = 3; LB.weight = wo3.data.data(); LB.up2 = 3; LB.out_pad = fpad;
-        emit_conv("fn.out3b", LB, CONV_NORMAL, i2, f3, f3.interior(), 1, f3.n());
-      } else
-      for (int py = 0; py < 2; ++py) {  // (A/B hook: one launch per row parity)
+      for (int py = 0; py < 2; ++py) {
         ConvLayer LB; LB.Cin = 32; LB.Cout = 8; LB.kd = 1; LB.kh = 3; LB.kw = 3; LB.weight = wo3.data.data(); LB.up2 = 1 + py; LB.out_pad = fpad;
         emit_conv(py ? "fn.out3c" : "fn.out3b", LB, CONV_NORMAL, i2, f3, f3.interior(), 1, f3.n() / 2);
       }
@@ -1164,7 +1159,7 @@ int drm_debug_conv(int device, const float *in, int D, int H, int W, int Cin, co
     ConvLayer L;
     L.Cin = Cin; L.Cout = Cout; L.kd = kd; L.kh = kh; L.kw = kw; L.sd = sd; L.sh = sh; L.sw = sw;
     L.transposed = transposed == 1; L.weight = weight; L.relu = relu != 0;
-    const bool up2 = transposed == 2 || transposed == 3;  // test hook for ConvLayer::up2: 2 = one launch per row parity, 3 = both parities as classes of one launch
+    const bool up2 = transposed == 2;  // test hook for ConvLayer::up2: both row parities, one launch each
     if (scale) L.scale.assign(scale, scale + Cout);
     if (bias) L.bias.assign(bias, bias + Cout);
     const ConvMode mode = (!transposed && sw == 1 && Cout == 8) ? CONV_XPAIR : ((!transposed && sw == 1 && Cout == 1) ? CONV_X8 : CONV_NORMAL);
@@ -1184,8 +1179,8 @@ int drm_debug_conv(int device, const float *in, int D, int H, int W, int Cin, co
     // DR_CONV_RANK (test hook): build the rank-th candidate of the planner's ranking instead of its first choice
     const char *rk = getenv("DR_CONV_RANK");
     ConvPlanOut P;
-    for (int py = 0; py < (transposed == 2 ? 2 : 1); ++py) {
-      L.up2 = transposed == 2 ? 1 + py : (transposed == 3 ? 3 : 0);
+    for (int py = 0; py < (up2 ? 2 : 1); ++py) {
+      L.up2 = up2 ? 1 + py : 0;
       P = plan_conv(L, mode, d_in, D, H, W, Cin, d_out, d_add, add_up2 ? 2 : 1, arena, rk ? atoi(rk) : 0);
       for (auto &cl : P.launches) launch_conv(cl, nullptr);
     }

@@ -173,12 +173,12 @@ class DrMvsnet:
 def debug_conv(x, weight, stride=(1, 1, 1), transposed=False, scale=None, bias=None, relu=False, add=None,
                add_up2=False, device=0):
     """Kernel unit-test hook: x (D,H,W,Cin) channels-last, weight in torch layout; returns (Do,Ho,Wo,Cout).
-    transposed: False / True, or "up2" / "up2both": a 3x3 stride-1 layer over the nearest x2 upsampling (H, W) of x (ConvLayer::up2)."""
+    transposed: False / True, or "up2": a 3x3 stride-1 layer over the nearest x2 upsampling (H, W) of x (ConvLayer::up2)."""
     x = np.ascontiguousarray(x, np.float32)
     w = np.ascontiguousarray(weight, np.float32)
     D, H, W, Cin = x.shape
-    up2 = transposed in ("up2", "up2both")  # "up2both": both row parities as the two classes of one launch
-    transposed = (3 if transposed == "up2both" else 2) if up2 else int(bool(transposed))
+    up2 = transposed == "up2"
+    transposed = 2 if up2 else int(bool(transposed))
     Cout = w.shape[1] if transposed == 1 else w.shape[0]
     kd, kh, kw = w.shape[2:]
     sd, sh, sw = stride

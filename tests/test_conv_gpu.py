@@ -208,9 +208,8 @@ def test_conv_over_upsampled_input(case, monkeypatch):
     xt = torch.from_numpy(x).permute(0, 3, 1, 2)  # (D, C, h, w)
     up = F.interpolate(xt, scale_factor=2, mode="nearest")
     ref = F.conv2d(up, torch.from_numpy(w[:, :, 0]), torch.from_numpy(bias), 1, 1).permute(0, 2, 3, 1).numpy() + add
-    for form in ("up2", "up2both"):  # one launch per row parity / both parities as the two classes of one launch
-        for rank in range(0, 40, 3):
-            monkeypatch.setenv("DR_CONV_RANK", str(rank))
-            got = debug_conv(x, w, (1, 1, 1), form, None, bias, False, add, False)
-            err = np.abs(got - ref).max()
-            assert got.shape == ref.shape and err <= 2e-5 * max(1.0, np.abs(ref).max()), f"{name} {form} rank {rank}: max|err| {err:.3e}"
+    for rank in range(0, 40, 3):
+        monkeypatch.setenv("DR_CONV_RANK", str(rank))
+        got = debug_conv(x, w, (1, 1, 1), "up2", None, bias, False, add, False)
+        err = np.abs(got - ref).max()
+        assert got.shape == ref.shape and err <= 2e-5 * max(1.0, np.abs(ref).max()), f"{name} rank {rank}: max|err| {err:.3e}"
