@@ -55,3 +55,17 @@ def test_persistent_kernel_emulation_matches_the_layer_definitions(conv_emul):
     assert len(a) >= 25, len(a)
     for needle in ("xpair2d_4_8", "conv2d_1x1_16_32_up2add", "conv3d_64_64", "up2_32_8_inplace_add"):  # CI = 4, an upsample-add epilogue, 4 passes, the phase layers
         assert any(needle in l for l in a), needle
+
+
+def test_every_tuned_row_names_a_plan_the_planner_can_build(tmp_path):
+    """conv_tuned.h rows are matched by layer signature and then by plan parameters; a row whose plan no longer exists (an instance
+    removed, a tile rule changed) is silently ignored and the layer falls back to the cost model.  tests/cpp/tuned_rows.hip plans
+    every row's layer on the host and checks that the row's plan is the one that comes out (and that duplicated signatures agree)."""
+    if not (os.path.exists(HIPCC) or shutil.which("hipcc")):
+        pytest.skip("needs hipcc to compile the host check")
+    exe = tmp_path / "tuned_rows"
+    subprocess.check_call([HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-Wno-unused-function",
+                           "-Wno-pass-failed", "-Wno-unused-result", os.path.join(ROOT, "tests", "cpp", "tuned_rows.hip"), "-o", str(exe)])
+    env = {k: v for k, v in os.environ.items() if not k.startswith("DR_")}
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and " 0 stale" in out.stdout, out.stdout[-3000:] + out.stderr[-1000:]
