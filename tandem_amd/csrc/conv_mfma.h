@@ -588,8 +588,8 @@ struct ConvLayer {  // logical description (torch semantics)
   int kd = 1, kh = 1, kw = 1;
   int sd = 1, sh = 1, sw = 1;
   bool transposed = false;          // ConvTranspose3d(k=3, pad=1, output_padding = stride-1)
-  int up2 = 0;                      // 1 + py: Conv2d(k=3, pad=1) applied to the nearest x2 upsampling (in H and W) of the input, which is given
-                                    // at HALF resolution and never upsampled in memory; this launch produces the output rows 2Y + py.  Output
+  int up2 = 0;                      // 1 + py (3: both py, as two classes): Conv2d(k=3, pad=1) applied to the nearest x2 upsampling (in H and W) of the input,
+                                    // which is given at HALF resolution and never upsampled in memory; this launch produces the output rows 2Y + py.  Output
                                     // pixel (2Y+py, 2X+px) reads 2 x 2 input pixels, the kernel rows / columns that fall on the same input
                                     // pixel summed (weight (Cout,Cin,1,3,3)); both px are rows of the launch (2 * Cout rows)
   const float *weight = nullptr;    // (Cout,Cin,kd,kh,kw) or transposed (Cin,Cout,kd,kh,kw)
@@ -804,8 +804,9 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   auto cz = axis_classes(L.kd, L.sd, L.transposed, inD, form >= 1);
   auto cy = axis_classes(L.kh, L.sh, L.transposed, inH, form >= 1);
   auto cx = axis_classes(L.kw, L.sw, L.transposed, inW, form >= 2);
-  if (L.up2) {  // one y parity per launch (a single class: the persistent kernels apply), both x parities as rows
-    cy = {axis_classes_up2(inH, true)[L.up2 - 1]};
+  if (L.up2) {  // both x parities as rows; one y parity per launch (up2 = 1, 2: a single class, the persistent kernels apply) or both
+    cy = axis_classes_up2(inH, true);  // as the two classes of one k_conv launch (up2 = 3)
+    if (L.up2 < 3) cy = {cy[L.up2 - 1]};
     cx = axis_classes_up2(inW, false);
   }
   const bool parity_layer = L.transposed || L.up2;

@@ -199,7 +199,8 @@ static bool emulate_async(const ConvLaunch &c, const float *in, float *out, cons
   return true;
 }
 
-// kind: 0 conv (any stride), 1 ConvTranspose3d(k=3, pad=1, output_padding = stride - 1), 2 Conv2d 3x3 over the nearest x2 upsampling
+// kind: 0 conv (any stride), 1 ConvTranspose3d(k=3, pad=1, output_padding = stride - 1), 2 Conv2d 3x3 over the nearest x2 upsampling (one launch
+// per row parity), 3 the same with both row parities as the two classes of one launch
 struct Case { const char *name; int kind, D, H, W, Cin, Cout, kd, kh, kw, sd, sh, sw; bool relu; int add; /* 0 none, 1 same, 2 up2 */ };
 
 static int run_case(const Case &cs, int max_plans) {
@@ -213,7 +214,7 @@ static int run_case(const Case &cs, int max_plans) {
   for (auto &v : bi) v = 0.3f * U(rng);
   int oD, oH, oW;
   if (cs.kind == 1) { oD = cs.D * cs.sd; oH = cs.H * cs.sh; oW = cs.W * cs.sw; }
-  else if (cs.kind == 2) { oD = cs.D; oH = 2 * cs.H; oW = 2 * cs.W; }
+  else if (cs.kind >= 2) { oD = cs.D; oH = 2 * cs.H; oW = 2 * cs.W; }
   else { oD = (cs.D + 2 * (cs.kd / 2) - cs.kd) / cs.sd + 1; oH = (cs.H + 2 * (cs.kh / 2) - cs.kh) / cs.sh + 1; oW = (cs.W + 2 * (cs.kw / 2) - cs.kw) / cs.sw + 1; }
   const size_t on = (size_t)oD * oH * oW * cs.Cout;
   std::vector<float> add(cs.add == 2 ? (size_t)oD * (oH / 2) * (oW / 2) * cs.Cout : on);
@@ -236,7 +237,7 @@ static int run_case(const Case &cs, int max_plans) {
           wt = w[((((size_t)ci * cs.Cout + co) * cs.kd + tz) * cs.kh + ty) * cs.kw + tx];
         } else {
           wt = w[((((size_t)co * cs.Cin + ci) * cs.kd + tz) * cs.kh + ty) * cs.kw + tx];
-          if (cs.kind == 2) {  // the upsampled image: up[Y][X] = in[Y / 2][X / 2], zero outside [0, 2H) x [0, 2W)
+          if (cs.kind >= 2) {  // the upsampled image: up[Y][X] = in[Y / 2][X / 2], zero outside [0, 2H) x [0, 2W)
             const int Y = y + ty - 1, X = x + tx - 1;
             v = (Y < 0 || Y >= oH || X < 0 || X >= oW) ? 0.0 : at(z, Y / 2, X / 2, ci);
           } else v = at(z * cs.sd + tz - cs.kd / 2, y * cs.sh + ty - cs.kh / 2, x * cs.sw + tx - cs.kw / 2, ci);
@@ -261,8 +262,8 @@ static int run_case(const Case &cs, int max_plans) {
     ConvLaunch c{};
     bool ok = true;
     int ncand = 0;
-    for (int py = 0; py < (cs.kind == 2 ? 2 : 1) && ok; ++py) {  // up2: one launch per row parity
-      L.up2 = cs.kind == 2 ? 1 + py : 0;
+    for (int py = 0; py < (cs.kind == 2 ? 2 : 1) && ok; ++py) {  // up2: one launch per row parity, or one launch with two classes
+      L.up2 = cs.kind == 2 ? 1 + py : (cs.kind == 3 ? 3 : 0);
       ConvPlanOut P = plan_conv(L, mode, in.data(), cs.D, cs.H, cs.W, cs.Cin, out.data(), cs.add ? add.data() : nullptr, cs.add == 2 ? 2 : 1, arena, rank);
       ncand = P.ncand;
       c = P.launches.at(0);
@@ -311,6 +312,7 @@ int main(int argc, char **argv) {
       {"deconv_64_32_s122", 1, 1, 4, 6, 64, 32, 3, 3, 3, 1, 2, 2, true, 1},           // conv7 at D = 4 stages
       {"up2_32_8_inplace_add", 2, 2, 7, 19, 32, 8, 1, 3, 3, 1, 1, 1, false, 1},       // the folded out.stage3's phase layers
       {"up2_16_16", 2, 1, 5, 33, 16, 16, 1, 3, 3, 1, 1, 1, true, 0},
+      {"up2both_32_8_inplace_add", 3, 2, 12, 40, 32, 8, 1, 3, 3, 1, 1, 1, false, 1},  // both row parities as two classes of one launch
       // large enough for the persistent kernel's tiles (8 waves x 2-4 position tiles)
       {"conv2d_3x3_16_16", 0, 2, 24, 48, 16, 16, 1, 3, 3, 1, 1, 1, true, 0},           // fn.conv1.x
       {"conv2d_3x3_32_16", 0, 2, 16, 40, 32, 16, 1, 3, 3, 1, 1, 1, false, 0},          // fn.out2: two channel passes
