@@ -11,7 +11,7 @@ all: $(LIB) oracle/libtsdf_oracle.so oracle/libtsdf_oracle_omp.so oracle/libtrac
 
 # the depth pipeline is held to a float tolerance, not to bit-exactness: let hipcc contract a*b+c into FMAs there (the
 # vector-pipe kernels -- cost volume, prob -- are VALU-bound, and the reference's cuDNN/ATen kernels use FMAs too)
-$(CSRC)/dr_mvsnet.o: $(CSRC)/dr_mvsnet.hip $(CSRC)/conv_mfma.h $(CSRC)/conv_tuned.h $(CSRC)/mvs_kernels.h $(CSRC)/dr_common.h include/dr_mi355x.h
+$(CSRC)/dr_mvsnet.o: $(CSRC)/dr_mvsnet.hip $(CSRC)/conv_mfma.h $(CSRC)/conv_bf3.h $(CSRC)/conv_march.h $(CSRC)/march_plan.h $(CSRC)/conv_tuned.h $(CSRC)/mvs_kernels.h $(CSRC)/dr_common.h include/dr_mi355x.h
 	$(HIPCC) $(subst -ffp-contract=off,-ffp-contract=fast,$(HIPFLAGS)) -c $< -o $@
 $(CSRC)/dr_fusion.o: $(CSRC)/dr_fusion.hip $(CSRC)/mesh_kernels.h $(CSRC)/mc_tables.h $(CSRC)/dr_common.h include/dr_mi355x.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@

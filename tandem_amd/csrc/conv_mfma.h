@@ -403,6 +403,8 @@ __global__ __launch_bounds__(kConvThreads, DR_KCONV_MIN_WAVES(CT, FZ)) void k_co
   conv_epilogue<CT, PT>(a, cls, acc, scv, biv, wave, j, g, ct0, pz0, py0, px0);
 }
 
+#include "conv_bf3.h"  // k_conv_b: k_conv on the bf16 matrix cores with three-term split operands (opt-in)
+
 // ------------------------------------------------------------------------------------------------
 // k_conv_a: the same implicit GEMM as a PERSISTENT workgroup whose staging is asynchronous.
 //
@@ -610,6 +612,7 @@ struct ConvLaunch {
   MarchArgs march{};
   int nup = 0;    // k_conv_m: K chunks per input plane
   int ncw = 8;    // k_conv_m: consumer waves (8 or 12)
+  int bf3 = 0;    // 1: k_conv_b (bf16 x 3 operands; wpk holds hi / lo bf16 fragments, 32-wide K chunks)
   dim3 grid;
   size_t lds_bytes;
   double flops;  // useful (algorithmic) flops of this launch
@@ -789,6 +792,25 @@ inline int conv_deconv_form(int Cout) {
 }
 // which kernel family the planner may use: 0 = k_conv only, 1 = k_conv_a only (falls back to k_conv when no async plan
 // fits), 2 = both, ranked together.  DR_CONV_ASYNC overrides (A/B hook).
+// Opt-in precision mode (DR_CONV_BF16X3=1): every layer with Cin % 8 == 0 runs on k_conv_b -- k_conv's data flow on the bf16 matrix cores
+// with both operands split into two bf16 terms and the three leading products accumulated in fp32 (conv_bf3.h has the numerics).
+inline int conv_bf3_policy() {
+  const char *e = getenv("DR_CONV_BF16X3");
+  return e && atoi(e) > 0 ? 1 : 0;
+}
+inline unsigned short bf16_rne(float f) {  // round to nearest even, as v_cvt_pk_bf16_f32 does
+  unsigned u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+inline float bf16_value(unsigned short h) {
+  const unsigned u = (unsigned)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
 inline int conv_async_policy() {
   if (const char *e = getenv("DR_CONV_ASYNC")) return atoi(e);
   return 2;
@@ -867,7 +889,8 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   int CI = 0, PT = 0, CT = 0, TZ = 0, TY = 0, TXT = 0, TZI = 0, TYI = 0, TXI = 0, ASYNC = 0;
   struct Cand { double cost; int ci, pt, ct, tz, ty, txt, tzi, tyi, txi, async; };
   std::vector<Cand> cands;
-  const int policy = fz ? 0 : conv_async_policy();
+  const bool bf3 = conv_bf3_policy() && !fz && L.Cin % 8 == 0;  // (the Cin = 4 first layer and the fused-skip form stay on the fp32 kernels)
+  const int policy = (fz || bf3) ? 0 : conv_async_policy();
   if (policy >= 1 && ncls == 1) {  // k_conv_a: 8 waves, 8*pt position tiles per workgroup, two tile buffers
     for (int ci : {16, 8, 4}) {
       if (L.Cin % ci || (ci == 4 && L.Cin != 4)) continue;
@@ -902,7 +925,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   // k_conv_m: the stride-1 3x3 / 3x3x3 layers on the marching producer/consumer kernel (conv_march.h)
   // (a fused FeatureNet skip runs on it in exactly one form: 8-channel source, 32 -> 8 XPAIR 3x3 layer, producers compute the tile)
   const bool march_fz_ok = !fz || (fz->cin == 8 && L.Cin == 32 && L.kd == 1 && mode == CONV_XPAIR && !getenv("DR_FZ_NO_MARCH"));
-  const int march_policy = march_fz_ok ? conv_march_policy() : 0;
+  const int march_policy = (march_fz_ok && !bf3) ? conv_march_policy() : 0;
   const bool march_ok = march_policy >= 1 && ncls == 1 && !L.transposed && !L.up2 && mode != CONV_X8 && L.kh == 3 && L.kw == 3 && (L.kd == 1 || L.kd == 3) &&
                         SZ == 1 && SY == 1 && L.sw == 1;
   const int march_ntp = march_ok ? 3 * (int)cx[0].t.size() : 0;  // taps per input plane
@@ -931,7 +954,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
     }
   }
   // the row march: 2-D 3x3 stride-1 layers on the same kernel, marching down the rows of each image (async = 3)
-  const bool rowmarch_ok = !fz && conv_rowmarch_policy() >= 1 && ncls == 1 && !L.transposed && !L.up2 && mode != CONV_X8 && L.kd == 1 && L.kh == 3 && L.kw == 3 &&
+  const bool rowmarch_ok = !fz && !bf3 && conv_rowmarch_policy() >= 1 && ncls == 1 && !L.transposed && !L.up2 && mode != CONV_X8 && L.kd == 1 && L.kh == 3 && L.kw == 3 &&
                            SZ == 1 && SY == 1 && L.sw == 1 && !add;
   const int row_ntp = rowmarch_ok ? (int)cx[0].t.size() : 0;  // x taps of one row
   if (rowmarch_ok) {
@@ -961,7 +984,8 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
     if (!sync_too) break;
     if (L.Cin % ci || (ci == 4 && L.Cin != 4)) continue;
     if (fz && ci != 16) continue;  // fused-skip instances exist for 16-channel passes, one row tile
-    const int npass = L.Cin / ci, tpc = 16 / ci;
+    if (bf3 && ci == 4) continue;
+    const int npass = L.Cin / ci, tpc = (bf3 ? 32 : 16) / ci, wkb = bf3 ? 2048 : 1024;  // taps and weight bytes per K chunk (and 16 output rows)
     double chunks = 0;  // K chunks per pass summed over classes
     for (auto &c : classes) chunks += cdiv(c.ntaps, tpc);
     for (int pt : {4, 1}) {
@@ -975,13 +999,13 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
         const double tiles = (double)cdiv(nPD, c[0]) * cdiv(nPH, c[1]) * cdiv(nPW, c[2] * 16);
         for (int ct : {4, 2, 1}) {
           if (CTtot % ct || !conv_instance_exists(ci, ct) || (fz && ct != 1)) continue;
-          const size_t bytes = (size_t)tzi * tyi * txi * (ci + 4) * 4 + (size_t)nu_max * ct * 1024 + (size_t)nu_max * tpc * 4 + 64;
+          const size_t bytes = (size_t)tzi * tyi * txi * (ci + 4) * 4 + (size_t)nu_max * ct * wkb + (size_t)nu_max * tpc * 4 + 64;
           if (bytes > kConvMaxLds) continue;
           const int split = CTtot / ct;
           // cost model (cycles): MFMA issue, staging, and a latency floor per chunk; see DESIGN.md
           const double wg_per_cu = std::max(1.0, std::min({(double)(kConvMaxLds / bytes), 8.0, (ct == 4 && pt == 4) ? 5.0 : 8.0}));
           const double stage = npass * (((double)tzi * tyi * txi * (ci / 4) + (chunks / ncls) * ct * 64.0) / 256.0 * 60.0 + 900.0);
-          const double chunk_mfma = 4.0 * ct * pt * 32.0;
+          const double chunk_mfma = bf3 ? 3.0 * ct * pt * 16.0 : 4.0 * ct * pt * 32.0;  // (bf3: three 16-cycle MFMAs per 32-wide chunk)
           const double n_wg = tiles * split;  // per class
           const double mfma_total = n_wg * npass * chunks * chunk_mfma, stage_total = n_wg * ncls * stage;
           const double lat_wg = npass * (chunks / ncls) * std::max(chunk_mfma, 160.0) + stage;
@@ -1011,7 +1035,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
     R.ncand = (int)cands.size();
   }
   if (!CI) fail(DR_ERR_ARG, "plan_conv: no kernel instance / tile shape for Cin=%d Cout=%d", L.Cin, L.Cout);
-  const int npass = L.Cin / CI, TPC = 16 / CI, CIS = CI + 4;
+  const int npass = L.Cin / CI, TPC = (bf3 ? 32 : 16) / CI, CIS = CI + 4;
 
   // per-row epilogue affine
   std::vector<float> sc(rows, 1.f), bi(rows, 0.f);
@@ -1047,40 +1071,54 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
       }
     }
     const size_t w0 = pk.size();
-    pk.resize(w0 + (size_t)npass * NU * CTtot * 64 * 4, 0.f);
+    auto weight_of = [&](int tap, int cin, int row) -> float {  // the weight that multiplies input channel `cin` of tap `tap` for output row `row`
+      float v = 0.f;
+      if (tap < ntaps && row < rows_valid) {
+        if (L.up2) {  // sum of the kernel entries that fall on this (parity, input offset) pair, per axis
+          const int q = row / L.Cout, co = row % L.Cout, bits = (par_map >> (3 * q)) & 7;
+          int ky[2], kx[2];
+          const int ny = up2_kernel_set(Y.par, ty[tap], ky), nx = up2_kernel_set(bits & 1, tx[tap], kx);
+          double acc = 0;
+          for (int iy = 0; iy < ny; ++iy) for (int ix = 0; ix < nx; ++ix) acc += weight_at(co, cin, 0, ky[iy], kx[ix]);
+          v = (float)acc;
+        } else if (L.transposed) {
+          const int q = row / L.Cout, co = row % L.Cout, bits = (par_map >> (3 * q)) & 7;
+          const int offs[3] = {tz[tap], ty[tap], tx[tap]};  // for transposed layers DimTaps::t carries the input offset
+          int kk[3];
+          bool ok = true;
+          const int cpar[3] = {Z.par, Y.par, X.par};
+          for (int d = 0; d < 3; ++d) {
+            if (strided[d]) kk[d] = parity_kernel_index(dense[d] ? (bits >> (2 - d)) & 1 : cpar[d], offs[d]);
+            else kk[d] = offs[d];  // stride-1 axis: DimTaps::t is the kernel index already (k == 1 or the 3-tap flip)
+            ok = ok && kk[d] >= 0;
+          }
+          if (ok) v = weight_at(co, cin, kk[0], kk[1], kk[2]);
+        } else if (mode == CONV_NORMAL) v = weight_at(row, cin, tz[tap], ty[tap], tx[tap]);
+        else {
+          const int shift = mode == CONV_XPAIR ? (row >> 3) : row, co = mode == CONV_XPAIR ? (row & 7) : 0;
+          const int kx = tx[tap] - shift;
+          if (kx >= 0 && kx < L.kw) v = weight_at(co, cin, tz[tap], ty[tap], kx);
+        }
+      }
+      return v;
+    };
+    pk.resize(w0 + (size_t)npass * NU * CTtot * 64 * 4 * (bf3 ? 2 : 1), 0.f);
+    if (bf3) {  // [pass][chunk][row tile][hi | lo][lane] x 8 bf16: lane (i = l & 15, g = l >> 4) holds K = 32 u + 8 g .. + 7 of row 16 ct + i
+      unsigned short *pb = reinterpret_cast<unsigned short *>(pk.data() + w0);
+      for (int p = 0; p < npass; ++p) for (int u = 0; u < NU; ++u) for (int ct = 0; ct < CTtot; ++ct)
+        for (int l = 0; l < 64; ++l) for (int s = 0; s < 8; ++s) {
+          const int g = l >> 4, i = l & 15, k32 = 8 * g + s;
+          const float v = weight_of(u * TPC + k32 / CI, p * CI + k32 % CI, ct * 16 + i);
+          const unsigned short hi = bf16_rne(v), lo = bf16_rne(v - bf16_value(hi));
+          const size_t frag = (((size_t)p * NU + u) * CTtot + ct) * 2;
+          pb[((frag + 0) * 64 + l) * 8 + s] = hi;
+          pb[((frag + 1) * 64 + l) * 8 + s] = lo;
+        }
+    } else
     for (int p = 0; p < npass; ++p) for (int u = 0; u < NU; ++u) for (int ct = 0; ct < CTtot; ++ct)
       for (int l = 0; l < 64; ++l) for (int s = 0; s < 4; ++s) {
         const int g = l >> 4, i = l & 15, k16 = 4 * g + s;
-        const int tap = u * TPC + k16 / CI, cin = p * CI + k16 % CI, row = ct * 16 + i;
-        float v = 0.f;
-        if (tap < ntaps && row < rows_valid) {
-          if (L.up2) {  // sum of the kernel entries that fall on this (parity, input offset) pair, per axis
-            const int q = row / L.Cout, co = row % L.Cout, bits = (par_map >> (3 * q)) & 7;
-            int ky[2], kx[2];
-            const int ny = up2_kernel_set(Y.par, ty[tap], ky), nx = up2_kernel_set(bits & 1, tx[tap], kx);
-            double acc = 0;
-            for (int iy = 0; iy < ny; ++iy) for (int ix = 0; ix < nx; ++ix) acc += weight_at(co, cin, 0, ky[iy], kx[ix]);
-            v = (float)acc;
-          } else if (L.transposed) {
-            const int q = row / L.Cout, co = row % L.Cout, bits = (par_map >> (3 * q)) & 7;
-            const int offs[3] = {tz[tap], ty[tap], tx[tap]};  // for transposed layers DimTaps::t carries the input offset
-            int kk[3];
-            bool ok = true;
-            const int cpar[3] = {Z.par, Y.par, X.par};
-            for (int d = 0; d < 3; ++d) {
-              if (strided[d]) kk[d] = parity_kernel_index(dense[d] ? (bits >> (2 - d)) & 1 : cpar[d], offs[d]);
-              else kk[d] = offs[d];  // stride-1 axis: DimTaps::t is the kernel index already (k == 1 or the 3-tap flip)
-              ok = ok && kk[d] >= 0;
-            }
-            if (ok) v = weight_at(co, cin, kk[0], kk[1], kk[2]);
-          } else if (mode == CONV_NORMAL) v = weight_at(row, cin, tz[tap], ty[tap], tx[tap]);
-          else {
-            const int shift = mode == CONV_XPAIR ? (row >> 3) : row, co = mode == CONV_XPAIR ? (row & 7) : 0;
-            const int kx = tx[tap] - shift;
-            if (kx >= 0 && kx < L.kw) v = weight_at(co, cin, tz[tap], ty[tap], kx);
-          }
-        }
-        pk[w0 + ((((size_t)p * NU + u) * CTtot + ct) * 64 + l) * 4 + s] = v;
+        pk[w0 + ((((size_t)p * NU + u) * CTtot + ct) * 64 + l) * 4 + s] = weight_of(u * TPC + k16 / CI, p * CI + k16 % CI, ct * 16 + i);
       }
     if (L.up2) flops += ic == 0 ? 2.0 * nPD * nPH * nPW * 16.0 * L.Cin * L.Cout : 0.0;  // 4 output pixels x (2 x 2 input pixels) per input position
     else if (L.transposed) flops += ic == 0 ? 2.0 * nPD * nPH * nPW * (double)L.kd * L.kh * L.kw * L.Cin * L.Cout : 0.0;
@@ -1120,7 +1158,8 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   int nu_max = 0;
   for (auto &c : cls) nu_max = std::max(nu_max, c.NU);
   a.nuMax = nu_max;
-  cl.lds_bytes = (size_t)TZI * TYI * TXI * CIS * 4 + (size_t)nu_max * CT * 1024 + (size_t)nu_max * TPC * 4 + 64;
+  cl.lds_bytes = (size_t)TZI * TYI * TXI * CIS * 4 + (size_t)nu_max * CT * (bf3 ? 2048 : 1024) + (size_t)nu_max * TPC * 4 + 64;
+  cl.bf3 = bf3 ? 1 : 0;
   a.zero16 = nullptr; a.a_slots = 0; a.a_wbufs = 1;
   if (ASYNC == 1) {
     cl.async = 1;
@@ -1197,6 +1236,12 @@ inline void launch_conv_inst(const ConvLaunch &c, hipStream_t st) {
   hipLaunchKernelGGL((k_conv<CI, CT, PT, FZ>), c.grid, dim3(kConvThreads), c.lds_bytes, st, c.args);
 }
 template <int CI, int CT, int PT>
+inline void launch_conv_b_inst(const ConvLaunch &c, hipStream_t st) {
+  static std::atomic<unsigned long long> done{0};
+  conv_allow_big_lds(reinterpret_cast<const void *>(&k_conv_b<CI, CT, PT>), done, c.lds_bytes);
+  hipLaunchKernelGGL((k_conv_b<CI, CT, PT>), c.grid, dim3(kConvThreads), c.lds_bytes, st, c.args);
+}
+template <int CI, int CT, int PT>
 inline void launch_conv_a_inst(const ConvLaunch &c, hipStream_t st) {
   static std::atomic<unsigned long long> done{0};
   conv_allow_big_lds(reinterpret_cast<const void *>(&k_conv_a<CI, CT, PT>), done, c.lds_bytes);
@@ -1209,6 +1254,22 @@ inline void launch_conv_m_inst(const ConvLaunch &c, hipStream_t st) {
   hipLaunchKernelGGL((k_conv_m<CI, NUP, CT, PT, FZ, NCW>), c.grid, dim3(64 * (NCW + (FZ ? kMarchFzProducers : kMarchProducers))), c.lds_bytes, st, c.args, c.march);
 }
 inline void launch_conv(const ConvLaunch &c, hipStream_t st) {
+  if (c.bf3) {
+#define DR_CONV_B_CASE(CI_, CT_)                                                \
+  if (c.ci == CI_ && c.ct == CT_ && !c.async && !c.fz) {                        \
+    if (c.pt == 4) launch_conv_b_inst<CI_, CT_, 4>(c, st);                      \
+    else launch_conv_b_inst<CI_, CT_, 1>(c, st);                                \
+    return;                                                                     \
+  }
+    DR_CONV_B_CASE(8, 1)
+    DR_CONV_B_CASE(8, 2)
+    DR_CONV_B_CASE(8, 4)
+    DR_CONV_B_CASE(16, 1)
+    DR_CONV_B_CASE(16, 2)
+    DR_CONV_B_CASE(16, 4)
+#undef DR_CONV_B_CASE
+    fail(DR_ERR_ARG, "launch_conv: no bf16x3 instance CI=%d CT=%d", c.ci, c.ct);
+  }
   if (c.async == 2 && c.fz) {
     if (c.fz != 8 || c.ci != 16 || c.nup != 12 || c.ct != 1 || c.ncw != 8) fail(DR_ERR_ARG, "launch_conv: no fused-skip marching instance FZ=%d CI=%d NUP=%d CT=%d", c.fz, c.ci, c.nup, c.ct);
     if (c.pt == 4) launch_conv_m_inst<16, 12, 1, 4, 8>(c, st);

@@ -421,6 +421,7 @@ class MvsEngine {
       char kn[64] = "misc";
       if (o.kind == Op::CONV && o.conv.async == 2) snprintf(kn, sizeof kn, "k_conv_m<%d,%d,%d,%d,%d,%d>", o.conv.ci, o.conv.nup, o.conv.ct, o.conv.pt, o.conv.fz, o.conv.ncw);  // rocprofv3's spelling of the instance
       else if (o.kind == Op::CONV && o.conv.async) snprintf(kn, sizeof kn, "k_conv_a<%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt);
+      else if (o.kind == Op::CONV && o.conv.bf3) snprintf(kn, sizeof kn, "k_conv_b<%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt);
       else if (o.kind == Op::CONV) snprintf(kn, sizeof kn, "k_conv<%d,%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt, o.conv.fz);
       else if (o.kind == Op::COSTVOL) snprintf(kn, sizeof kn, costvol_v1_ ? "k_costvol<%d>" : (costvol_v2_ ? "k_costvol2<%d>" : "k_costvol3<%d>"), 32 >> (o.stage - 1));
       else if (o.kind == Op::PROB) snprintf(kn, sizeof kn, getenv("DR_PROB_V1") ? "k_prob" : "k_prob2");
@@ -1195,7 +1196,7 @@ int drm_debug_conv(int device, const float *in, int D, int H, int W, int Cin, co
     if (march_err) fail(DR_ERR_DEVICE, "k_conv_m: a ring wait gave up (code %d)", march_err);
     if (getenv("DR_CONV_PRINT")) {
       const ConvLaunch &c = P.launches.at(0);
-      fprintf(stderr, "debug_conv: %s<%d,%d,%d> nup %d tile %dx%dx%d lds %zu grid %ux%u (%d candidates)\n", (c.async == 2 ? (c.march.rm ? "rowmarch" : "march") : (c.async ? "async" : "sync")), c.ci, c.ct, c.pt,
+      fprintf(stderr, "debug_conv: %s<%d,%d,%d> nup %d tile %dx%dx%d lds %zu grid %ux%u (%d candidates)\n", (c.async == 2 ? (c.march.rm ? "rowmarch" : "march") : (c.async ? "async" : (c.bf3 ? "bf16x3" : "sync"))), c.ci, c.ct, c.pt,
               c.nup, c.args.TZ, c.args.TY, c.args.TXT * 16, c.lds_bytes, c.grid.x, c.grid.z, P.ncand);
     }
     DR_HIP(hipMemcpy(out, d_out, on * 4, hipMemcpyDeviceToHost));

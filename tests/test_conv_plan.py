@@ -27,6 +27,7 @@ def conv_emul(tmp_path_factory):
 def test_generic_kernel_emulation_matches_the_layer_definitions(conv_emul, form):
     env = dict(os.environ)
     env.pop("DR_DECONV_FORM", None)
+    env.pop("DR_CONV_BF16X3", None)
     if form != "default":
         env["DR_DECONV_FORM"] = form
     out = subprocess.run([conv_emul, "12"], capture_output=True, text=True, timeout=600, env=env)
@@ -40,6 +41,27 @@ def test_generic_kernel_emulation_matches_the_layer_definitions(conv_emul, form)
         assert ("classes 4" in text) or ("classes 8" in text)
     if form == "0":
         assert "classes 4" not in text and "classes 8" not in text
+
+
+def test_bf16x3_kernel_emulation_matches_the_layer_definitions(conv_emul):
+    """The opt-in precision mode (DR_CONV_BF16X3=1, tandem_amd/csrc/conv_bf3.h): every layer with Cin % 8 == 0 is planned for k_conv_b
+    -- 32-wide K chunks, weights packed as hi / lo bf16 fragments -- and emulated with the kernel's byte layout of the staged tile
+    ([CI hi | CI lo | pad] records), its operand gathers and three bf16 products per term pair; the error against the layer's
+    definition is the three-term split's (~1e-5 of the value range), an order above fp32 reassociation and three below plain bf16.
+    The first layer (Cin = 4) stays on the fp32 kernel."""
+    env = dict(os.environ)
+    env.pop("DR_DECONV_FORM", None)
+    env["DR_CONV_BF16X3"] = "1"
+    out = subprocess.run([conv_emul, "12"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if " plan rank " in l]
+    assert len(lines) >= 60 and all(": ok " in l for l in lines), out.stdout[-4000:]
+    b = [l for l in lines if " k_conv_b " in l]
+    assert len(b) >= 50 and all("xpair2d_4_8" in l for l in lines if " k_conv " in l), out.stdout[-4000:]
+    errs = [float(l.split("max rel err ")[1].rstrip(")")) for l in b]
+    assert 1e-6 < max(errs) < 1e-4, max(errs)  # really the split arithmetic, and no worse than it should be
+    for needle in ("conv2d_5x5_s2_8_16", "deconv_64_32_s122", "up2_32_8_inplace_add", "xpair3d_16_8", "x8_prob_8_1", "ci=8 "):
+        assert any(needle in l for l in b), needle
 
 
 def test_persistent_kernel_emulation_matches_the_layer_definitions(conv_emul):
