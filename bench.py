@@ -32,18 +32,42 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+def source_stamp():
+    """sha1 over the HIP sources the library is built from: the stamp a PMC profile carries (tools/pmc_to_json.py) and this
+    run compares, so that counters of another tree are never reported as this run's."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "tandem_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "tandem_amd", "csrc", "*.hip"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r*_pmc_traffic.json, written by
-    tools/gpu_pmc_traffic.sh + tools/pmc_to_json.py on the same workload; counters cannot be read from inside this
-    process).  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950; returns None if no profile exists."""
+    tools/gpu_r4_final.sh + tools/pmc_to_json.py on the same workload; counters cannot be read from inside this process).
+    FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.  None when there is no profile, when the profile
+    does not carry THIS tree's source stamp (a stale file is refused, not reported), or when it lacks the kernel."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
         return None
-    e = json.load(open(files[-1])).get(kernel)
+    prof = json.load(open(files[-1]))
+    if prof.get("_meta", {}).get("source_stamp") != source_stamp():
+        return None
+    e = prof.get(kernel)
     if not e or "fetch_bytes_corrected" not in e or "write_bytes" not in e:
         return None
     return e["fetch_bytes_corrected"] + e["write_bytes"]
+
+
+def pmc_profile_state():
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return "no PMC profile committed"
+    st = json.load(open(files[-1])).get("_meta", {}).get("source_stamp")
+    return "%s: %s" % (os.path.basename(files[-1]), "matches this tree's sources" if st == source_stamp() else "STALE (source stamp %s, tree %s): traffic reported as null" % (st, source_stamp()))
 
 
 def host_cores():
@@ -69,6 +93,9 @@ PEAK_HBM_GBPS = 8000.0          # HBM3E spec peak (6.3 TB/s measured achievable)
 H, W, V = 480, 640, 7
 PLANES = (48, 32, 8)
 DISCARD = 10.0                  # TANDEM's mvsnet_discard_percentage default (settings.cpp:300)
+# the headline window is run at the depth range eval.py / export_model.py pass (cva_mvsnet/eval.py:31-32);
+# the scene's own range (synth/scene.py: 0.5 .. 5.0, what the parity tests use) rides along as `scene_depth_range`.
+DEPTH_MIN, DEPTH_MAX = 0.01, 10.0
 
 
 _BLOB = {}
@@ -103,7 +130,7 @@ def mvsnet_leg(args, rank, dev, world):
     for e in range(E):
         win = scene.make_window(H, W, V, seed=rank * 16 + e)
         m = DrMvsnet(blob, device=dev)
-        m.upload(H, W, V, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), win["depth_min"], win["depth_max"], DISCARD)
+        m.upload(H, W, V, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), DEPTH_MIN, DEPTH_MAX, DISCARD)
         if args.warmup > 0:
             m.forward(args.warmup)
         engines.append(m); wins.append(win)
@@ -165,6 +192,14 @@ def mvsnet_leg(args, rank, dev, world):
                                tflops=flops / step_s / 1e12, frac_mfma=flops / step_s / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                                gbps=nbytes / step_s / 1e9, frac_hbm=nbytes / step_s / 1e9 / PEAK_HBM_GBPS,
                                kernels={k: round(v["ms"], 4) for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])})
+        res["roofline"]["traffic_source"] = pmc_profile_state()
+        # the same window at the scene's own depth range (synth/scene.py: 0.5 .. 5.0 m, what the parity tests run): the FLOPs do
+        # not change with the range, the gather footprint of the cost-volume kernels does
+        m.upload(H, W, V, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), win["depth_min"], win["depth_max"], DISCARD)
+        m.forward(5)
+        nalt = max(10, min(60, args.steps))
+        alt = m.forward(nalt) / nalt
+        res["scene_depth_range"] = dict(depth_min=win["depth_min"], depth_max=win["depth_max"], single_window_ms=alt, forwards=nalt)
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = mvsnet_cpu_baseline(win, blob)
     m.close()
@@ -188,22 +223,22 @@ def mvsnet_cpu_baseline(win, blob):
             from oracle import mvsnet_oracle as O, ref_model
             net, cva = ref_model.build(PLANES, tens, view_aggregation=True)
             image, Ks, c2w = O.preprocess(win["bgrs"], win["K"], win["c2ws"], win["ref_index"])
-            run = lambda: ref_model.run(net, cva, image, Ks, c2w, win["depth_min"], win["depth_max"], DISCARD)
+            run = lambda: ref_model.run(net, cva, image, Ks, c2w, DEPTH_MIN, DEPTH_MAX, DISCARD)
             kind = "reference"
         except Exception as e:  # fall back to the port, say why
             print("bench.py: reference model not usable (%s); timing the port" % e, file=sys.stderr)
     if run is None:
         from oracle import mvsnet_oracle as O
         w = O.Weights(meta, tens)
-        run = lambda: O.forward(w, win["bgrs"], win["K"], win["c2ws"], win["ref_index"], win["depth_min"], win["depth_max"], DISCARD)
+        run = lambda: O.forward(w, win["bgrs"], win["K"], win["c2ws"], win["ref_index"], DEPTH_MIN, DEPTH_MAX, DISCARD)
     run()  # warm-up
     times = []
     while len(times) < 5 and sum(times) < 90.0:  # >= 5 timed forwards (about 11 s each on the GPU box's host)
         t0 = time.perf_counter(); run(); times.append(time.perf_counter() - t0)
     med = sorted(times)[len(times) // 2]
     return dict(value=1.0 / med, unit="depth-maps/s", cores=torch.get_num_threads(), physical_cores=phys, logical_cpus=logical, kind=kind,
-                sample="%d timed forwards of the same %dx%dx7-view (%d,%d,%d) window after 1 warm-up, torch CPU fp32, %d threads; median %.2f s, best %.2f s"
-                       % ((len(times), W, H) + PLANES + (torch.get_num_threads(), med, min(times))))
+                sample="%d timed forwards of the same %dx%dx7-view (%d,%d,%d) window (depth range %g .. %g) after 1 warm-up, torch CPU fp32, %d threads; median %.2f s, best %.2f s"
+                       % ((len(times), W, H) + PLANES + (DEPTH_MIN, DEPTH_MAX, torch.get_num_threads(), med, min(times))))
 
 
 def shipped_leg(args, dev):
@@ -224,7 +259,7 @@ def shipped_leg(args, dev):
         for e in range(3):
             win = scene.make_window(h, w, V, seed=60 + e)
             m = DrMvsnet(blob, device=dev)
-            m.upload(h, w, V, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), win["depth_min"], win["depth_max"], DISCARD)
+            m.upload(h, w, V, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), DEPTH_MIN, DEPTH_MAX, DISCARD)
             m.forward(5)
             engines.append(m)
         n1 = max(20, min(200, args.steps))
@@ -265,7 +300,7 @@ def boundary_leg(args, dev):
             m, w = engines[e], wins[e]
             for _ in range(n):
                 t0 = time.perf_counter()
-                m.CallAsync(H, W, V, w["ref_index"], w["bgrs"], w["K"], list(w["c2ws"]), w["depth_min"], w["depth_max"], DISCARD)
+                m.CallAsync(H, W, V, w["ref_index"], w["bgrs"], w["K"], list(w["c2ws"]), DEPTH_MIN, DEPTH_MAX, DISCARD)
                 call_ms[e] += 1e3 * (time.perf_counter() - t0)
                 m.GetResult()
         for e in range(E):
@@ -465,7 +500,7 @@ def view_shard_leg(args, rank, dev, world):
     steps, warmup = min(args.steps, 20), 2
     win = scene.make_window(H, W, V, seed=0)  # the SAME window on every rank
     window = dict(bgrs=win["bgrs"], K=win["K"], c2ws=list(win["c2ws"]), ref_index=win["ref_index"],
-                  depth_min=win["depth_min"], depth_max=win["depth_max"], discard=DISCARD)
+                  depth_min=DEPTH_MIN, depth_max=DEPTH_MAX, discard=DISCARD)
     m = DrMvsnet(model_blob(), device=dev)
     one_dev = os.environ.get("DR_BENCH_ONE_DEVICE") == "1"  # test scaffold: RCCL refuses two ranks on one device
     P = view_shard.shard_world(V, world)  # at most one rank per source view takes part (8 GPUs, 6 source views: two stay out)
@@ -535,6 +570,9 @@ def tsdf_cpu_baseline(scans, opt):
         key = "openmp" if omp else "single"
         out[key] = dict(value=st["updated_total"] / t, frames=n, seconds=t, cores=phys if omp else 1, mismatches=st["mismatches"])
     best = out.get("openmp", out["single"])
+    if best is not out["single"] and best["mismatches"] != 0:  # blocks were NOT independent in the parallel run: its figure is void
+        out["openmp"]["void"] = "round-trip mismatches != 0: the OpenMP integration raced; single-core figure reported"
+        best = out["single"]
     return dict(value=best["value"], unit="voxels/s", cores=best["cores"], kind="port", single_core=out["single"], openmp=out.get("openmp"),
                 sample="allocate + integrate of the first %d of the same frames, C restatement (oracle/tsdf_oracle.c, pinned to the reference build by "
                        "tests/test_ref_fusion.py): one core, and integration parallel over blocks with OpenMP on %d physical cores (allocation serial)"
@@ -627,13 +665,20 @@ def main():
                                    "independent windows, %d in flight per GPU (one DrMvsnet engine each) x %d GPU replica(s); trained weights recovered from the reference's exported "
                                    "tandem_512x320 model (same architecture), inputs resident in HBM" % (mv["engines_per_gpu"], world),
                        "height": H, "width": W, "views": V, "planes": list(PLANES), "discard_percentage": DISCARD, "name": args.config,
+                       "depth_min": DEPTH_MIN, "depth_max": DEPTH_MAX,
                        "parallelism": "replicas x%d, %d engines per GPU" % (world, mv["engines_per_gpu"]),
                        "reference_published": "2.70 FPS (abl03, unstated GPU, incl. data loading) -- not the same clock, so vs_baseline is null"},
             "event_ms_per_step": mv["event_ms_per_step"],
         }
-        for k in ("repeats", "roofline", "cpu_baseline", "pipeline", "engines_per_gpu", "single_engine"):
+        for k in ("repeats", "roofline", "cpu_baseline", "pipeline", "engines_per_gpu", "single_engine", "scene_depth_range"):
             if k in mv:
                 out[k] = mv[k]
+        # TANDEM's usage is ONE window in flight (tandem_backend.cpp:147): its latency and the operator boundary's rate as flat keys
+        if "single_engine" in mv:
+            out["single_window_ms"] = mv["single_engine"]["ms_per_depth_map"]
+        if bd is not None and "engines_1" in bd:
+            out["boundary_single_engine_ms"] = bd["engines_1"]["ms_per_depth_map_per_engine"]
+            out["boundary_single_engine_depth_maps_per_s"] = bd["engines_1"]["depth_maps_per_s"]
         if ts is not None:
             out["tsdf"] = ts
         if bd is not None:

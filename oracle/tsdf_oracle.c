@@ -310,7 +310,12 @@ static int update_voxel(tsdf_t *t, f3 wp, const voxel_t *v, int from_block, int 
   int b = find_block(t, world_to_block(t, wp));
   if (b < 0) return 0;
   int li = local_index(t, world_to_local_voxel(t, wp));
-  if (b != from_block || li != from_index) t->mismatches++;
+  if (b != from_block || li != from_index) {
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+    t->mismatches++;
+  }
   combine(&t->vox[(size_t)b * nvox(t) + li], v, (unsigned char)t->o.max_sdf_weight);
   return 1;
 }

@@ -314,6 +314,8 @@ class MvsEngine {
       t_before += t0; t_after += best;
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    DR_HIP(hipStreamSynchronize(stream_));
+    check_march();
     if (before_ms) *before_ms = (float)t_before;
     if (after_ms) *after_ms = (float)t_after;
   }
@@ -383,6 +385,7 @@ class MvsEngine {
     DR_HIP(hipMemcpyAsync(depth_dense, T("depth3").d, n, hipMemcpyDeviceToHost, stream_));
     DR_HIP(hipMemcpyAsync(conf_dense, T("conf3").d, n, hipMemcpyDeviceToHost, stream_));
     DR_HIP(hipStreamSynchronize(stream_));
+    check_march();
   }
   void get_tensor(const char *name, float *out, size_t n_max, size_t *n, int dims[4]) {
     std::unique_lock<std::mutex> lk(mu_);
@@ -395,6 +398,7 @@ class MvsEngine {
     if (out) {
       if (logical > n_max) fail(DR_ERR_ARG, "get_tensor(%s): need %zu floats, have %zu", name, logical, n_max);
       DR_HIP(hipStreamSynchronize(stream_));
+      check_march();
       if (!t.pad) DR_HIP(hipMemcpy(out, t.d, logical * 4, hipMemcpyDeviceToHost));
       else  // bordered tensor: the caller gets the logical (D, H, W, C) block
         for (int z = 0; z < t.D; ++z)
@@ -412,6 +416,7 @@ class MvsEngine {
     for (auto &e : ev) DR_HIP(hipEventCreate(&e));
     forward(&ev);
     DR_HIP(hipStreamSynchronize(stream_));
+    check_march();
     names.clear(); ms.clear();
     for (size_t i = 0; i < ops_.size(); ++i) {
       float t = 0;
@@ -885,8 +890,6 @@ class MvsEngine {
         }
         case Op::CONV:
           launch_conv(o.conv, stream_);
-          if (on_side && i - 1 == feat2_op_) DR_HIP(hipEventRecord(ev_feat2_, side_));
-          if (on_side && i - 1 == fork_hi_ - 1) DR_HIP(hipEventRecord(ev_feat3_, side_));
           break;
         case Op::BORDERFIX: {
           const int per = 2 * (o.d1 + o.d2) - 4, n = o.d0 * per * 8;
@@ -937,6 +940,10 @@ class MvsEngine {
           // projection / tap arithmetic.  DR_COSTVOL_CPL=4|8 overrides (A/B hook).
           int cpl = C >= 16 ? cpl_wide_ : 4;
           const int pxb = 256 / (C / cpl);
+          if (a.V - 1 <= 0) {  // a view-shard rank that holds the reference view only: its partial volume is the empty sum (the kernels return without storing)
+            const DevTensor &vol0 = T("volume" + std::to_string(o.stage));
+            DR_HIP(hipMemsetAsync(vol0.d, 0, vol0.n() * 4, stream_));
+          }
           CostVolArgs b = a;
           b.gx = cdiv(a.w, pxb); b.gz = cdiv(a.planes.D, a.dchunk); b.nwg = b.gx * b.gz * a.h;
           dim3 grid(8 * cdiv(b.nwg, 8));
@@ -1005,6 +1012,10 @@ class MvsEngine {
                              T("depth").d, T("confidence").d, H_ * W_);
           break;
       }
+      // the side stream's results are published after whichever op ends them (fn.out2; the LAST op of the fork range: a
+      // convolution in the fused-skip form, the border kernel in the folded form) -- independent of the op kind
+      if (on_side && i - 1 == feat2_op_) DR_HIP(hipEventRecord(ev_feat2_, side_));
+      if (on_side && i - 1 == fork_hi_ - 1) DR_HIP(hipEventRecord(ev_feat3_, side_));
     }
     if (ev) DR_HIP(hipEventRecord((*ev)[i], stream_));
     DR_HIP(hipGetLastError());

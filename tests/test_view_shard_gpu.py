@@ -40,12 +40,15 @@ def run_sharded(blob, window, world):
     subs = [view_shard.upload(m, window, r, world) for r, m in enumerate(models)]
     reduce_all = host_allreduce(models)
     parts_log = {}
-    for p in range(3):
+    # TWO forwards on the same engines: after the first one every volume holds the reduced sum of all ranks, so a rank whose
+    # partial volume is the empty sum (reference view only) must actively zero it -- a fresh allocation hides that
+    for _ in range(2):
+        for p in range(3):
+            for m in models:
+                m.forward_phase(p)
+            parts_log[p + 1] = reduce_all("volume%d" % (p + 1))
         for m in models:
-            m.forward_phase(p)
-        parts_log[p + 1] = reduce_all("volume%d" % (p + 1))
-    for m in models:
-        m.forward_phase(3)
+            m.forward_phase(3)
     outs = [m.download() for m in models]
     for m in models:
         m.close()

@@ -25,5 +25,10 @@ for n, c in acc.items():
     if "SQ_VALU_MFMA_BUSY_CYCLES" in e and e.get("GRBM_GUI_ACTIVE"):
         e["mfma_util"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["GRBM_GUI_ACTIVE"] / 8 * 1024)  # GUI_ACTIVE is summed over 8 XCDs
     out[n] = e
+# stamp: the sources these counters were taken on (bench.py refuses a profile whose stamp differs from its own tree's)
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+out["_meta"] = {"source_stamp": bench.source_stamp(), "kernels": sorted(out)}
 json.dump(out, open(sys.argv[1], "w"), indent=1, sort_keys=True)
 print("wrote", sys.argv[1], len(out), "kernels")
