@@ -392,9 +392,13 @@ def tsdf_leg(args, rank, dev, world):
 
 
 def tandem_loop_leg(args, dev):
-    """BASELINE configs[4] stand-in (the DSO front-end cannot run here): TandemBackend's call order through the C++ shim,
-    tools/tandem_loop.cpp compiled with g++ against tandem_amd/libdr/*.h and the C ABI -- CallAsync(k) beside
-    IntegrateScanAsync / RenderAsync / GetRenderResult of k-1 -- on this GPU, host buffers at the boundary."""
+    """BASELINE configs[4] stand-in (the DSO front-end cannot run here).  Driver: the REFERENCE's own TandemBackend
+    (tandem/src/tandem/tandem_backend.cpp, compiled UNCHANGED against tandem_amd/libdr/*.h by oracle/Makefile.ref ->
+    oracle/_ref/tandem_backend_run; tools/tandem_backend_main.cpp plays FullSystem::deliverDrFrame): GetResult(k-1), CallAsync(k),
+    IntegrateScanAsync / RenderAsync / GetRenderResult of k-1, the tracker's depth-map hand-over, all in the reference's code and
+    order, on this GPU, host buffers at the boundary.  What is measured is libdr_mi355x.so; the binary is the reference's caller,
+    not a checker.  Where that binary was not built (no reference checkout at build time) the hand-written imitation of the same
+    call order, tools/tandem_loop.cpp, is compiled and timed instead; `driver` in the result says which one ran."""
     import subprocess
     import tempfile
     from synth import scene
@@ -402,27 +406,33 @@ def tandem_loop_leg(args, dev):
     from export_fixture import write_tdms
     out = {}
     with tempfile.TemporaryDirectory() as td:
-        exe = os.path.join(td, "tandem_loop")
-        try:
-            subprocess.check_call(["g++", "-std=c++14", "-O2", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tandem_amd", "libdr"),
-                                   os.path.join(ROOT, "tools", "tandem_loop.cpp"), "-o", exe, "-L" + os.path.join(ROOT, "tandem_amd"),
-                                   "-ldr_mi355x", "-Wl,-rpath," + os.path.join(ROOT, "tandem_amd")])
-        except (OSError, subprocess.CalledProcessError) as e:
-            return dict(error="g++ build of tools/tandem_loop.cpp failed: %s" % e)
+        exe = os.path.join(ROOT, "oracle", "_ref", "tandem_backend_run")
+        if not os.path.isfile(exe):
+            exe = os.path.join(td, "tandem_loop")
+            try:
+                subprocess.check_call(["g++", "-std=c++14", "-O2", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tandem_amd", "libdr"),
+                                       os.path.join(ROOT, "tools", "tandem_loop.cpp"), "-o", exe, "-L" + os.path.join(ROOT, "tandem_amd"),
+                                       "-ldr_mi355x", "-Wl,-rpath," + os.path.join(ROOT, "tandem_amd")])
+            except (OSError, subprocess.CalledProcessError) as e:
+                return dict(error="g++ build of tools/tandem_loop.cpp failed: %s" % e)
         blob = os.path.join(ROOT, "weights", "tandem_va.tdmw")
         for name, (h, w, vs) in (("640x480_5mm", (480, 640, "0.005")), ("640x480_10mm", (480, 640, "0.01"))):
             win = scene.make_window(h, w, V, seed=5)
             sample = os.path.join(td, name + ".tdms")
             z = np.zeros((h, w), np.float32)
-            write_tdms(sample, np.stack(win["bgrs"]), win["K"], win["c2ws"], win["ref_index"], win["depth_min"], win["depth_max"], DISCARD, z, z)
+            # depth range: TANDEM passes depth_min = 0.01 (FullSystem.h:388) and 3 x the 0.2-quantile of the tracker's sparse depths
+            # (FullSystem.cpp:1175-1193): here that quantile is taken from the window's ground-truth depth
+            dmax = 3.0 * float(np.quantile(win["gt_depth"], 0.2))
+            write_tdms(sample, np.stack(win["bgrs"]), win["K"], win["c2ws"], win["ref_index"], 0.01, dmax, DISCARD, z, z)
             env = dict(os.environ, HIP_VISIBLE_DEVICES=str(dev)) if dev else dict(os.environ)
             r = subprocess.run([exe, blob, sample, str(args.loop_keyframes), vs, "0", "1"], capture_output=True, text=True, timeout=900, env=env)
             if r.returncode != 0:
                 out[name] = dict(error=(r.stdout + r.stderr)[-500:])
                 continue
             out[name] = json.loads(r.stdout.strip().splitlines()[-1])
-    out["note"] = ("tandem_backend.cpp:137-283 call order through the header-compatible shim; depth network of keyframe k overlaps fusion + "
-                   "ray-cast of keyframe k-1; (48,32,8) planes, discard 10 %, dense tracking render on; TANDEM's own setting is 10 mm")
+            out[name]["depth_range"] = [0.01, dmax]
+    out["note"] = ("tandem_backend.cpp's own call order (the reference's file, unchanged, where oracle/_ref/tandem_backend_run exists); depth network of "
+                   "keyframe k overlaps fusion + ray-cast of keyframe k-1; (48,32,8) planes, discard 10 %, dense tracking render on; TANDEM's own setting is 10 mm")
     return out
 
 

@@ -29,7 +29,11 @@ CASES = [  # name, H, W, V, planes, discard, weights, view_aggregation
     # cva_mvsnet/configs/abl04_fewer_depth_planes.yaml:8) and BASELINE configs[0] (320x256, ref + 2 src)
     ("v7_320x512_shipped", 320, 512, 7, (48, 4, 4), 10.0, "trained", True),
     ("v3_256x320_cfg0", 256, 320, 3, (48, 32, 8), 10.0, "trained", True),
+    # BASELINE configs[1], the shape and depth range the headline metric is quoted on (640x480, ref + 6 src, planes
+    # (48,32,8), depth_min / depth_max = 0.01 / 10.0 as cva_mvsnet/eval.py:31-32 passes them), TANDEM's discard percentage
+    ("v7_480x640_headline", 480, 640, 7, (48, 32, 8), 10.0, "trained", True),
 ]
+DEPTH_RANGE = {"v7_480x640_headline": (0.01, 10.0)}  # cases that do not use the scene's own range (0.5 .. 5.0)
 
 
 def main():
@@ -50,6 +54,8 @@ def main():
             state = Wt.random_state(planes, seed=7)
         net, cva = ref_model.build(planes, state, view_aggregation=va)
         win = scene.make_window(H, Wd, V, seed=len(name))
+        if name in DEPTH_RANGE:
+            win["depth_min"], win["depth_max"] = DEPTH_RANGE[name]
         w = O.Weights(dict(depth_num=planes, interval_ratio=(1.0, 0.5, 0.25), view_aggregation=va,
                            base_channels=8), state)
         image, Ks, c2w = O.preprocess(win["bgrs"], win["K"], win["c2ws"], win["ref_index"])

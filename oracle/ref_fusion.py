@@ -13,33 +13,34 @@ from .tsdf_oracle import Options
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_ref", "libdr_fusion_ref.so")
+_SO_FMA = os.path.join(_HERE, "_ref", "libdr_fusion_ref_fma.so")  # the same sources with -ffp-contract=fast -mfma (Makefile.ref)
 _REF = os.environ.get("TANDEM_REFERENCE", "/root/reference")
 
 
-def build():
+def build(fma=False):
     """(Re)build from the reference checkout when it exists; otherwise use the prebuilt library as it is."""
+    so = _SO_FMA if fma else _SO
     if os.path.isdir(os.path.join(_REF, "tandem", "libdr", "dr_fusion", "src")):
-        subprocess.check_call(["make", "-s", "-f", "oracle/Makefile.ref", "REF=" + _REF, "oracle/_ref/libdr_fusion_ref.so"],
+        subprocess.check_call(["make", "-s", "-f", "oracle/Makefile.ref", "REF=" + _REF, os.path.relpath(so, os.path.dirname(_HERE))],
                               cwd=os.path.dirname(_HERE))
-    return _SO if os.path.isfile(_SO) else None
+    return so if os.path.isfile(so) else None
 
 
-def available():
+def available(fma=False):
     try:
-        return build() is not None
+        return build(fma) is not None
     except Exception:
         return False
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        so = build()
+def lib(fma=False):
+    if fma not in _libs:
+        so = build(fma)
         if so is None:
-            raise RuntimeError("oracle/_ref/libdr_fusion_ref.so is missing and /root/reference is not present")
+            raise RuntimeError("%s is missing and /root/reference is not present" % (_SO_FMA if fma else _SO))
         L = C.CDLL(so)
         L.refdrf_create.restype = C.c_void_p
         L.refdrf_create.argtypes = [C.POINTER(Options)]
@@ -62,21 +63,22 @@ def lib():
         L.ref_xform.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.ref_world_maps.argtypes = [C.c_void_p] * 6
         L.ref_hash.argtypes = [C.c_void_p, C.c_void_p]
-        _lib = L
-    return _lib
+        _libs[fma] = L
+    return _libs[fma]
 
 
 class RefFusion:
     """The reference DrFusion on the host (serial kernels).  The reference's mandatory call order is kept:
     integrate -> render (exactly num_render_streams poses) -> ... (tsdf_volume.cu:520-524,635-653)."""
 
-    def __init__(self, **opts):
+    def __init__(self, fma=False, **opts):
         self.o = Options(**opts)
-        self._h = lib().refdrf_create(C.byref(self.o))
+        self._fma = fma  # True: the contracted twin (libdr_fusion_ref_fma.so)
+        self._h = lib(fma).refdrf_create(C.byref(self.o))
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().refdrf_destroy(self._h)
+            lib(self._fma).refdrf_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -86,7 +88,7 @@ class RefFusion:
         bgr = np.ascontiguousarray(bgr, np.uint8)
         depth = np.ascontiguousarray(depth, np.float32)
         pose = np.ascontiguousarray(pose, np.float32).reshape(16)
-        lib().refdrf_integrate(self._h, bgr.ctypes.data, depth.ctypes.data, pose.ctypes.data)
+        lib(self._fma).refdrf_integrate(self._h, bgr.ctypes.data, depth.ctypes.data, pose.ctypes.data)
         return 0
 
     def render(self, poses):
@@ -100,25 +102,25 @@ class RefFusion:
         pp = (C.c_void_p * n)(*[p.ctypes.data for p in ps])
         bp = (C.c_void_p * n)(*[b.ctypes.data for b in bs])
         dp = (C.c_void_p * n)(*[d.ctypes.data for d in ds])
-        lib().refdrf_render(self._h, pp, n, bp, dp)
+        lib(self._fma).refdrf_render(self._h, pp, n, bp, dp)
         return list(zip(bs, ds))
 
     def num_blocks(self):
-        return lib().refdrf_num_blocks(self._h)
+        return lib(self._fma).refdrf_num_blocks(self._h)
 
     def export_blocks(self):
         n = self.num_blocks()
         nv = self.o.block_size ** 3
         coords = np.empty((max(n, 1), 3), np.int32)
         vox = np.empty((max(n, 1), nv * 8), np.uint8)
-        got = lib().refdrf_export_blocks(self._h, n, coords.ctypes.data, vox.ctypes.data)
+        got = lib(self._fma).refdrf_export_blocks(self._h, n, coords.ctypes.data, vox.ctypes.data)
         return {tuple(int(v) for v in coords[i]): vox[i] for i in range(got)}
 
     def extract_mesh(self, lower, upper, max_tri=2_000_000):
         lo = np.ascontiguousarray(lower, np.float32)
         up = np.ascontiguousarray(upper, np.float32)
         vert, cols = np.empty((max_tri * 3, 3), np.float32), np.empty((max_tri * 3, 3), np.float32)
-        n = lib().refdrf_get_mesh(self._h, lo.ctypes.data, up.ctypes.data, max_tri, vert.ctypes.data, cols.ctypes.data)
+        n = lib(self._fma).refdrf_get_mesh(self._h, lo.ctypes.data, up.ctypes.data, max_tri, vert.ctypes.data, cols.ctypes.data)
         if n > max_tri:
             raise RuntimeError("reference mesh has %d triangles > max_tri=%d" % (n, max_tri))
         return vert[:3 * n].copy(), cols[:3 * n].copy()
@@ -127,9 +129,9 @@ class RefFusion:
         p = np.ascontiguousarray(p, np.float32)
         g, b, l = (np.empty(3, np.int32) for _ in range(3))
         w = np.empty(3, np.float32)
-        lib().ref_world_maps(self._h, p.ctypes.data, g.ctypes.data, b.ctypes.data, l.ctypes.data, w.ctypes.data)
+        lib(self._fma).ref_world_maps(self._h, p.ctypes.data, g.ctypes.data, b.ctypes.data, l.ctypes.data, w.ctypes.data)
         return g, b, l, w
 
     def hash(self, p):
         p = np.ascontiguousarray(p, np.int32)
-        return lib().ref_hash(self._h, p.ctypes.data)
+        return lib(self._fma).ref_hash(self._h, p.ctypes.data)

@@ -108,3 +108,54 @@ def test_reference_test_program_runs(tmp_path, trained_blob):
     assert pred.shape == g["ref_s3_depth"].shape
     same = (pred == 0) == (g["ref_s3_depth"] == 0)
     assert same.mean() > 0.998 and np.abs(pred - g["ref_s3_depth"])[same].mean() < 1e-4
+
+
+BACKEND_RUN = os.path.join(ROOT, "oracle", "_ref", "tandem_backend_run")
+BACKEND_SRC = "/root/reference/tandem/src/tandem/tandem_backend.cpp"
+
+
+@pytest.mark.skipif(not os.path.isfile(BACKEND_SRC), reason="reference checkout not present")
+def test_reference_tandem_backend_compiles_unchanged_against_the_shims(tmp_path):
+    """ref:tandem/src/tandem/tandem_backend.cpp -- TANDEM's own caller of DrMvsnet AND DrFusion -- compiled as it is against
+    tandem_amd/libdr/{dr_mvsnet,dr_fusion}.h; cv::Mat / boost::thread / Output3DWrapper come from oracle/ref_stub_backend/
+    (container, <thread>, three virtuals), util/Timer.h is the reference's own.  The product library resolves every symbol."""
+    exe = str(tmp_path / "tandem_backend_run")
+    subprocess.check_call(["g++", "-std=c++14", "-w", "-I" + os.path.join(ROOT, "oracle", "ref_stub_backend"), "-I/root/reference/tandem/src",
+                           "-I/root/reference/tandem/src/tandem", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tandem_amd", "libdr"),
+                           os.path.join(ROOT, "tools", "tandem_backend_main.cpp"), BACKEND_SRC, "-o", exe, "-L" + os.path.join(ROOT, "tandem_amd"),
+                           "-ldr_mi355x", "-lpthread", "-Wl,-rpath," + os.path.join(ROOT, "tandem_amd")])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage:" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mesh_freq", [0, 3])
+def test_reference_tandem_backend_drives_both_operators(tmp_path, trained_blob, mesh_freq):
+    """The reference's TandemBackend (unchanged) as the integration driver: 8 keyframes of a 96 x 128 x 5-view window through
+    CallAsync / GetResult / IntegrateScanAsync / RenderAsync / GetRenderResult (+ ExtractMeshAsync / GetMeshSync every 3rd call) in the
+    reference's own order; the output wrapper receives a depth map per keyframe, the tracker's depth map becomes valid and is
+    mostly covered, the mesh is non-empty."""
+    import json
+    import sys
+    if not os.path.isfile(BACKEND_RUN):
+        pytest.skip("oracle/_ref/tandem_backend_run not built (needs the reference checkout at build time)")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from export_fixture import write_tdms
+    from synth import scene
+    H, W, V = 96, 128, 5
+    win = scene.make_window(H, W, V, seed=3)
+    sample = str(tmp_path / "w.tdms")
+    z = np.zeros((H, W), np.float32)
+    write_tdms(sample, np.stack(win["bgrs"]), win["K"], win["c2ws"], win["ref_index"], win["depth_min"], win["depth_max"], 10.0, z, z)
+    r = subprocess.run([BACKEND_RUN, trained_blob, sample, "8", "0.02", str(mesh_freq), "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["driver"].startswith("reference tandem_backend.cpp") and d["keyframes"] == 8
+    # 3 warm-up + 8 timed calls: every call after the first pushes the previous keyframe's image and depth map
+    assert d["pushed"]["depth_maps"] == 10 and d["pushed"]["images"] == 10
+    assert d["tracking_maps_valid"] >= 6 and d["tracked_sample"] > 0.5 * (H * W / 97)
+    assert d["last_depth_sample_sum"] > 0
+    if mesh_freq:
+        assert d["pushed"]["meshes"] >= 2 and d["pushed"]["last_mesh_vertices"] > 1000
+    else:
+        assert d["pushed"]["meshes"] == 0

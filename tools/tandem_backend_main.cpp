@@ -1,0 +1,127 @@
+// tandem_backend_main -- drives the REFERENCE's own TandemBackend (ref:tandem/src/tandem/tandem_backend.cpp, compiled UNCHANGED by
+// oracle/Makefile.ref against tandem_amd/libdr/*.h and the stand-ins under oracle/ref_stub_backend/) on one GPU.
+// BASELINE configs[4] stand-in: the DSO front-end (FullSystem::deliverDrFrame, FullSystem.cpp:1122-1198) cannot be built here
+// (Eigen / Sophus / Boost / OpenCV / Pangolin are absent), so this main plays that one function: per keyframe it does what
+// deliverDrFrame does with the back-end --
+//     if (!tandem_backend->Ready()) tandem_backend->Wait();          (FullSystem.cpp:1146-1153, linearizeOperation)
+//     tandem_backend->CallAsync(view_num, index_offset, corrected_ref_index, bgrs, K, cam_to_worlds, depth_min, depth_max, pose)
+// -- with a stored keyframe window (TDMS sample, tools/export_fixture.py) moved rigidly from keyframe to keyframe, and then
+// reads the tracking depth map under its mutex the way CoarseTracker::makeCoarseDepthL0 does (CoarseTracker.cpp:655-668).
+// Everything between those calls and the GPU -- GetResult(k-1), CallAsync(k), IntegrateScanAsync / RenderAsync / GetRenderResult
+// of k-1, the A/B depth-map swap, the mesh every mesh_freq-th call, the output-wrapper pushes -- is the reference's code.
+//   usage: tandem_backend_run <weights.tdmw> <window.tdms> <keyframes> [voxel_size=0.01] [mesh_freq=0] [dense_tracking=1]
+// Prints ONE JSON line.
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "tandem_backend.h"
+
+typedef std::chrono::steady_clock Clock;
+static double ms_since(Clock::time_point t) { return std::chrono::duration<double, std::milli>(Clock::now() - t).count(); }
+
+struct CountingWrapper : public dso::IOWrap::Output3DWrapper {  // what a viewer would receive
+  int images = 0, depths = 0, meshes = 0;
+  size_t last_mesh_vertices = 0;
+  double depth_sum = 0;
+  int w, h;
+  CountingWrapper(int w_, int h_) : w(w_), h(h_) {}
+  void pushDrKfImage(unsigned char *bgr) override { images += bgr != nullptr; }
+  void pushDrKfDepth(float const *image, float depth_min, float depth_max) override {
+    depths++;
+    depth_sum = 0;
+    for (size_t i = 0; i < (size_t) w * h; i += 101) depth_sum += image[i];
+  }
+  void pushDrMesh(size_t num, float const *vert, float const *cols) override { meshes++; last_mesh_vertices = num; }
+};
+
+int main(int argc, char **argv) {
+  if (argc < 4) { fprintf(stderr, "usage: %s <weights.tdmw> <window.tdms> <keyframes> [voxel_size] [mesh_freq] [dense_tracking]\n", argv[0]); return 2; }
+  const int n_kf = atoi(argv[3]);
+  const float voxel = argc > 4 ? (float) atof(argv[4]) : 0.01f;   // FullSystem.cpp:260
+  const int mesh_freq = argc > 5 ? atoi(argv[5]) : 0;
+  const bool dense_tracking = argc > 6 ? atoi(argv[6]) != 0 : true;
+  FILE *f = fopen(argv[2], "rb");
+  if (!f) { fprintf(stderr, "cannot open %s\n", argv[2]); return 2; }
+  char magic[8]; int hdr[4]; float sc[3], K[9];
+  if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "TDMS0001", 8) || fread(hdr, 4, 4, f) != 4 || fread(sc, 4, 3, f) != 3 || fread(K, 4, 9, f) != 9) return 2;
+  const int V = hdr[0], H = hdr[1], W = hdr[2], ref = hdr[3];
+  const size_t npx = (size_t) H * W;
+  std::vector<float> c2w0((size_t) V * 16);
+  std::vector<unsigned char> img((size_t) V * npx * 3);
+  if (fread(c2w0.data(), 4, c2w0.size(), f) != c2w0.size() || fread(img.data(), 1, img.size(), f) != img.size()) return 2;
+  fclose(f);
+
+  // FullSystem::initDr (FullSystem.cpp:255-290): the two operators, then the back-end that owns the call order
+  DrMvsnet *mvsnet = new DrMvsnet(argv[1]);
+  DrFusionOptions o;
+  o.voxel_size = voxel; o.num_buckets = 1000000; o.bucket_size = 10; o.num_blocks = 1000000; o.block_size = 8; o.max_sdf_weight = 64;
+  o.truncation_distance = 4 * voxel; o.max_sensor_depth = 10.f; o.min_sensor_depth = 0.1f; o.num_render_streams = dense_tracking ? 1 : 0;
+  o.fx = K[0]; o.fy = K[4]; o.cx = K[2]; o.cy = K[5]; o.height = H; o.width = W;
+  DrFusion *fusion = new DrFusion(o);
+  Timer dr_timer;
+  CountingWrapper wrapper(W, H);
+  std::vector<dso::IOWrap::Output3DWrapper *> wrappers{&wrapper};
+  // never deleted: TandemBackendImpl's worker loop has no exit (tandem_backend.cpp:127-137), TANDEM leaves it to process exit too
+  TandemBackend *backend = new TandemBackend(W, H, dense_tracking, mvsnet, fusion, sc[2], &dr_timer, wrappers, mesh_freq);
+
+  cv::Mat Kmat(3, 3, CV_32F);
+  memcpy(Kmat.data, K, sizeof K);
+  double t_wait = 0, t_call = 0, t_track = 0;
+  size_t tracked = 0;
+  int valid_maps = 0;
+  const int warm = 3;
+  Clock::time_point t_begin = Clock::now();
+  for (int k = 0; k < n_kf + warm; k++) {
+    if (k == warm) { t_begin = Clock::now(); t_wait = t_call = t_track = 0; valid_maps = 0; }
+    // keyframe k's window: the stored one moved rigidly (x advances 4 cm per keyframe on a slow arc), fresh cv::Mat per keyframe as
+    // deliverDrFrame builds them (FullSystem.cpp:1159-1173): images are views of the frames' buffers, poses are owned 4x4 floats
+    const float ang = 0.01f * k, cs = std::cos(ang), sn = std::sin(ang), tx = 0.04f * k;
+    std::vector<cv::Mat> bgrs_in, c2ws_in;
+    for (int v = 0; v < V; v++) {
+      bgrs_in.emplace_back(H, W, CV_8U, img.data() + (size_t) v * npx * 3);
+      c2ws_in.emplace_back(4, 4, CV_32F);
+      const float *a = c2w0.data() + 16 * v;
+      float *b = (float *) c2ws_in.back().data;
+      for (int c = 0; c < 4; c++) {       // b = S * a,  S = rot_y(ang) with translation (tx, 0, 0)
+        b[c] = cs * a[c] + sn * a[8 + c] + (c == 3 ? tx : 0.f);
+        b[4 + c] = a[4 + c];
+        b[8 + c] = -sn * a[c] + cs * a[8 + c];
+        b[12 + c] = a[12 + c];
+      }
+    }
+    Clock::time_point t = Clock::now();
+    if (!backend->Ready()) backend->Wait();                                                       // FullSystem.cpp:1146-1148
+    t_wait += ms_since(t);
+    t = Clock::now();
+    backend->CallAsync(V, 0, ref, bgrs_in, Kmat, c2ws_in, sc[0], sc[1], c2ws_in[ref]);            // FullSystem.cpp:1185-1195
+    t_call += ms_since(t);
+    if (dense_tracking) {                                                                         // CoarseTracker.cpp:655-668
+      t = Clock::now();
+      boost::unique_lock<boost::mutex> lock(backend->GetTrackingDepthMapMutex());
+      TandemCoarseTrackingDepthMap const *dm = backend->GetTrackingDepthMap();
+      if (dm && dm->is_valid) {
+        valid_maps++;
+        tracked = 0;
+        for (size_t i = 0; i < npx; i += 97) tracked += dm->depth[i] > 0;
+      }
+      t_track += ms_since(t);
+    }
+  }
+  backend->Wait();
+  fusion->Synchronize();
+  const double total = ms_since(t_begin);
+  printf("{\"driver\": \"reference tandem_backend.cpp, unchanged\", \"keyframes\": %d, \"keyframes_per_s\": %.3f, \"ms_per_keyframe\": %.4f, "
+         "\"height\": %d, \"width\": %d, \"views\": %d, \"voxel_size\": %g, \"dense_tracking\": %d, \"mesh_every\": %d, "
+         "\"mean_ms\": {\"backend_wait\": %.4f, \"backend_CallAsync\": %.4f, \"tracking_map_read\": %.4f, \"IntegrateScanAsync\": %.4f, \"fusion_mesh\": %.4f}, "
+         "\"pushed\": {\"images\": %d, \"depth_maps\": %d, \"meshes\": %d, \"last_mesh_vertices\": %zu}, \"tracking_maps_valid\": %d, "
+         "\"tracked_sample\": %zu, \"last_depth_sample_sum\": %.3f}\n",
+         n_kf, 1e3 * n_kf / total, total / n_kf, H, W, V, voxel, (int) dense_tracking, mesh_freq, t_wait / n_kf, t_call / n_kf, t_track / n_kf,
+         dr_timer.mean_timing("IntegrateScanAsync"), dr_timer.mean_timing("fusion-mesh"), wrapper.images, wrapper.depths, wrapper.meshes,
+         wrapper.last_mesh_vertices, valid_maps, tracked, wrapper.depth_sum);
+  fflush(stdout);
+  _Exit(0);  // the back-end's worker thread never ends; leave without running destructors under it
+}
