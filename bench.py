@@ -281,6 +281,41 @@ def shipped_leg(args, dev):
                 gflop_per_depth_map=flops / 1e9, reference_published_fps=4.96)
 
 
+def bf16x3_leg(args, dev):
+    """The opt-in precision mode DR_CONV_BF16X3=1 (csrc/conv_bf3.h): every convolution with Cin % 8 == 0 on the bf16 matrix cores, both
+    operands split into two bf16 terms, the three leading products accumulated in fp32.  Operands then carry 16 mantissa bits, not 24:
+    the depth maps stay inside the bounds the fp32 path is held to (tests: test_bf16x3_mode_stays_inside_the_fp32_bounds), but this is
+    NOT fp32 arithmetic -- reported here as its own object, never as `value` / `dtype`."""
+    import threading
+    from synth import scene
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    os.environ["DR_CONV_BF16X3"] = "1"  # read when an engine plans its layers
+    try:
+        engines = []
+        for e in range(3):
+            win = scene.make_window(H, W, V, seed=80 + e)
+            m = DrMvsnet(model_blob(), device=dev)
+            m.upload(H, W, V, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), DEPTH_MIN, DEPTH_MAX, DISCARD)
+            m.forward(5)
+            engines.append(m)
+    finally:
+        del os.environ["DR_CONV_BF16X3"]
+    n1 = max(20, min(100, args.steps))
+    lat = engines[0].forward(n1) / n1
+    per = max(20, min(100, args.steps // 3))
+    threads = [threading.Thread(target=lambda m=m: m.forward(per)) for m in engines]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    dt = time.perf_counter() - t0
+    for m in engines:
+        m.close()
+    return dict(mode="DR_CONV_BF16X3=1: convolutions on bf16 MFMA with two-term split operands (3 products, fp32 accumulation); operand precision 16 bits",
+                dtype="bf16x3 (not f32)", single_window_ms=lat, depth_maps_per_s_3_engines=3 * per / dt, windows=3 * per)
+
+
 def boundary_leg(args, dev):
     """The operator boundary as the reference times it (test_dr_mvsnet, dr_mvsnet.cpp:540-545): CallAsync(host u8 images,
     K, poses) -> Ready -> GetResult (four host float maps) per window, E engines = E independent DrMvsnet objects.
@@ -645,6 +680,7 @@ def main():
     bd = boundary_leg(args, local_rank) if (rank == 0 and world == 1 and not args.no_boundary) else None
     lp = tandem_loop_leg(args, local_rank) if (rank == 0 and world == 1 and not args.no_loop) else None
     sh = shipped_leg(args, local_rank) if (rank == 0 and world == 1 and not args.no_boundary) else None
+    b3 = bf16x3_leg(args, local_rank) if (rank == 0 and world == 1 and not args.no_boundary) else None
     vs, vs_hung = None, False
     if world > 1 and not args.no_view_shard:
         # The sharded leg is the only part of this program with a data-path collective.  It runs under a watchdog: if a
@@ -695,6 +731,8 @@ def main():
             out["boundary"] = bd
         if sh is not None:
             out["shipped_model"] = sh
+        if b3 is not None:
+            out["bf16x3_mode"] = b3
         if lp is not None:
             out["tandem_loop"] = lp
         if tr is not None:

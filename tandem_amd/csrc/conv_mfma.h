@@ -229,6 +229,12 @@ __global__ __launch_bounds__(kConvThreads, DR_KCONV_MIN_WAVES(CT, FZ)) void k_co
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const ConvClass cls = a.cls[blockIdx.y];
   const int ct0 = blockIdx.z * CT;
+#ifdef DR_CONV_DEPHASE  // A/B build (tools/build_ab.sh): every other layer of 32 workgroups per XCD of the FIRST generation starts late, so that
+  {                     // co-resident workgroups stage and multiply at different times instead of in lock-step
+    const unsigned layer = (blockIdx.x >> 3) >> 5;
+    if (layer < 8 && (layer & 1)) for (int i = 0; i < DR_CONV_DEPHASE; ++i) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
 
   // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (own L2 each), so XCD k takes the k-th
   // contiguous range of tiles (x fastest, then y, then z): neighbouring tiles, which share their halo, share an L2.
@@ -590,7 +596,7 @@ struct ConvLayer {  // logical description (torch semantics)
   int kd = 1, kh = 1, kw = 1;
   int sd = 1, sh = 1, sw = 1;
   bool transposed = false;          // ConvTranspose3d(k=3, pad=1, output_padding = stride-1)
-  int up2 = 0;                      // 1 + py (3: both py, as two classes): Conv2d(k=3, pad=1) applied to the nearest x2 upsampling (in H and W) of the input,
+  int up2 = 0;                      // 1 + py: Conv2d(k=3, pad=1) applied to the nearest x2 upsampling (in H and W) of the input,
                                     // which is given at HALF resolution and never upsampled in memory; this launch produces the output rows 2Y + py.  Output
                                     // pixel (2Y+py, 2X+px) reads 2 x 2 input pixels, the kernel rows / columns that fall on the same input
                                     // pixel summed (weight (Cout,Cin,1,3,3)); both px are rows of the launch (2 * Cout rows)
@@ -714,8 +720,8 @@ struct ConvTuned {
 inline bool conv_instance_exists(int ci, int ct) {
   return (ci == 4 && ct == 1) || ((ci == 8 || ci == 16) && (ct == 1 || ct == 2 || ct == 4));
 }
-inline bool conv_a_instance_exists(int ci, int ct, int pt) {
-  return (pt == 2 || pt == 4) && ((ci == 4 && ct == 1) || ((ci == 8 || ci == 16) && (ct == 1 || ct == 2)));
+inline bool conv_a_instance_exists(int ci, int ct, int pt) {  // PT = 1 (round 4): 128-position tiles, for the layers whose halo (stride 2, 5 x 5) does not fit twice at 256
+  return (pt == 1 || pt == 2 || pt == 4) && ((ci == 4 && ct == 1 && pt != 1) || ((ci == 8 || ci == 16) && (ct == 1 || ct == 2)));
 }
 // k_conv_m instances (CI, NUP, CT, PT, consumer waves).  3-D layers: NUP = 6 (8 channels, XPAIR), 12 (16 channels, XPAIR), 9 (16 channels);
 // row march of 2-D layers: NUP = 2 (8 channels, XPAIR), 4 (16 channels, XPAIR), 3 (16 channels).  CT = 2 with PT = 4 needs more than the
@@ -821,14 +827,13 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   // rank: which candidate of the cost model's ranking to build (0 = its choice); used by the engine's autotuner
   if (L.Cin % 4 != 0 || inC < L.Cin) fail(DR_ERR_ARG, "plan_conv: Cin=%d must be a multiple of 4 (tensor C=%d)", L.Cin, inC);
   const int form = L.transposed ? conv_deconv_form(L.Cout) : 0;
-  if (L.up2 && (L.transposed || L.kd != 1 || L.kh != 3 || L.kw != 3 || L.sd != 1 || L.sh != 1 || L.sw != 1 || mode != CONV_NORMAL))
+  if (L.up2 && (L.up2 > 2 || L.transposed || L.kd != 1 || L.kh != 3 || L.kw != 3 || L.sd != 1 || L.sh != 1 || L.sw != 1 || mode != CONV_NORMAL))
     fail(DR_ERR_ARG, "plan_conv: up2 is a plain 3x3 stride-1 2-D layer over the upsampled input");
   auto cz = axis_classes(L.kd, L.sd, L.transposed, inD, form >= 1);
   auto cy = axis_classes(L.kh, L.sh, L.transposed, inH, form >= 1);
   auto cx = axis_classes(L.kw, L.sw, L.transposed, inW, form >= 2);
-  if (L.up2) {  // both x parities as rows; one y parity per launch (up2 = 1, 2: a single class, the persistent kernels apply) or both
-    cy = axis_classes_up2(inH, true);  // as the two classes of one k_conv launch (up2 = 3)
-    if (L.up2 < 3) cy = {cy[L.up2 - 1]};
+  if (L.up2) {  // one y parity per launch (a single class: the persistent kernels apply), both x parities as rows
+    cy = {axis_classes_up2(inH, true)[L.up2 - 1]};
     cx = axis_classes_up2(inW, false);
   }
   const bool parity_layer = L.transposed || L.up2;
@@ -896,7 +901,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
       if (L.Cin % ci || (ci == 4 && L.Cin != 4)) continue;
       const int npass = L.Cin / ci, tpc = 16 / ci, nu = cdiv(classes[0].ntaps, tpc);
       if (npass > 2 && (npass & 1)) continue;  // weight buffers alternate with the pass parity
-      for (int pt : {2, 4})
+      for (int pt : {1, 2, 4})
         for (int tz = 1; tz <= 8 * pt; tz *= 2)
           for (int ty = 1; tz * ty <= 8 * pt; ty *= 2) {
             const int txt = 8 * pt / (tz * ty);
@@ -1287,9 +1292,11 @@ inline void launch_conv(const ConvLaunch &c, hipStream_t st) {
 #define DR_CONV_A_CASE(CI_, CT_)                                                \
   if (c.ci == CI_ && c.ct == CT_) {                                             \
     if (c.pt == 4) launch_conv_a_inst<CI_, CT_, 4>(c, st);                      \
-    else launch_conv_a_inst<CI_, CT_, 2>(c, st);                                \
+    else if (c.pt == 2) launch_conv_a_inst<CI_, CT_, 2>(c, st);                 \
+    else launch_conv_a_inst<CI_, CT_, 1>(c, st);                                \
     return;                                                                     \
   }
+    if (c.ci == 4 && c.ct == 1 && c.pt == 1) fail(DR_ERR_ARG, "launch_conv: no async instance CI=4 PT=1");
     DR_CONV_A_CASE(4, 1)
     DR_CONV_A_CASE(8, 1)
     DR_CONV_A_CASE(8, 2)

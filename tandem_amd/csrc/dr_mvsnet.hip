@@ -697,10 +697,6 @@ class MvsEngine {
       DevTensor &f3 = alloc("feat3", c3.D, c3.H, c3.W, 8, fpad);
       ConvLayer LA; LA.Cin = 8; LA.Cout = 8; LA.kd = 1; LA.kh = 3; LA.kw = 3; LA.weight = wa.data(); LA.bias = bint; LA.out_pad = fpad;
       emit_conv("fn.out3a", LA, CONV_XPAIR, c3, f3, nullptr, 0, 0);
-      if (getenv("DR_OUT3_ONE_LAUNCH")) {  // opt-in (measured 0.097 against 2 x 0.058 ms, not yet the default: profiles/r03_experiments.txt, 18):
-        ConvLayer LB; LB.Cin = 32; LB.Cout = 8; LB.kd = 1; LB.kh = 3; LB.kw = 3; LB.weight = wo3.data.data(); LB.up2 = 3; LB.out_pad = fpad;  // both row parities as the two classes of one k_conv launch
-        emit_conv("fn.out3b", LB, CONV_NORMAL, i2, f3, f3.interior(), 1, f3.n());
-      } else
       for (int py = 0; py < 2; ++py) {
         ConvLayer LB; LB.Cin = 32; LB.Cout = 8; LB.kd = 1; LB.kh = 3; LB.kw = 3; LB.weight = wo3.data.data(); LB.up2 = 1 + py; LB.out_pad = fpad;
         emit_conv(py ? "fn.out3c" : "fn.out3b", LB, CONV_NORMAL, i2, f3, f3.interior(), 1, f3.n() / 2);

@@ -307,8 +307,8 @@ static int run_case(const Case &cs, int max_plans) {
     ConvLaunch c{};
     bool ok = true;
     int ncand = 0;
-    for (int py = 0; py < (cs.kind == 2 ? 2 : 1) && ok; ++py) {  // up2: one launch per row parity, or one launch with two classes
-      L.up2 = cs.kind == 2 ? 1 + py : (cs.kind == 3 ? 3 : 0);
+    for (int py = 0; py < (cs.kind == 2 ? 2 : 1) && ok; ++py) {  // up2: one launch per row parity
+      L.up2 = cs.kind == 2 ? 1 + py : 0;
       ConvPlanOut P = plan_conv(L, mode, in.data(), cs.D, cs.H, cs.W, cs.Cin, out.data(), cs.add ? add.data() : nullptr, cs.add == 2 ? 2 : 1, arena, rank);
       ncand = P.ncand;
       c = P.launches.at(0);
@@ -358,7 +358,6 @@ int main(int argc, char **argv) {
       {"deconv_64_32_s122", 1, 1, 4, 6, 64, 32, 3, 3, 3, 1, 2, 2, true, 1},           // conv7 at D = 4 stages
       {"up2_32_8_inplace_add", 2, 2, 7, 19, 32, 8, 1, 3, 3, 1, 1, 1, false, 1},       // the folded out.stage3's phase layers
       {"up2_16_16", 2, 1, 5, 33, 16, 16, 1, 3, 3, 1, 1, 1, true, 0},
-      {"up2both_32_8_inplace_add", 3, 2, 12, 40, 32, 8, 1, 3, 3, 1, 1, 1, false, 1},  // both row parities as two classes of one launch
       // large enough for the persistent kernel's tiles (8 waves x 2-4 position tiles)
       {"conv2d_3x3_16_16", 0, 2, 24, 48, 16, 16, 1, 3, 3, 1, 1, 1, true, 0},           // fn.conv1.x
       {"conv2d_3x3_32_16", 0, 2, 16, 40, 32, 16, 1, 3, 3, 1, 1, 1, false, 0},          // fn.out2: two channel passes

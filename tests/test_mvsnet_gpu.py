@@ -438,10 +438,7 @@ def test_shared_setup_cost_volume_is_bit_identical(trained_blob, tmp_path, monke
                 assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), np.abs(a - b).max()
 
 
-# ---- the opt-in bf16 x 3 precision mode (csrc/conv_bf3.h).  The kernel was written at the end of round 3 against a host emulation
-# only; until it has passed on a GPU these cases run only with DR_TEST_BF16X3=1 (tools/gpu_r4_bf3.sh), so that they cannot turn the
-# suite red unseen.
-@pytest.mark.skipif(os.environ.get("DR_TEST_BF16X3") != "1", reason="k_conv_b has not been validated on a GPU yet (DR_TEST_BF16X3=1 runs it)")
+# ---- the opt-in bf16 x 3 precision mode (csrc/conv_bf3.h, DR_CONV_BF16X3=1; first run on a GPU in round 4: green) ----
 @pytest.mark.parametrize("path", [p for p in GOLD if "rand" not in p and "novar" not in p], ids=lambda p: os.path.basename(p))
 def test_bf16x3_mode_stays_inside_the_fp32_bounds(path, trained_blob, tmp_path, monkeypatch):
     """With every convolution (Cin % 8 == 0) on k_conv_b the depth maps must still pass the bounds the fp32 path is held to -- what
