@@ -104,6 +104,19 @@ SIGNATURES = {
 }
 
 
+HOOKS_LIB_PATH = os.path.join(_HERE, "libdr_mi355x_hooks.so")  # the PARITY build (-DDR_PARITY_HOOKS): superseded kernel generations selectable
+_loaded = {}
+
+
+def switch(path=None):
+    """Make `path` (default: the product library) the library every operator object created from now on talks to.  Test
+    infrastructure: the -m gpu cases that compare kernel generations switch to HOOKS_LIB_PATH for their duration (tests/conftest.py::
+    parity_hooks).  Objects created before a switch must be closed first: a handle belongs to the library that made it."""
+    global _lib, LIB_PATH
+    LIB_PATH = path or os.environ.get("DR_MI355X_LIB") or os.path.join(_HERE, "libdr_mi355x.so")
+    _lib = _loaded.get(LIB_PATH)
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -114,7 +127,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError = ABI/header mismatch: fail loudly
             fn.restype, fn.argtypes = res, args
-        _lib = L
+        _lib = _loaded[LIB_PATH] = L
     return _lib
 
 

@@ -229,12 +229,6 @@ __global__ __launch_bounds__(kConvThreads, DR_KCONV_MIN_WAVES(CT, FZ)) void k_co
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const ConvClass cls = a.cls[blockIdx.y];
   const int ct0 = blockIdx.z * CT;
-#ifdef DR_CONV_DEPHASE  // A/B build (tools/build_ab.sh): every other layer of 32 workgroups per XCD of the FIRST generation starts late, so that
-  {                     // co-resident workgroups stage and multiply at different times instead of in lock-step
-    const unsigned layer = (blockIdx.x >> 3) >> 5;
-    if (layer < 8 && (layer & 1)) for (int i = 0; i < DR_CONV_DEPHASE; ++i) __builtin_amdgcn_s_sleep(32);
-  }
-#endif
 
   // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (own L2 each), so XCD k takes the k-th
   // contiguous range of tiles (x fastest, then y, then z): neighbouring tiles, which share their halo, share an L2.
@@ -1275,12 +1269,16 @@ inline void launch_conv(const ConvLaunch &c, hipStream_t st) {
 #undef DR_CONV_B_CASE
     fail(DR_ERR_ARG, "launch_conv: no bf16x3 instance CI=%d CT=%d", c.ci, c.ct);
   }
+#ifndef DR_PARITY_HOOKS  // the fused-skip forms (FeatureNet's stage-3 head in its literal order) are instantiated in the parity build only
+  if (c.fz) fail(DR_ERR_UNSUPPORTED, "launch_conv: fused-skip kernels are built with -DDR_PARITY_HOOKS only");
+#else
   if (c.async == 2 && c.fz) {
     if (c.fz != 8 || c.ci != 16 || c.nup != 12 || c.ct != 1 || c.ncw != 8) fail(DR_ERR_ARG, "launch_conv: no fused-skip marching instance FZ=%d CI=%d NUP=%d CT=%d", c.fz, c.ci, c.nup, c.ct);
     if (c.pt == 4) launch_conv_m_inst<16, 12, 1, 4, 8>(c, st);
     else launch_conv_m_inst<16, 12, 1, 2, 8>(c, st);
     return;
   }
+#endif
   if (c.async == 2) {
 #define DR_X(CI_, NUP_, CT_, PT_, NCW_) \
   if (c.ci == CI_ && c.nup == NUP_ && c.ct == CT_ && c.pt == PT_ && c.ncw == NCW_) { launch_conv_m_inst<CI_, NUP_, CT_, PT_, 0, NCW_>(c, st); return; }
@@ -1305,12 +1303,14 @@ inline void launch_conv(const ConvLaunch &c, hipStream_t st) {
 #undef DR_CONV_A_CASE
     fail(DR_ERR_ARG, "launch_conv: no async instance CI=%d CT=%d PT=%d", c.ci, c.ct, c.pt);
   }
+#ifdef DR_PARITY_HOOKS
   if (c.fz) {
     if (c.fz != 8 || c.ci != 16 || c.ct != 1) fail(DR_ERR_ARG, "launch_conv: no fused-skip instance FZ=%d CI=%d CT=%d", c.fz, c.ci, c.ct);
     if (c.pt == 4) launch_conv_inst<16, 1, 4, 8>(c, st);
     else launch_conv_inst<16, 1, 1, 8>(c, st);
     return;
   }
+#endif
 #define DR_CONV_CASE(CI_, CT_)                                                  \
   if (c.ci == CI_ && c.ct == CT_) {                                             \
     if (c.pt == 4) launch_conv_inst<CI_, CT_, 4>(c, st);                        \

@@ -469,7 +469,6 @@ __global__ __launch_bounds__(256) void k_cull(const FusionDev d, const Mat Ti) {
 // and one 128-bit load for two voxels that are neighbours in z.
 struct alignas(8) Voxel8 { unsigned lo, hi; };
 struct __attribute__((packed, aligned(8))) Voxel16 { unsigned a, b, c, d; };
-struct __attribute__((packed, aligned(4))) Cell2 { int lo, hi; };  // two neighbouring (in z) cells of the dense block grid
 __device__ inline Voxel unpack_voxel(unsigned lo, unsigned hi) {
   Voxel v;
   v.sdf = __uint_as_float(lo);
@@ -672,6 +671,7 @@ __device__ inline Voxel get_interpolated_voxel(const FusionDev &d, F3 pos) {  //
   return v;
 }
 
+#ifdef DR_PARITY_HOOKS  // the literal first generation as a whole-image kernel (DR_RAYCAST_V1); k_raycast_fix below is its per-pixel form
 __global__ __launch_bounds__(64) void k_raycast(const FusionDev d, const Mat pose, unsigned char *__restrict__ bgr,
                                                 float *__restrict__ depth_out) {
   const drf_options_t &o = d.o;
@@ -708,6 +708,8 @@ __global__ __launch_bounds__(64) void k_raycast(const FusionDev d, const Mat pos
     }
   }
 }
+
+#endif  // DR_PARITY_HOOKS
 
 // ---- ray-cast, second generation: same arithmetic, a fraction of the instructions and of the dependent loads ----
 // What GetInterpolatedVoxel costs when it is written out literally (above): 9 GetVoxel calls = 27 IEEE divisions by
@@ -889,19 +891,16 @@ __device__ inline Voxel interp_voxel2(const FusionDev &d, F3 pos, bool far_block
   v.sdf = dist;
   return v;
 }
-// interp_voxel2 with HALF the gathers.  Round 4: the kernel is not bound by vector-ALU issue but by the load path -- a sample of
-// interp_voxel2 is 18 wave-wide gathers (9 grid cells, 9 voxels) in which nearly every lane has its own address, and each such
-// instruction occupies the texture addresser / L1 tag path for tens of cycles whatever it brings back (62 samples per ray, ~19
-// waves per CU: the addresser alone is ~10^4 cycles per sample round of a CU, which IS the measured 0.39 ms).  Same values, fewer
-// and wider requests:
-//   * z is the fastest index of the grid AND of a block's voxels, and the two z-corners of an (x, y) corner pair are always
-//     neighbours in z (gz[1] == gz[0] + 1): ONE 8-byte load brings both grid cells of a pair, ONE 16-byte load both voxels (when the
-//     pair straddles two blocks, lz == 7 -- one lane in eight -- the upper voxel comes from a second load issued under that
-//     condition, all four pairs inside one branch);
-//   * the centre voxel (GetVoxel(position), tsdf_volume.cu:166) IS one of the eight corners: the voxel nearest to p is a corner
-//     of the dual cell that contains p.  It is selected from the corner loads instead of fetched (a lane whose rounded centre
-//     coordinate matches neither corner coordinate -- a float tie at a cell boundary -- is sent to the literal pass).
-// 4 + 4 gathers (+ 4 for an eighth of the lanes) instead of 9 + 9; arithmetic, corner order and fallback rule unchanged.
+// interp_voxel2 without the centre voxel's own look-ups.  PMC (r3): the kernel is bound by the L1's tag path -- 131.6 M cache-line
+// accesses per 640 x 480 render, 20 lines per gather instruction (the 64 rays of a tile sit in 64 different z-columns of a block, and
+// a line is one column) against 6.5 M gather instructions and 0.13 ms of vector-ALU issue -- so what counts is the number of
+// voxel gathers per sample.  The centre voxel (GetVoxel(position), tsdf_volume.cu:166) IS one of the eight corners: the voxel nearest
+// to p is a corner of the dual cell that contains p.  It is selected from the corner loads (7 + 7 selects) instead of fetched: 8 + 8
+// gathers per sample instead of 9 + 9.  A lane whose rounded centre coordinate matches neither corner coordinate (a float tie at a cell
+// boundary) is sent to the literal pass.  Arithmetic, corner order and fallback rule unchanged.
+// (Round 4 also measured PAIRED gathers -- one 8-byte load for the two grid cells and one 16-byte load for the two voxels of a z-corner
+//  pair, 4 + 4 per sample: 4x SLOWER, 1.34 against 0.34 ms per render.  The pairs start at any z, so half of those loads are not
+//  naturally aligned, and a misaligned wide gather is split by the load unit into many narrow ones.  profiles/r04_experiments.txt)
 template <bool FAST, bool COLOUR>
 __device__ inline Voxel interp_voxel3(const FusionDev &d, F3 pos, bool far_blocks, bool &bail, int *empty_cell = nullptr) {
   const float vs = d.o.voxel_size, hv = vs / 2.0f, y = d.vs_rcp;
@@ -917,78 +916,37 @@ __device__ inline Voxel interp_voxel3(const FusionDev &d, F3 pos, bool far_block
     gy[j] = f2i(div_by<FAST>(ay, vs, y) + signf_(ay) * 0.5f);
     gz[j] = f2i(div_by<FAST>(az, vs, y) + signf_(az) * 0.5f);
   }
-  // which corner is the centre voxel; the pairing also needs the z-corners to be neighbours
-  const bool mx = g0x == gx[1], my = g0y == gy[1], mz = g0z == gz[1];
-  if ((!mx && g0x != gx[0]) || (!my && g0y != gy[0]) || (!mz && g0z != gz[0]) || gz[1] != gz[0] + 1) { bail = true; return zero; }
-  constexpr int H = 1 << (kGridBits - 1);
-  unsigned ux[2], uy[2], uz[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) { ux[j] = (unsigned)((gx[j] >> 3) + H); uy[j] = (unsigned)((gy[j] >> 3) + H); uz[j] = (unsigned)((gz[j] >> 3) + H); }
-  const bool same_bz = uz[1] == uz[0];  // both z-corners in one block (lz0 != 7)
-  const bool okz0 = (uz[0] >> kGridBits) == 0, okz1 = (uz[1] >> kGridBits) == 0;
-  // ---- round trip 1: four 8-byte loads = the grid cells (x, y, uz[0]) and (x, y, uz[0] + 1) of every corner pair ----
-  int P[8];
-  bool okc[8];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const unsigned x = ux[c & 1], yy = uy[c >> 1];
-    const bool okxy = ((x | yy) >> kGridBits) == 0;
-    const unsigned idx = (okxy && okz0) ? ((x << (2 * kGridBits)) | (yy << kGridBits) | uz[0]) : 0u;  // (the grid carries two ints of slack behind its last cell)
-    const Cell2 t = *reinterpret_cast<const Cell2 *>(d.grid + idx);
-    okc[c] = okxy && okz0;
-    okc[c | 4] = okxy && okz1;
-    P[c] = okc[c] ? t.lo - 1 : -1;
-    P[c | 4] = okc[c | 4] ? (same_bz ? t.lo : t.hi) - 1 : -1;
-    // z0 below the grid and z1 its first cell: the pair load (redirected to cell 0) did not fetch that cell.  Such a sample sits on
-    // the grid's lower z face (10 m from the origin at 5 mm voxels): it goes to the literal pass
-    if (!same_bz && !okz0 && okc[c | 4]) { bail = true; return zero; }
-  }
+  const bool mx = g0x == gx[1], my = g0y == gy[1], mz = g0z == gz[1];  // which corner is the centre voxel
+  if ((!mx && g0x != gx[0]) || (!my && g0y != gy[0]) || (!mz && g0z != gz[0])) { bail = true; return zero; }
   auto pick = [&](const int (&a)[8]) {
     const int a0 = mz ? a[4] : a[0], a1 = mz ? a[5] : a[1], a2 = mz ? a[6] : a[2], a3 = mz ? a[7] : a[3];
     const int b0 = my ? a2 : a0, b1 = my ? a3 : a1;
     return mx ? b1 : b0;
   };
+  // ---- round trip 1: the eight corner cells ----
+  auto cell_of = [&](int x, int yy, int z, bool &ok) { I3 p; p.x = x; p.y = yy; p.z = z; unsigned idx = 0; ok = grid_index(p, idx); return ok ? idx : 0u; };
+  bool okc[8];
+  int ic[8], P[8], oki[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { ic[c] = (int)cell_of(gx[c & 1] >> 3, gy[(c >> 1) & 1] >> 3, gz[(c >> 2) & 1] >> 3, okc[c]); oki[c] = okc[c] ? 1 : 0; }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) P[c] = d.grid[ic[c]];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) P[c] = okc[c] ? P[c] - 1 : -1;
   const int b0 = pick(P);
-  const bool ok0 = mz ? (my ? (mx ? okc[7] : okc[6]) : (mx ? okc[5] : okc[4])) : (my ? (mx ? okc[3] : okc[2]) : (mx ? okc[1] : okc[0]));
+  const bool ok0 = pick(oki) != 0;
   if (!ok0 && far_blocks) bail = true;
-  if (empty_cell) {
-    const unsigned i0 = (ux[mx ? 1 : 0] << (2 * kGridBits)) | (uy[my ? 1 : 0] << kGridBits) | uz[mz ? 1 : 0];
-    *empty_cell = (b0 < 0 && ok0) ? (int)i0 : -1;
-  }
+  if (empty_cell) *empty_cell = (b0 < 0 && ok0) ? pick(ic) : -1;
   if (b0 < 0) return zero;
-  // ---- round trip 2: four 16-byte loads = both z-corners of every pair (voxels lz, lz + 1; lz == 7: voxels 6, 7 and a second load) ----
-  const int lz0 = gz[0] & 7, lzb = same_bz ? lz0 : 6;
-  unsigned vlo[8], vhi[8];  // the eight corner voxels as two words each
-  // (loaded as ONE vector value each: as a struct of four words hipcc sinks the selects below into the addresses and splits every
-  //  16-byte load into three narrower ones -- seen in the ISA -- the opposite of what this sampler is for)
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  typedef u32x4 u32x4_a8 __attribute__((aligned(8)));
-  u32x4 tp[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int lxy = ((gx[c & 1] & 7) << 6) | ((gy[c >> 1] & 7) << 3);
-    tp[c] = *reinterpret_cast<const u32x4_a8 *>(d.vox + (size_t)(P[c] >= 0 ? P[c] : b0) * 512 + (lxy | lzb));
-  }
-  unsigned ulo[4], uhi[4];  // the z1 corners of the lanes whose pairs straddle two blocks (requested before anything waits for the loads above)
-#pragma unroll
-  for (int c = 0; c < 4; ++c) ulo[c] = uhi[c] = 0u;
-  if (!same_bz) {  // one lane in eight: the z1 corners are voxel z = 0 of the blocks above
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int lxy = ((gx[c & 1] & 7) << 6) | ((gy[c >> 1] & 7) << 3);
-      const Voxel8 t = *reinterpret_cast<const Voxel8 *>(d.vox + (size_t)(P[c | 4] >= 0 ? P[c | 4] : b0) * 512 + lxy);
-      ulo[c] = t.lo; uhi[c] = t.hi;
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    vlo[c] = same_bz ? tp[c].x : tp[c].z; vhi[c] = same_bz ? tp[c].y : tp[c].w;  // corner z0
-    vlo[c | 4] = same_bz ? tp[c].z : ulo[c]; vhi[c | 4] = same_bz ? tp[c].w : uhi[c];  // corner z1
-  }
+  // ---- round trip 2: the eight corner voxels ----
   int ilo[8], ihi[8];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) { ilo[c] = (int)vlo[c]; ihi[c] = (int)vhi[c]; }
-  const Voxel v0 = unpack_voxel((unsigned)pick(ilo), (unsigned)pick(ihi));  // (b0 >= 0: the centre's own corner was loaded from its own block)
+  for (int c = 0; c < 8; ++c) {
+    const int local = ((gx[c & 1] & 7) << 6) | ((gy[(c >> 1) & 1] & 7) << 3) | (gz[(c >> 2) & 1] & 7);
+    const Voxel8 t = *reinterpret_cast<const Voxel8 *>(d.vox + (size_t)(P[c] >= 0 ? P[c] : b0) * 512 + local);
+    ilo[c] = (int)t.lo; ihi[c] = (int)t.hi;
+  }
+  const Voxel v0 = unpack_voxel((unsigned)pick(ilo), (unsigned)pick(ihi));  // (b0 >= 0: the centre's corner was loaded from its own block)
   if (v0.weight == 0) return v0;
 #pragma unroll
   for (int c = 0; c < 8; ++c) if (!okc[c] && far_blocks) bail = true;
@@ -1000,7 +958,7 @@ __device__ inline Voxel interp_voxel3(const FusionDev &d, F3 pos, bool far_block
     const int c = order[k];
     const float a = (c & 1) ? wx : (1.0f - wx), b = (c & 2) ? wy : (1.0f - wy), cc = (c & 4) ? wz : (1.0f - wz);
     const float wt = a * b * cc;
-    Voxel cvx = unpack_voxel(vlo[c], vhi[c]);
+    Voxel cvx = unpack_voxel((unsigned)ilo[c], (unsigned)ihi[c]);
     if (P[c] < 0) cvx = zero;
     const Voxel &src = cvx.weight == 0 ? v0 : cvx;
     dist += wt * src.sdf;
@@ -1039,7 +997,8 @@ __device__ inline int skip_steps(unsigned cell, F3 q, F3 dirw, F3 inv_dir, float
 // [0] lane iterations, [1] longest ray, [2] sum over waves of their longest ray (what the wave pays), [3] samples whose
 // centre block does not exist, [4] skip events, [5] skipped steps, [6] samples with weight != 0, [7] waves, [8..] histogram
 // of the waves' longest rays in buckets of 16 iterations.
-// SAMPLER: 2 = interp_voxel3 (paired gathers, the default), 1 = interp_voxel2 (18 gathers in two round trips), 0 = interp_voxel (four stages)
+// SAMPLER: 2 = interp_voxel3 (8 + 8 gathers: the centre voxel selected from the corners; the default), 1 = interp_voxel2 (9 + 9 gathers in two
+// round trips), 0 = interp_voxel (four stages)
 template <bool FAST, bool STATS = false, int SAMPLER = 2>
 __global__ __launch_bounds__(64) void k_raycast2(const FusionDev d, const Mat pose, unsigned char *__restrict__ bgr,
                                                  float *__restrict__ depth_out, int *__restrict__ n_flagged, unsigned long long *st = nullptr) {
@@ -1258,8 +1217,8 @@ class FusionEngine {
     for (int l = 0; l < kSuperLevels; ++l) d_.super[l] = dalloc<unsigned char>((size_t)1 << (3 * (kGridBits - kSuperShift[l])));
     d_.present = dalloc<unsigned>((size_t)1 << (3 * kPresentBits - 5));
     DR_HIP(hipMemsetAsync(d_.present, 0, (size_t)1 << (3 * kPresentBits - 3), int_stream_));
-    d_.grid = dalloc<int>(((size_t)1 << (3 * kGridBits)) + 2);  // + 2: interp_voxel3 reads cells in (z, z + 1) pairs
-    DR_HIP(hipMemsetAsync(d_.grid, 0, (sizeof(int) << (3 * kGridBits)) + 8, int_stream_));
+    d_.grid = dalloc<int>((size_t)1 << (3 * kGridBits));
+    DR_HIP(hipMemsetAsync(d_.grid, 0, sizeof(int) << (3 * kGridBits), int_stream_));
     for (int l = 0; l < kSuperLevels; ++l) DR_HIP(hipMemsetAsync(d_.super[l], 0, (size_t)1 << (3 * (kGridBits - kSuperShift[l])), int_stream_));
     d_.req = dalloc<unsigned>(o.num_blocks);
     d_.req_count = dalloc<int>(4);
@@ -1336,10 +1295,13 @@ class FusionEngine {
   }
   void launch_raycast(hipStream_t st, unsigned char *d_bgr, float *d_depth, int *d_flag, const Mat &P) {
     const dim3 grid(8 * cdiv(cdiv((int)npix_, 64), 8)), block(64);
+#ifdef DR_PARITY_HOOKS
     if (raycast_v1_) { hipLaunchKernelGGL(k_raycast, grid, block, 0, st, d_, P, d_bgr, d_depth); return; }
+#endif
     hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(1), 0, st, d_flag);
     FusionDev dv = d_;
     if (raycast_no_skip_) dv.super[0] = nullptr;  // DR_RAYCAST_NO_SKIP=1: every sample is looked up (A/B and parity hook)
+#ifdef DR_PARITY_HOOKS
     if (raycast_stats_ && d_.fast_div) {  // DR_RAYCAST_STATS=1: a synchronous, counting launch of the same loop (prints to stderr)
       if (!d_rstats_) d_rstats_ = dalloc<unsigned long long>(32);
       DR_HIP(hipMemsetAsync(d_rstats_, 0, 32 * 8, st));
@@ -1352,13 +1314,14 @@ class FusionEngine {
       for (int i = 0; i < 24; ++i) fprintf(stderr, " %llu", h[8 + i]);
       fprintf(stderr, "\n");
     } else
-    if (raycast_sampler_ == 0) {  // DR_RAYCAST_SAMPLER=0: the four-stage sampler of round 2 (A/B and parity hook)
+    if (raycast_sampler_ == 0) {  // DR_RAYCAST_SAMPLER=0: the four-stage sampler of round 2 (parity hook)
       if (d_.fast_div) hipLaunchKernelGGL((k_raycast2<true, false, 0>), grid, block, 0, st, dv, P, d_bgr, d_depth, d_flag, (unsigned long long *)nullptr);
       else hipLaunchKernelGGL((k_raycast2<false, false, 0>), grid, block, 0, st, dv, P, d_bgr, d_depth, d_flag, (unsigned long long *)nullptr);
-    } else if (raycast_sampler_ == 1) {  // DR_RAYCAST_SAMPLER=1: round 3's sampler, 9 + 9 gathers in two round trips (A/B and parity hook)
+    } else if (raycast_sampler_ == 1) {  // DR_RAYCAST_SAMPLER=1: round 3's sampler, 9 + 9 gathers in two round trips (parity hook)
       if (d_.fast_div) hipLaunchKernelGGL((k_raycast2<true, false, 1>), grid, block, 0, st, dv, P, d_bgr, d_depth, d_flag, (unsigned long long *)nullptr);
       else hipLaunchKernelGGL((k_raycast2<false, false, 1>), grid, block, 0, st, dv, P, d_bgr, d_depth, d_flag, (unsigned long long *)nullptr);
     } else
+#endif
     if (d_.fast_div) hipLaunchKernelGGL((k_raycast2<true, false, 2>), grid, block, 0, st, dv, P, d_bgr, d_depth, d_flag, (unsigned long long *)nullptr);
     else hipLaunchKernelGGL((k_raycast2<false, false, 2>), grid, block, 0, st, dv, P, d_bgr, d_depth, d_flag, (unsigned long long *)nullptr);
     hipLaunchKernelGGL(k_raycast_fix, dim3(512), dim3(64), 0, st, d_, P, d_bgr, d_depth, d_flag);
@@ -1366,7 +1329,7 @@ class FusionEngine {
   // render -> host (k_publish); DR_RENDER_D2H=copy: the two hipMemcpyAsync of round 2 (A/B hook)
   void publish_render(int i) {
     auto &r = renders_[i];
-    if (render_copy_) {
+    if (render_copy_) {  // (parity build only)
       DR_HIP(hipMemcpyAsync(r.h_bgr[free_slot_], r.d_bgr, npix_ * 3, hipMemcpyDeviceToHost, r.stream));
       DR_HIP(hipMemcpyAsync(r.h_depth[free_slot_], r.d_depth, npix_ * 4, hipMemcpyDeviceToHost, r.stream));
       return;
@@ -1719,12 +1682,18 @@ class FusionEngine {
   float *d_depth_in_ = nullptr, *h_depth_in_ = nullptr;
   int integrate_grid_ = 4096;
   unsigned long long fast_div_mismatches_ = 0;
-  bool raycast_v1_ = getenv("DR_RAYCAST_V1") != nullptr;  // A/B hook: the literal first-generation ray-caster
-  bool raycast_no_skip_ = getenv("DR_RAYCAST_NO_SKIP") != nullptr;  // A/B hook: no empty-space skip in k_raycast2
-  // which sampler k_raycast2 uses (see its SAMPLER parameter); DR_RAYCAST_UNSTAGED=1 is the old spelling of sampler 0
+  // switches, read once here.  Product: the empty-space skip's A/B switch (a run-time flag of the same kernel) and DR_FUSION_IEEE_DIV (the
+  // IEEE-division instances are the product's fallback when the exact fast division fails its check).  Parity build (-DDR_PARITY_HOOKS):
+  // the superseded generations -- the literal ray-caster, the 4-stage and 18-gather samplers, copy-engine result transfers, statistics.
+  bool raycast_no_skip_ = getenv("DR_RAYCAST_NO_SKIP") != nullptr;
+#ifdef DR_PARITY_HOOKS
+  bool raycast_v1_ = getenv("DR_RAYCAST_V1") != nullptr;
   int raycast_sampler_ = getenv("DR_RAYCAST_SAMPLER") ? std::max(0, std::min(2, atoi(getenv("DR_RAYCAST_SAMPLER")))) : (getenv("DR_RAYCAST_UNSTAGED") ? 0 : 2);
   bool render_copy_ = getenv("DR_RENDER_D2H") && !strcmp(getenv("DR_RENDER_D2H"), "copy");
   bool raycast_stats_ = getenv("DR_RAYCAST_STATS") != nullptr;     // measuring hook: iteration statistics of k_raycast2 on stderr
+#else
+  static constexpr bool render_copy_ = false;
+#endif
   unsigned long long *d_rstats_ = nullptr;
   std::vector<Render> renders_;
   int free_slot_ = 0;

@@ -176,6 +176,37 @@ __global__ __launch_bounds__(256) void k_publish4(const float4 *__restrict__ a, 
   }
 }
 
+// Every DR_* switch of the engine, read ONCE when the engine is created (nothing on the launch path calls getenv).  Tuning knobs and
+// the two fallback kernels (k_costvol2, k_regress) are part of the product; switches that select a SUPERSEDED kernel generation
+// exist only in the parity build (-DDR_PARITY_HOOKS, libdr_mi355x_hooks.so: what the tests that compare generations load).
+struct MvsSwitches {
+  static int num(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+  static bool on(const char *name) { return getenv(name) != nullptr; }
+  bool side_stream = !on("DR_MVS_NO_SIDE_STREAM");       // FeatureNet's stage-2/3 heads on a second stream (off: strictly sequential kernels, for profiles)
+  int conv_print = num("DR_CONV_PRINT", 0);              // autotune / debug printing
+  std::string autotune_only = getenv("DR_AUTOTUNE_ONLY") ? getenv("DR_AUTOTUNE_ONLY") : "";  // tuning: restrict autotune to layers whose name contains this
+  int cv_dchunk[3] = {num("DR_CV_DCHUNK1", 0), num("DR_CV_DCHUNK2", 0), num("DR_CV_DCHUNK3", 0)};  // tuning: depth planes per cost-volume workgroup (0: default)
+  int prob_zchunk = num("DR_PROB_ZCHUNK", 0);            // tuning: z-march chunk of k_prob2 (0: default)
+  int hist_blocks = std::max(1, num("DR_HIST_BLOCKS", 128));  // workgroups of a histogram level (each flushes its bins with atomics on a few hot addresses)
+  bool costvol_v2 = on("DR_COSTVOL_V2");                 // k_costvol2 (the fallback for depth chunks that are not multiples of 4) everywhere
+  bool regress_generic = on("DR_REGRESS_GENERIC");       // k_regress (the fallback for other plane counts) everywhere
+  bool shard_allreduce = on("DR_SHARD_ALLREDUCE");       // view shard: round 2's all-reduce form instead of reduce + broadcast
+#ifdef DR_PARITY_HOOKS
+  bool costvol_v1 = on("DR_COSTVOL_V1");                 // round 2's k_costvol on unpadded feature maps
+  int costvol_cpl = num("DR_COSTVOL_CPL", 4) == 8 ? 8 : 4;
+  bool prob_v1 = on("DR_PROB_V1");                       // round 2's k_prob (L1 gathers)
+  int prob_block = std::max(64, std::min(256, num("DR_PROB_BLOCK", 256) / 64 * 64)), prob_xo = num("DR_PROB_XO", 1);
+  bool prob_launch_order = on("DR_PROB_LAUNCH_ORDER"), prob_on_conv = on("DR_PROB_ON_CONV");
+  bool skip_on_conv = on("DR_SKIP_ON_CONV"), no_skip_fusion = on("DR_NO_SKIP_FUSION");
+  bool out3_folded = num("DR_OUT3_FOLDED", 1) != 0;      // 0: FeatureNet's stage-3 head in its literal order (fused-skip kernel)
+  bool d2h_copy = getenv("DR_MVS_D2H") && !strcmp(getenv("DR_MVS_D2H"), "copy");  // four copy-engine transfers instead of k_publish4
+#else
+  static constexpr bool costvol_v1 = false, prob_v1 = false, prob_launch_order = false, prob_on_conv = false, skip_on_conv = false,
+                        no_skip_fusion = false, out3_folded = true, d2h_copy = false;
+  static constexpr int costvol_cpl = 4, prob_block = 256, prob_xo = 1;
+#endif
+};
+
 class MvsEngine {
  public:
   MvsEngine(const char *path, int device) : device_(device), blob_(load_blob(path)) {
@@ -185,7 +216,7 @@ class MvsEngine {
     DR_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     DR_HIP(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
     for (auto *e : {&ev_fork_, &ev_feat2_, &ev_feat3_}) DR_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
-    side_enabled_ = !getenv("DR_MVS_NO_SIDE_STREAM");
+    side_enabled_ = sw_.side_stream;
     std::vector<float> lut(256);
     for (int i = 0; i < 256; ++i) lut[i] = (float)((double)(float)i / 255.0);
     lut_ = consts_.upload(lut);
@@ -288,8 +319,8 @@ class MvsEngine {
       return t / 8;
     };
     double t_before = 0, t_after = 0;
-    const bool print = getenv("DR_CONV_PRINT") != nullptr;
-    const char *only = getenv("DR_AUTOTUNE_ONLY");  // tuning hook: restrict to layers whose name contains this
+    const bool print = sw_.conv_print > 0;
+    const char *only = sw_.autotune_only.empty() ? nullptr : sw_.autotune_only.c_str();
     for (Op &o : ops_) {
       if (o.kind != Op::CONV || !o.replan || (only && o.name.find(only) == std::string::npos)) continue;
       const float t0 = time_launch(o.conv);
@@ -299,7 +330,7 @@ class MvsEngine {
       for (int r = 1; r < std::min(k, o.ncand); ++r) {
         const ConvLaunch c = o.replan(r);
         const float t = time_launch(c);
-        if (print && atoi(getenv("DR_CONV_PRINT")) > 1)
+        if (sw_.conv_print > 1)
           fprintf(stderr, "  cand %-12s rank %2d %s<%d,%d,%d> tile %dx%dx%d lds %zu KB grid %u: %.4f ms\n", o.name.c_str(), r, (c.async == 2 ? (c.march.rm ? "rowmarch" : "march") : (c.async ? "async" : "")), c.ci, c.ct, c.pt,
                   c.args.TZ, c.args.TY, c.args.TXT * 16, c.lds_bytes >> 10, c.grid.x, t);
         if (t < best * 0.98f) { best = t; best_rank = r; best_c = c; }
@@ -428,8 +459,8 @@ class MvsEngine {
       else if (o.kind == Op::CONV && o.conv.async) snprintf(kn, sizeof kn, "k_conv_a<%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt);
       else if (o.kind == Op::CONV && o.conv.bf3) snprintf(kn, sizeof kn, "k_conv_b<%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt);
       else if (o.kind == Op::CONV) snprintf(kn, sizeof kn, "k_conv<%d,%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt, o.conv.fz);
-      else if (o.kind == Op::COSTVOL) snprintf(kn, sizeof kn, costvol_v1_ ? "k_costvol<%d>" : (costvol_v2_ ? "k_costvol2<%d>" : "k_costvol3<%d>"), 32 >> (o.stage - 1));
-      else if (o.kind == Op::PROB) snprintf(kn, sizeof kn, getenv("DR_PROB_V1") ? "k_prob" : "k_prob2");
+      else if (o.kind == Op::COSTVOL) snprintf(kn, sizeof kn, sw_.costvol_v1 ? "k_costvol<%d>" : (sw_.costvol_v2 ? "k_costvol2<%d>" : "k_costvol3<%d>"), 32 >> (o.stage - 1));
+      else if (o.kind == Op::PROB) snprintf(kn, sizeof kn, sw_.prob_v1 ? "k_prob" : "k_prob2");
       else if (o.kind == Op::REGRESS) snprintf(kn, sizeof kn, "k_regress");
       else if (o.kind == Op::PREPROCESS) snprintf(kn, sizeof kn, "k_preprocess");
       else if (o.kind == Op::SKIPUP) snprintf(kn, sizeof kn, "k_skip_up<%d>", o.stage);
@@ -474,7 +505,7 @@ class MvsEngine {
           DR_HIP(hipSetDevice(device_));
           forward(nullptr);
           const size_t n = (size_t)H_ * W_ * 4;
-          if (out_copy_) {  // DR_MVS_D2H=copy: the four copy-engine transfers of round 2 (A/B hook)
+          if (sw_.d2h_copy) {  // DR_MVS_D2H=copy: the four copy-engine transfers of round 2 (A/B hook)
             DR_HIP(hipMemcpyAsync(h_out_, T("depth").d, n, hipMemcpyDeviceToHost, stream_));
             DR_HIP(hipMemcpyAsync(h_out_ + n / 4, T("confidence").d, n, hipMemcpyDeviceToHost, stream_));
             DR_HIP(hipMemcpyAsync(h_out_ + 2 * (n / 4), T("depth3").d, n, hipMemcpyDeviceToHost, stream_));
@@ -532,7 +563,7 @@ class MvsEngine {
     const HostTensor &w = blob_.at(wname + ".weight");
     // (measured at 640x480x7: stage 3, Cin = 8: 0.141 -> 0.108 ms; stage 2, Cin = 16, a quarter of the pixels and twice the
     // weights per lane: 0.038 -> 0.073 ms, so that one stays where it was)
-    if (getenv("DR_SKIP_ON_CONV") || w.dims[0] != 32 || w.dims[1] != in.C || in.C != 8 || coarse.C != 32 ||
+    if (!kParityHooks || sw_.skip_on_conv || w.dims[0] != 32 || w.dims[1] != in.C || in.C != 8 || coarse.C != 32 ||
         coarse.H * 2 != in.H || coarse.W * 2 != in.W)
       return add_conv(opname, wname, "", true, false, in, outname, 1, 1, 1, 1, 1, 1, false, CONV_NORMAL, &coarse, 2);
     DevTensor &out = alloc(outname, in.D, in.H, in.W, 32);
@@ -661,7 +692,7 @@ class MvsEngine {
     DevTensor &c1b = cbr2("fn.conv2.1", fn + "conv2.1", c1a, 3, 1, CONV_NORMAL);
     DevTensor &c1 = cbr2("fn.conv2.2", fn + "conv2.2", c1b, 3, 1, CONV_NORMAL);
     // feature maps handed to the cost volume carry a one-pixel zero border (k_costvol2); DR_COSTVOL_V1=1: the unpadded layout + k_costvol
-    const int fpad = costvol_v1_ ? 0 : 1;
+    const int fpad = sw_.costvol_v1 ? 0 : 1;
     add_conv("fn.out1", fn + "out.stage1", "", false, false, c1, "feat1", 1, 1, 1, 1, 1, 1, false, CONV_NORMAL, nullptr, 0, nullptr, fpad);
     fork_lo_ = ops_.size();
     DevTensor &i2 = add_skip("fn.skip2", fn + "skip.stage2", c2, "inter2", c1);
@@ -677,8 +708,7 @@ class MvsEngine {
     // add their rows in place (ConvLayer::up2: the upsampled tensor never exists), and a border kernel.  11.0 GFLOP become 6.9, the
     // 275 MB inter3 and the skip staging disappear, and all three convolutions run on the persistent kernels (0.22 -> 0.13 ms).
     // feat3 then differs from the literal order by fp32 reassociation (2e-6 of its range).  DR_OUT3_FOLDED=0: the fused-skip form.
-    const char *fold_env = getenv("DR_OUT3_FOLDED");
-    if ((!fold_env || atoi(fold_env) != 0) && !getenv("DR_NO_SKIP_FUSION") && !getenv("DR_SKIP_ON_CONV") && w3.dims[0] == 32 && w3.dims[1] == 8 && c3.C == 8 &&
+    if (sw_.out3_folded && !sw_.no_skip_fusion && !sw_.skip_on_conv && w3.dims[0] == 32 && w3.dims[1] == 8 && c3.C == 8 &&
         i2.C == 32 && wo3.dims[0] == 8 && wo3.dims[1] == 32 && i2.H * 2 == c3.H && i2.W * 2 == c3.W) {
       const std::vector<float> &b3 = blob_.at(fn + "skip.stage3.bias").data;
       std::vector<float> wa((size_t)8 * 8 * 9), T(9 * 8), bint(8, 0.f);
@@ -705,8 +735,8 @@ class MvsEngine {
       o.stage = fpad; o.bytes = 64.0 * c3.D * (c3.H + c3.W);
       ops_.push_back(o);
     } else
-    if (!getenv("DR_NO_SKIP_FUSION") && !getenv("DR_SKIP_ON_CONV") && w3.dims[0] == 32 && w3.dims[1] == 8 && c3.C == 8 && i2.C == 32 &&
-        i2.H * 2 == c3.H && i2.W * 2 == c3.W) {
+    if (!sw_.no_skip_fusion && !sw_.skip_on_conv && kParityHooks && w3.dims[0] == 32 && w3.dims[1] == 8 && c3.C == 8 && i2.C == 32 &&
+        i2.H * 2 == c3.H && i2.W * 2 == c3.W) {  // (parity build only: the fused-skip kernel instances are not in the product library)
       ConvFuse fz{c3.d, plan_arena_->upload(w3.data), plan_arena_->upload(blob_.at(fn + "skip.stage3.bias").data), i2.d, 8};
       DevTensor virt; virt.D = c3.D; virt.H = c3.H; virt.W = c3.W; virt.C = 32; virt.d = nullptr;  // inter3 exists in LDS only
       add_conv("fn.out3", fn + "out.stage3", "", false, false, virt, "feat3", 1, 3, 3, 1, 1, 1, false, CONV_XPAIR, nullptr, 0, &fz, fpad);
@@ -738,7 +768,7 @@ class MvsEngine {
       DevTensor &x7 = dbr3(pre + "conv7", cr + "conv7", k6, four ? 1 : 2, k4);
       DevTensor &x9 = dbr3(pre + "conv9", cr + "conv9", x7, 2, k2);
       DevTensor &x11 = dbr3(pre + "conv11", cr + "conv11", x9, 2, c0);
-      if (getenv("DR_PROB_ON_CONV") && w % 8 == 0) {
+      if (sw_.prob_on_conv && w % 8 == 0) {
         // A/B hook: the Cout = 1 head as 8 x-shifts per column on the MFMA kernel (CONV_X8, 50 % of the rows carry work);
         // measured against k_prob in profiles/r02_experiments.txt
         add_conv(pre + "prob", cr + "prob", "", false, false, x11, "logits" + S, 3, 3, 3, 1, 1, 1, false, CONV_X8, nullptr, 0);
@@ -778,8 +808,12 @@ class MvsEngine {
     std::vector<int> order;
     order.push_back(ref);
     for (int i = 0; i < V; ++i) if (i != ref) order.push_back(i);
-    for (int v = 0; v < V; ++v) memcpy(h_in_ + v * img_bytes, bgrs[order[v]], img_bytes);
-    DR_HIP(hipMemcpyAsync(d_bgr_, h_in_, V * img_bytes, hipMemcpyHostToDevice, stream_));
+    // view by view: the copy engine moves view v to the device while the host gathers view v + 1 into the pinned block (one 6.45 MB
+    // transfer behind seven memcpys cost their sum: 0.3 + 0.2 ms at 640 x 480 x 7 on the operator boundary's critical path)
+    for (int v = 0; v < V; ++v) {
+      memcpy(h_in_ + v * img_bytes, bgrs[order[v]], img_bytes);
+      DR_HIP(hipMemcpyAsync(d_bgr_ + v * img_bytes, h_in_ + v * img_bytes, img_bytes, hipMemcpyHostToDevice, stream_));
+    }
 
     // stage intrinsics: rows 0-1 x 0.25 / 0.5 / 1 (the C++ rule, dr_mvsnet.cpp:226-247)
     double w2c[8][16];
@@ -801,7 +835,7 @@ class MvsEngine {
       a.vol = T("volume" + std::to_string(s)).d;
       a.V = V; a.h = h; a.w = w;
       a.dchunk = s == 1 ? 4 : (D >= 16 ? 8 : D);  // enough workgroups to fill 256 CUs at every stage
-      if (const char *e = getenv(s == 1 ? "DR_CV_DCHUNK1" : (s == 2 ? "DR_CV_DCHUNK2" : "DR_CV_DCHUNK3"))) a.dchunk = std::max(1, std::min(D, atoi(e)));  // tuning hook
+      if (sw_.cv_dchunk[s - 1] > 0) a.dchunk = std::min(D, sw_.cv_dchunk[s - 1]);  // tuning hook
       a.view_aggregation = blob_.view_aggregation;
       // view sharding: this rank's window holds a subset of the source views, the divisor stays the whole window's
       if (shard_nsrc_ && !blob_.view_aggregation) fail(DR_ERR_UNSUPPORTED, "view sharding needs a view-aggregation model (the variance volume is not a sum over views)");
@@ -864,7 +898,7 @@ class MvsEngine {
   void forward(std::vector<hipEvent_t> *ev, size_t first = 0, size_t last = ~(size_t)0) {
     const bool fork = side_enabled_ && !ev && first == 0 && last >= ops_.size() && fork_lo_ < fork_hi_;
     // view shard, reduce-to-root form: between a stage's cost volume and its regression only rank 0 works
-    const bool rooted = comm_ && shard_nsrc_ && !phase_mode_ && !shard_allreduce_;
+    const bool rooted = comm_ && shard_nsrc_ && !phase_mode_ && !sw_.shard_allreduce;
     bool idle_stage = false;
     size_t i = 0;
     for (const Op &o : ops_) {
@@ -894,72 +928,74 @@ class MvsEngine {
           break;
         }
         case Op::SKIPUP: {
+#ifdef DR_PARITY_HOOKS
           const size_t npix = (size_t)o.d0 * o.d1 * o.d2;
           const dim3 grid((unsigned)std::min<size_t>((npix + 31) / 32, 8192));
           hipLaunchKernelGGL(k_skip_up<8>, grid, dim3(256), 0, stream_, o.p0, o.p1, o.p3, o.p4, o.p2, o.d0, o.d1, o.d2);
+#endif
           break;
         }
-        case Op::PROB:
-        {
+        case Op::PROB: {
           // z-march chunk: long chunks amortise the 2 halo planes, but the launch needs ~1000 waves to fill the chip
           // (tools/gpu_sweep_chunks.sh: 48x120x160 -> 4, 32x240x320 -> 8, 8x480x640 -> 8)
-          int zchunk = std::min(o.d0, 8);
-          while (zchunk > 2 && cdiv(o.d1 * (o.d2 / 4), 64) * cdiv(o.d0, zchunk) < 800) zchunk /= 2;
-          if (const char *e = getenv("DR_PROB_ZCHUNK")) zchunk = std::max(1, std::min(o.d0, atoi(e)));  // tuning hook
-          int pb = 256, xo = 1;  // r2 sweep: one output column per lane (4x the waves) beats the 4-column variant 0.204 -> 0.124 ms over the three stages
-          if (const char *e = getenv("DR_PROB_BLOCK")) pb = std::max(64, std::min(256, atoi(e) / 64 * 64));  // tuning hooks
-          if (const char *e = getenv("DR_PROB_XO")) xo = atoi(e) == 2 ? 2 : (atoi(e) == 4 ? 4 : 1);
-          if (!getenv("DR_PROB_V1")) {  // LDS-staged plane tiles (k_prob2); DR_PROB_V1=1: the L1-gather kernel (A/B hook)
-            int zc = std::min(o.d0, 8);
-            while (zc > 2 && cdiv(o.d1, kProbTY) * cdiv(o.d2, kProbTX) * cdiv(o.d0, zc) < 1024) zc /= 2;  // ~4 workgroups per CU
-            if (const char *e = getenv("DR_PROB_ZCHUNK")) zc = std::max(1, std::min(o.d0, atoi(e)));
-            const int gxp = cdiv(o.d2, kProbTX), gyp = cdiv(o.d1, kProbTY), gzp = cdiv(o.d0, zc), nw = gxp * gyp * gzp;
-            hipLaunchKernelGGL(k_prob2, dim3(8 * cdiv(nw, 8)), dim3(256), 0, stream_, o.p0, o.p1, o.p2, o.d0, o.d1, o.d2, zc, gxp, gyp, gzp, nw);
+#ifdef DR_PARITY_HOOKS
+          if (sw_.prob_v1) {  // round 2's L1-gather kernel: one output column per lane (r2 sweep: 4x the waves beats the 4-column variant)
+            int zchunk = std::min(o.d0, 8);
+            while (zchunk > 2 && cdiv(o.d1 * (o.d2 / 4), 64) * cdiv(o.d0, zchunk) < 800) zchunk /= 2;
+            if (sw_.prob_zchunk > 0) zchunk = std::min(o.d0, sw_.prob_zchunk);
+            const int pb = sw_.prob_block, xo = sw_.prob_xo == 2 ? 2 : (sw_.prob_xo == 4 ? 4 : 1);
+            dim3 grid(cdiv(o.d1 * (o.d2 / xo), pb), cdiv(o.d0, zchunk));
+            int gz = 0, nwg = 0;
+            if (!sw_.prob_launch_order) {  // XCD-band workgroup order (A/B hook: the plain 2-D launch order)
+              gz = (int)grid.y; nwg = (int)(grid.x * grid.y);
+              grid = dim3(8 * cdiv(nwg, 8));
+            }
+            if (xo == 4) hipLaunchKernelGGL(k_prob<4>, grid, dim3(pb), 0, stream_, o.p0, o.p1, o.p2, o.d0, o.d1, o.d2, zchunk, gz, nwg);
+            else if (xo == 2) hipLaunchKernelGGL(k_prob<2>, grid, dim3(pb), 0, stream_, o.p0, o.p1, o.p2, o.d0, o.d1, o.d2, zchunk, gz, nwg);
+            else hipLaunchKernelGGL(k_prob<1>, grid, dim3(pb), 0, stream_, o.p0, o.p1, o.p2, o.d0, o.d1, o.d2, zchunk, gz, nwg);
             break;
           }
-          dim3 grid(cdiv(o.d1 * (o.d2 / xo), pb), cdiv(o.d0, zchunk));
-          int gz = 0, nwg = 0;
-          if (!getenv("DR_PROB_LAUNCH_ORDER")) {  // XCD-band workgroup order (A/B hook: the plain 2-D launch order)
-            gz = (int)grid.y; nwg = (int)(grid.x * grid.y);
-            grid = dim3(8 * cdiv(nwg, 8));
-          }
-          if (xo == 4) hipLaunchKernelGGL(k_prob<4>, grid, dim3(pb), 0, stream_, o.p0, o.p1, o.p2, o.d0, o.d1, o.d2, zchunk, gz, nwg);
-          else if (xo == 2) hipLaunchKernelGGL(k_prob<2>, grid, dim3(pb), 0, stream_, o.p0, o.p1, o.p2, o.d0, o.d1, o.d2, zchunk, gz, nwg);
-          else hipLaunchKernelGGL(k_prob<1>, grid, dim3(pb), 0, stream_, o.p0, o.p1, o.p2, o.d0, o.d1, o.d2, zchunk, gz, nwg);
-        }
+#endif
+          int zc = std::min(o.d0, 8);  // LDS-staged plane tiles (k_prob2)
+          while (zc > 2 && cdiv(o.d1, kProbTY) * cdiv(o.d2, kProbTX) * cdiv(o.d0, zc) < 1024) zc /= 2;  // ~4 workgroups per CU
+          if (sw_.prob_zchunk > 0) zc = std::min(o.d0, sw_.prob_zchunk);
+          const int gxp = cdiv(o.d2, kProbTX), gyp = cdiv(o.d1, kProbTY), gzp = cdiv(o.d0, zc), nw = gxp * gyp * gzp;
+          hipLaunchKernelGGL(k_prob2, dim3(8 * cdiv(nw, 8)), dim3(256), 0, stream_, o.p0, o.p1, o.p2, o.d0, o.d1, o.d2, zc, gxp, gyp, gzp, nw);
           break;
+        }
         case Op::COSTVOL: {
           const CostVolArgs &a = cv_[o.stage - 1];
           const int C = 32 >> (o.stage - 1);
-          // channels per lane: 4 = the lanes of a pixel read its whole record with one instruction (fewest L1 line
-          // accesses per byte: the kernel is bound by the L1's one tag look-up per cycle), 8 = half the per-pixel
-          // projection / tap arithmetic.  DR_COSTVOL_CPL=4|8 overrides (A/B hook).
-          int cpl = C >= 16 ? cpl_wide_ : 4;
-          const int pxb = 256 / (C / cpl);
           if (a.V - 1 <= 0) {  // a view-shard rank that holds the reference view only: its partial volume is the empty sum (the kernels return without storing)
             const DevTensor &vol0 = T("volume" + std::to_string(o.stage));
             DR_HIP(hipMemsetAsync(vol0.d, 0, vol0.n() * 4, stream_));
           }
           CostVolArgs b = a;
-          b.gx = cdiv(a.w, pxb); b.gz = cdiv(a.planes.D, a.dchunk); b.nwg = b.gx * b.gz * a.h;
-          dim3 grid(8 * cdiv(b.nwg, 8));
-          if (a.fpad) {  // bordered feature maps: 4 channels per lane, no per-tap validity logic
+          b.gz = cdiv(a.planes.D, a.dchunk);
+#ifdef DR_PARITY_HOOKS
+          if (!a.fpad) {  // DR_COSTVOL_V1: round 2's kernel on unpadded feature maps; channels per lane 4 (fewest L1 line accesses per byte) or 8
+            const int cpl = C >= 16 ? sw_.costvol_cpl : 4, pxb = 256 / (C / cpl);
+            b.gx = cdiv(a.w, pxb); b.nwg = b.gx * b.gz * a.h;
+            const dim3 grid1(8 * cdiv(b.nwg, 8));
+            if (C == 32 && cpl == 8) hipLaunchKernelGGL((k_costvol<32, 8>), grid1, dim3(256), 0, stream_, b);
+            else if (C == 32) hipLaunchKernelGGL((k_costvol<32, 4>), grid1, dim3(256), 0, stream_, b);
+            else if (C == 16 && cpl == 8) hipLaunchKernelGGL((k_costvol<16, 8>), grid1, dim3(256), 0, stream_, b);
+            else if (C == 16) hipLaunchKernelGGL((k_costvol<16, 4>), grid1, dim3(256), 0, stream_, b);
+            else hipLaunchKernelGGL((k_costvol<8, 4>), grid1, dim3(256), 0, stream_, b);
+          } else
+#endif
+          {  // bordered feature maps: 4 channels per lane, no per-tap validity logic
             b.gx = cdiv(a.w, 1024 / C); b.nwg = b.gx * b.gz * a.h;
-            grid = dim3(8 * cdiv(b.nwg, 8));
+            const dim3 grid(8 * cdiv(b.nwg, 8));
             // k_costvol3 (the lanes of a pixel share the per-sample set-up) needs whole batches of 4 iterations per depth chunk
-            const bool v3 = !costvol_v2_ && a.dchunk % 4 == 0 && a.planes.D % 4 == 0;
+            const bool v3 = !sw_.costvol_v2 && a.dchunk % 4 == 0 && a.planes.D % 4 == 0;
             if (v3 && C == 32) hipLaunchKernelGGL((k_costvol3<32>), grid, dim3(256), 0, stream_, b);
             else if (v3 && C == 16) hipLaunchKernelGGL((k_costvol3<16>), grid, dim3(256), 0, stream_, b);
             else if (v3) hipLaunchKernelGGL((k_costvol3<8>), grid, dim3(256), 0, stream_, b);
             else if (C == 32) hipLaunchKernelGGL((k_costvol2<32>), grid, dim3(256), 0, stream_, b);
             else if (C == 16) hipLaunchKernelGGL((k_costvol2<16>), grid, dim3(256), 0, stream_, b);
             else hipLaunchKernelGGL((k_costvol2<8>), grid, dim3(256), 0, stream_, b);
-          } else
-          if (C == 32 && cpl == 8) hipLaunchKernelGGL((k_costvol<32, 8>), grid, dim3(256), 0, stream_, b);
-          else if (C == 32) hipLaunchKernelGGL((k_costvol<32, 4>), grid, dim3(256), 0, stream_, b);
-          else if (C == 16 && cpl == 8) hipLaunchKernelGGL((k_costvol<16, 8>), grid, dim3(256), 0, stream_, b);
-          else if (C == 16) hipLaunchKernelGGL((k_costvol<16, 4>), grid, dim3(256), 0, stream_, b);
-          else hipLaunchKernelGGL((k_costvol<8, 4>), grid, dim3(256), 0, stream_, b);
+          }
           if (comm_ && shard_nsrc_ && !phase_mode_) {  // view shard: sum the partial volumes of all ranks, in place, in stream order
             const DevTensor &vol = T("volume" + std::to_string(o.stage));
             Rccl &r = Rccl::get();
@@ -974,7 +1010,7 @@ class MvsEngine {
           const RegressArgs &r = rg_[o.stage - 1];
           if (!idle_stage) {
             const dim3 grid(cdiv(r.h * r.w, 256)), block(256);
-            const int D = regress_generic_ ? 0 : r.planes.D;  // DR_REGRESS_GENERIC=1: the three-pass kernel for every plane count (A/B and parity hook)
+            const int D = sw_.regress_generic ? 0 : r.planes.D;  // DR_REGRESS_GENERIC=1: the three-pass kernel for every plane count (A/B and parity hook)
             if (D == 48) hipLaunchKernelGGL(k_regress_r<48>, grid, block, 0, stream_, r);
             else if (D == 32) hipLaunchKernelGGL(k_regress_r<32>, grid, block, 0, stream_, r);
             else if (D == 8) hipLaunchKernelGGL(k_regress_r<8>, grid, block, 0, stream_, r);
@@ -998,7 +1034,7 @@ class MvsEngine {
           hipLaunchKernelGGL(k_edge, dim3(cdiv(H_ * W_, 256)), dim3(256), 0, stream_, T("depth3").d, T("edge").d, H_, W_);
           break;
         case Op::HIST:
-          hipLaunchKernelGGL(k_hist, dim3(std::min(cdiv(H_ * W_, 256), hist_blocks_)), dim3(256), 0, stream_, T("edge").d, H_ * W_, o.shift, o.bits, d_state_, d_hist_);
+          hipLaunchKernelGGL(k_hist, dim3(std::min(cdiv(H_ * W_, 256), sw_.hist_blocks)), dim3(256), 0, stream_, T("edge").d, H_ * W_, o.shift, o.bits, d_state_, d_hist_);
           break;
         case Op::SCAN:
           hipLaunchKernelGGL(k_scan, dim3(1), dim3(256), 0, stream_, d_state_, d_hist_, o.shift, o.bits);
@@ -1020,14 +1056,14 @@ class MvsEngine {
   hipStream_t side_ = nullptr;
   hipEvent_t ev_fork_ = nullptr, ev_feat2_ = nullptr, ev_feat3_ = nullptr;
   bool side_enabled_ = true;
-  // channels per lane of k_costvol for C >= 16 (measured: stage 2 0.210 -> 0.194 ms, stage 1 0.146 -> 0.143 ms with 4)
-  bool costvol_v1_ = getenv("DR_COSTVOL_V1") != nullptr;
-  bool costvol_v2_ = getenv("DR_COSTVOL_V2") != nullptr;  // k_costvol2 instead of k_costvol3 (A/B and parity hook)
-  bool regress_generic_ = getenv("DR_REGRESS_GENERIC") != nullptr;
-  int hist_blocks_ = getenv("DR_HIST_BLOCKS") ? std::max(1, atoi(getenv("DR_HIST_BLOCKS"))) : 128;  // workgroups of a histogram level (each flushes its bins with atomics on a few hot addresses)
-  int cpl_wide_ = getenv("DR_COSTVOL_CPL") ? (atoi(getenv("DR_COSTVOL_CPL")) == 8 ? 8 : 4) : 4;
   size_t fork_lo_ = 0, fork_hi_ = 0, feat2_op_ = 0;  // ops [fork_lo_, fork_hi_) = fn.skip2 .. fn.out3
 
+  const MvsSwitches sw_;  // read once, here
+#ifdef DR_PARITY_HOOKS
+  static constexpr bool kParityHooks = true;
+#else
+  static constexpr bool kParityHooks = false;
+#endif
   int device_;
   int *march_err_ = nullptr;
   // called after a stream synchronise: a marching convolution that gave up a wait leaves garbage behind -- report it, never return it
@@ -1046,19 +1082,17 @@ class MvsEngine {
   RegressArgs rg_[3];
   uint8_t *d_bgr_ = nullptr, *h_in_ = nullptr;
   float *h_out_ = nullptr, *h_out_dev_ = nullptr;  // pinned result block (4 maps) and the address the device uses for it
-  bool out_copy_ = getenv("DR_MVS_D2H") && !strcmp(getenv("DR_MVS_D2H"), "copy");
   unsigned *d_state_ = nullptr, *d_hist_ = nullptr;
   unsigned filter_rank_ = 0;
   int H_ = 0, W_ = 0, V_ = 0;
   int shard_nsrc_ = 0;  // > 0: view-shard rank, cost-volume divisor = source views of the whole window
   ncclComm_t comm_ = nullptr;  // view-shard communicator (drm_comm_init); the volumes are reduced in stream order when set
   int comm_world_ = 0, comm_rank_ = 0;
-  // Collective form of a sharded forward.  Default: the partial volumes are REDUCED to rank 0, which alone regularises and
-  // regresses the stage, and the stage's depth map (what the next stage's hypotheses hang on: 77 / 307 / 1229 KB) is
-  // BROADCAST back -- (n-1)/n x 354 MB over xGMI per depth map instead of the all-reduce's 2(n-1)/n, and no redundant
+  // Collective form of a sharded forward (MvsSwitches::shard_allreduce).  Default: the partial volumes are REDUCED to rank 0, which
+  // alone regularises and regresses the stage, and the stage's depth map (what the next stage's hypotheses hang on: 77 / 307 /
+  // 1229 KB) is BROADCAST back -- (n-1)/n x 354 MB over xGMI per depth map instead of the all-reduce's 2(n-1)/n, and no redundant
   // CostRegNet on the other ranks.  DR_SHARD_ALLREDUCE=1: round 2's form (sum all-reduce, every rank
   // regularises redundantly; no broadcast).
-  bool shard_allreduce_ = getenv("DR_SHARD_ALLREDUCE") != nullptr;
   bool phase_mode_ = false;
 
   std::thread worker_;

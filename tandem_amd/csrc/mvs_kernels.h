@@ -28,6 +28,7 @@ __global__ void k_preprocess(const uint8_t *__restrict__ bgr, float4 *__restrict
   img[i] = make_float4(lut[p[2]], lut[p[1]], lut[p[0]], 0.f);
 }
 
+#ifdef DR_PARITY_HOOKS  // only the literal (unfolded) order of FeatureNet's stage-3 head uses this kernel
 // ------------------------------------------------------------------ FeatureNet skip connection
 // inter = nearest_up2(coarser) + conv1x1(x) + bias   (module.py:518-531: `F.interpolate(..., scale_factor=2) + skip(...)`).
 // Cin = 8 or 16 inputs, 32 outputs per pixel: 512-1024 flop against 128 B written, 128 B re-read -- a streaming
@@ -69,6 +70,8 @@ __global__ __launch_bounds__(256) void k_skip_up(const float *__restrict__ x, co
     *reinterpret_cast<float4 *>(out + p * CO + 4 * q) = o;
   }
 }
+
+#endif  // DR_PARITY_HOOKS
 
 // ------------------------------------------------------------------ depth hypotheses
 struct PlaneArgs {
@@ -134,6 +137,7 @@ struct CostVolArgs {
 
 __device__ inline float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
+#ifdef DR_PARITY_HOOKS  // round 2's generation (DR_COSTVOL_V1), kept for the parity build
 // One lane owns CPL channels of one pixel (4: the C / 4 lanes of a pixel read its whole channels-last record with one
 // instruction -- the kernel is bound by the L1's one tag look-up per cycle, PMC: 0.8 line accesses per cycle per CU with
 // CPL = 8) and walks the depth planes of its chunk.
@@ -250,6 +254,8 @@ __global__ __launch_bounds__(256) void k_costvol(const CostVolArgs a) {
     }
   }
 }
+
+#endif  // DR_PARITY_HOOKS
 
 // k_costvol2: the same arithmetic on feature maps stored with a ONE-PIXEL ZERO BORDER ((h+2) x (w+2) per view), as a
 // software-pipelined flat loop over (plane, view).
@@ -509,6 +515,7 @@ __global__ __launch_bounds__(256) void k_costvol3(const CostVolArgs a) {
 // Workgroup order (gz > 0): as in k_costvol, XCD k (= blockIdx.x % 8, own L2) walks the k-th band of rows, z chunks of a
 // pixel block innermost -- the three input rows an output row needs and the two halo planes of a z chunk are then
 // fetched into ONE L2 (launch order spread them over all eight: PMC showed 208 MB fetched per launch against 62 MB of input).
+#ifdef DR_PARITY_HOOKS  // round 2's generation (DR_PROB_V1), kept for the parity build
 template <int XO>  // x outputs per lane (4: fewest L1 accesses per output; 2: twice the waves to hide their latency)
 __global__ __launch_bounds__(256) void k_prob(const float *__restrict__ x, const float *__restrict__ wt /*[27][8]*/,
                                               float *__restrict__ out, int D, int h, int w, int zchunk, int gz, int nwg) {
@@ -563,6 +570,8 @@ __global__ __launch_bounds__(256) void k_prob(const float *__restrict__ x, const
     for (int o = 0; o < XO; ++o) { a0[o] = a1[o]; a1[o] = a2[o]; a2[o] = 0.f; }
   }
 }
+
+#endif  // DR_PARITY_HOOKS
 
 // k_prob2: the same layer with the input plane staged through LDS.  k_prob reads every input position nine times per
 // plane from L1 (three rows x three columns per lane: 288 B per output and plane against 64 B/clk/CU of L1 bandwidth,

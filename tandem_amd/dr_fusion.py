@@ -22,12 +22,13 @@ class DrFusion:
     def __init__(self, options, device=0):
         self.options = options
         self._h = C.c_void_p()
-        check(_lib.lib().drf_create(C.byref(options), int(device), C.byref(self._h)))
+        self._L = _lib.lib()  # the library this handle belongs to (tests may switch the process default, _lib.switch)
+        check(self._L.drf_create(C.byref(options), int(device), C.byref(self._h)))
         self._hw = (options.height, options.width)
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
-            _lib.lib().drf_destroy(self._h)
+            self._L.drf_destroy(self._h)
             self._h = C.c_void_p()
 
     __del__ = close
@@ -38,19 +39,19 @@ class DrFusion:
         depth = np.ascontiguousarray(depth, np.float32)
         pose = np.ascontiguousarray(pose, np.float32).reshape(16)
         assert bgr.size == self._hw[0] * self._hw[1] * 3 and depth.size == self._hw[0] * self._hw[1]
-        check(_lib.lib().drf_integrate_scan_async(self._h, bgr.ctypes.data_as(u8p), fptr(depth), fptr(pose)))
+        check(self._L.drf_integrate_scan_async(self._h, bgr.ctypes.data_as(u8p), fptr(depth), fptr(pose)))
 
     def RenderAsync(self, camera_poses):
         """dr_fusion.h:52: exactly num_render_streams poses."""
         poses = [np.ascontiguousarray(p, np.float32).reshape(16) for p in camera_poses]
         arr = (f32p * max(len(poses), 1))(*[fptr(p) for p in poses])
-        check(_lib.lib().drf_render_async(self._h, arr, len(poses)))
+        check(self._L.drf_render_async(self._h, arr, len(poses)))
 
     def GetRenderResult(self):
         """dr_fusion.h:54: returns (bgr list, depth list); arrays are copies of the library-owned pinned buffers."""
         n = self.options.num_render_streams
         pb, pd = (u8p * max(n, 1))(), (f32p * max(n, 1))()
-        check(_lib.lib().drf_get_render_result(self._h, pb, pd, n))
+        check(self._L.drf_get_render_result(self._h, pb, pd, n))
         H, W = self._hw
         bgrs = [np.ctypeslib.as_array(pb[i], shape=(H, W, 3)).copy() for i in range(n)]
         depths = [np.ctypeslib.as_array(pd[i], shape=(H, W)).copy() for i in range(n)]
@@ -59,24 +60,24 @@ class DrFusion:
     def ExtractMeshAsync(self, lower_corner, upper_corner):
         """dr_fusion.h:60: marching cubes over the lattice lower + g * voxel_size, legal after GetRenderResult."""
         lo, up = (np.ascontiguousarray(a, np.float32) for a in (lower_corner, upper_corner))
-        check(_lib.lib().drf_extract_mesh_async(self._h, fptr(lo), fptr(up)))
+        check(self._L.drf_extract_mesh_async(self._h, fptr(lo), fptr(up)))
 
     def GetMeshSync(self):
         """dr_fusion.h:61: fills the public members dr_mesh_num (vertices = 3 * triangles), dr_mesh_vert, dr_mesh_cols
         ((num, 3) float32: positions, RGB colours in [0, 1]) and returns (vert, cols)."""
         ntri = C.c_size_t()
-        check(_lib.lib().drf_mesh_num_triangles(self._h, C.byref(ntri)))
+        check(self._L.drf_mesh_num_triangles(self._h, C.byref(ntri)))
         nv = 3 * ntri.value
         vert, cols = np.empty((max(nv, 1), 3), np.float32), np.empty((max(nv, 1), 3), np.float32)
         num = C.c_size_t()
-        check(_lib.lib().drf_get_mesh_sync(self._h, max(nv, 1), C.byref(num), fptr(vert), fptr(cols)))
+        check(self._L.drf_get_mesh_sync(self._h, max(nv, 1), C.byref(num), fptr(vert), fptr(cols)))
         self.dr_mesh_num, self.dr_mesh_vert, self.dr_mesh_cols = int(num.value), vert[:nv], cols[:nv]
         return self.dr_mesh_vert, self.dr_mesh_cols
 
     def mesh_num_triangles(self):
         """Size of the pending mesh (waits for the extraction, does not consume it)."""
         ntri = C.c_size_t()
-        check(_lib.lib().drf_mesh_num_triangles(self._h, C.byref(ntri)))
+        check(self._L.drf_mesh_num_triangles(self._h, C.byref(ntri)))
         return int(ntri.value)
 
     def GetMesh(self, lower_corner, upper_corner):
@@ -86,21 +87,21 @@ class DrFusion:
 
     def SaveMeshToFile(self, filename, lower_corner, upper_corner):
         lo, up = (np.ascontiguousarray(a, np.float32) for a in (lower_corner, upper_corner))
-        check(_lib.lib().drf_save_mesh(self._h, str(filename).encode(), fptr(lo), fptr(up)))
+        check(self._L.drf_save_mesh(self._h, str(filename).encode(), fptr(lo), fptr(up)))
 
     def render_device_pointers(self, stream=0):
         """(d_bgr, d_depth) device pointers of a render stream's result, valid until the next RenderAsync."""
         b, d = C.c_void_p(), C.c_void_p()
-        check(_lib.lib().drf_get_render_device(self._h, stream, C.byref(b), C.byref(d)))
+        check(self._L.drf_get_render_device(self._h, stream, C.byref(b), C.byref(d)))
         return b.value, d.value
 
     def Synchronize(self):
-        check(_lib.lib().drf_synchronize(self._h))
+        check(self._L.drf_synchronize(self._h))
 
     # ---- introspection / measurement hooks (no reference counterpart) ----
     def stats(self):
         out = (C.c_uint64 * 4)()
-        check(_lib.lib().drf_stats(self._h, out))
+        check(self._L.drf_stats(self._h, out))
         return dict(blocks=int(out[0]), updated_last=int(out[1]), updated_total=int(out[2]), mismatches=int(out[3]))
 
     def export_blocks(self):
@@ -109,14 +110,14 @@ class DrFusion:
         coords = np.empty((max(n, 1), 3), np.int32)
         vox = np.empty((max(n, 1), 4096), np.uint8)
         got = C.c_int()
-        check(_lib.lib().drf_export_blocks(self._h, n, coords.ctypes.data_as(C.POINTER(C.c_int32)),
+        check(self._L.drf_export_blocks(self._h, n, coords.ctypes.data_as(C.POINTER(C.c_int32)),
                                            vox.ctypes.data_as(u8p), C.byref(got)))
         return {tuple(int(v) for v in coords[i]): vox[i] for i in range(got.value)}
 
     def fast_div_status(self):
         """(enabled, mismatches) of the exact fast division self-check run at construction."""
         en, mm = C.c_int(), C.c_uint64()
-        check(_lib.lib().drf_fast_div_status(self._h, C.byref(en), C.byref(mm)))
+        check(self._L.drf_fast_div_status(self._h, C.byref(en), C.byref(mm)))
         return bool(en.value), int(mm.value)
 
     def test_combine(self, a, b, max_weight):
@@ -124,7 +125,7 @@ class DrFusion:
         a, b = np.ascontiguousarray(a, np.uint8), np.ascontiguousarray(b, np.uint8)
         assert a.shape == b.shape and a.shape[1] == 8
         out = np.empty_like(a)
-        check(_lib.lib().drf_test_combine(self._h, a.shape[0], a.ctypes.data_as(u8p), b.ctypes.data_as(u8p), int(max_weight),
+        check(self._L.drf_test_combine(self._h, a.shape[0], a.ctypes.data_as(u8p), b.ctypes.data_as(u8p), int(max_weight),
                                           out.ctypes.data_as(u8p)))
         return out
 
@@ -133,12 +134,12 @@ class DrFusion:
         milliseconds -- total (hipEvents), allocate / integrate / raycast / d2h sums, host wall clock."""
         ps = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
         ms = (C.c_float * 6)()
-        check(_lib.lib().drf_bench_sequence(self._h, C.c_void_p(d_bgr), C.c_void_p(d_depth), fptr(ps), ps.shape[0], int(bool(render)), ms))
+        check(self._L.drf_bench_sequence(self._h, C.c_void_p(d_bgr), C.c_void_p(d_depth), fptr(ps), ps.shape[0], int(bool(render)), ms))
         return dict(total=ms[0], allocate=ms[1], integrate=ms[2], raycast=ms[3], d2h=ms[4], wall=ms[5])
 
     def bench_integrate(self, bgrs, depths, poses):
         """Uploads the scans once, then times back-to-back allocate+integrate of all of them (HBM-resident)."""
-        L = _lib.lib()
+        L = self._L
         n = len(bgrs)
         bg = np.ascontiguousarray(np.stack(bgrs), np.uint8)
         dp = np.ascontiguousarray(np.stack(depths), np.float32)

@@ -45,12 +45,13 @@ class DrMvsnet:
     def __init__(self, filename, device=0):
         """dr_mvsnet.h:38 `explicit DrMvsnet(char const* filename)`; filename = TDMW weight blob."""
         self._h = C.c_void_p()
-        check(_lib.lib().drm_create(str(filename).encode(), int(device), C.byref(self._h)))
+        self._L = _lib.lib()  # the library this handle belongs to (tests may switch the process default, _lib.switch)
+        check(self._L.drm_create(str(filename).encode(), int(device), C.byref(self._h)))
         self._hw = None
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
-            _lib.lib().drm_destroy(self._h)
+            self._L.drm_destroy(self._h)
             self._h = C.c_void_p()
 
     __del__ = close
@@ -60,22 +61,22 @@ class DrMvsnet:
         """dr_mvsnet.h:43-53.  Blocking for the last input, non-blocking for this one."""
         assert len(bgrs) == view_num and len(cam_to_worlds) == view_num
         keep = _marshal(bgrs, intrinsic_matrix, cam_to_worlds, height, width)
-        check(_lib.lib().drm_call_async(self._h, height, width, view_num, ref_index, keep[3], fptr(keep[2]), keep[4],
+        check(self._L.drm_call_async(self._h, height, width, view_num, ref_index, keep[3], fptr(keep[2]), keep[4],
                                         depth_min, depth_max, discard_percentage))
         self._hw = (height, width)
 
     def Ready(self):
-        return bool(_lib.lib().drm_ready(self._h))
+        return bool(self._L.drm_ready(self._h))
 
     def Wait(self):
-        check(_lib.lib().drm_wait(self._h))
+        check(self._L.drm_wait(self._h))
 
     def GetResult(self):
         """dr_mvsnet.h:56 -- blocking; a second call without a new CallAsync is a protocol error."""
         if self._hw is None:
             raise _lib.DrError(2, "GetResult before CallAsync")
         out = DrMvsnetOutput(*self._hw)
-        check(_lib.lib().drm_get_result(self._h, fptr(out.depth), fptr(out.confidence), fptr(out.depth_dense),
+        check(self._L.drm_get_result(self._h, fptr(out.depth), fptr(out.confidence), fptr(out.depth_dense),
                                         fptr(out.confidence_dense)))
         return out
 
@@ -83,28 +84,28 @@ class DrMvsnet:
     def upload(self, height, width, view_num, ref_index, bgrs, intrinsic_matrix, cam_to_worlds, depth_min, depth_max,
                discard_percentage):
         keep = _marshal(bgrs, intrinsic_matrix, cam_to_worlds, height, width)
-        check(_lib.lib().drm_upload(self._h, height, width, view_num, ref_index, keep[3], fptr(keep[2]), keep[4],
+        check(self._L.drm_upload(self._h, height, width, view_num, ref_index, keep[3], fptr(keep[2]), keep[4],
                                     depth_min, depth_max, discard_percentage))
         self._hw = (height, width)
 
     def forward(self, iters=1):
         ms = C.c_float()
-        check(_lib.lib().drm_forward(self._h, iters, C.byref(ms)))
+        check(self._L.drm_forward(self._h, iters, C.byref(ms)))
         return ms.value
 
     def autotune(self, max_candidates=8):
         """Time the planner's top candidates per convolution layer on the device and keep the fastest (opt-in; results
         move at the 1e-7 level).  Returns (summed layer ms before, after)."""
         a, b = C.c_float(), C.c_float()
-        check(_lib.lib().drm_autotune(self._h, max_candidates, C.byref(a), C.byref(b)))
+        check(self._L.drm_autotune(self._h, max_candidates, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     # ---- view sharding hooks (include/dr_mi355x.h "view sharding"; host protocol in tandem_amd/view_shard.py) ----
     def set_view_shard(self, nsrc_total):
-        check(_lib.lib().drm_set_view_shard(self._h, int(nsrc_total)))
+        check(self._L.drm_set_view_shard(self._h, int(nsrc_total)))
 
     def forward_phase(self, phase):
-        check(_lib.lib().drm_forward_phase(self._h, int(phase)))
+        check(self._L.drm_forward_phase(self._h, int(phase)))
 
     @staticmethod
     def comm_available():
@@ -122,20 +123,20 @@ class DrMvsnet:
         """In-engine view-shard collective: afterwards a sharded window's cost volumes are reduced to rank 0 and the stage depth
         maps broadcast back on the engine's stream (include/dr_mi355x.h)."""
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
-        check(_lib.lib().drm_comm_init(self._h, int(rank), int(world), buf))
+        check(self._L.drm_comm_init(self._h, int(rank), int(world), buf))
 
     def comm_destroy(self):
-        check(_lib.lib().drm_comm_destroy(self._h))
+        check(self._L.drm_comm_destroy(self._h))
 
     def device_tensor(self, name):
         """(device pointer, float count) of a named internal tensor, e.g. "volume2"."""
         ptr, n = C.c_void_p(), C.c_size_t()
-        check(_lib.lib().drm_device_tensor(self._h, name.encode(), C.byref(ptr), C.byref(n)))
+        check(self._L.drm_device_tensor(self._h, name.encode(), C.byref(ptr), C.byref(n)))
         return ptr.value, int(n.value)
 
     def download(self):
         out = DrMvsnetOutput(*self._hw)
-        check(_lib.lib().drm_download(self._h, fptr(out.depth), fptr(out.confidence), fptr(out.depth_dense),
+        check(self._L.drm_download(self._h, fptr(out.depth), fptr(out.confidence), fptr(out.depth_dense),
                                       fptr(out.confidence_dense)))
         return out
 
@@ -143,21 +144,21 @@ class DrMvsnet:
         sc = 2 ** (3 - stage)
         h, w = self._hw[0] // sc, self._hw[1] // sc
         d, c = np.empty((h, w), np.float32), np.empty((h, w), np.float32)
-        check(_lib.lib().drm_get_stage_output(self._h, stage, fptr(d), fptr(c)))
+        check(self._L.drm_get_stage_output(self._h, stage, fptr(d), fptr(c)))
         return d, c
 
     def tensor(self, name):
         n, dims = C.c_size_t(), (C.c_int * 4)()
-        check(_lib.lib().drm_get_tensor(self._h, name.encode(), None, 0, C.byref(n), dims))
+        check(self._L.drm_get_tensor(self._h, name.encode(), None, 0, C.byref(n), dims))
         out = np.empty(tuple(dims), np.float32)
-        check(_lib.lib().drm_get_tensor(self._h, name.encode(), fptr(out), n.value, C.byref(n), dims))
+        check(self._L.drm_get_tensor(self._h, name.encode(), fptr(out), n.value, C.byref(n), dims))
         return out
 
     def profile(self):
         names = C.create_string_buffer(1 << 16)
         ms = (C.c_float * 512)()
         cnt = C.c_int()
-        check(_lib.lib().drm_profile(self._h, names, len(names), ms, 512, C.byref(cnt)))
+        check(self._L.drm_profile(self._h, names, len(names), ms, 512, C.byref(cnt)))
         rows = []
         for line, t in zip(names.value.decode().strip().split("\n"), list(ms)[:cnt.value]):
             op, kern, fl, by = line.split("\t")
@@ -166,7 +167,7 @@ class DrMvsnet:
 
     def work(self):
         f, b = C.c_double(), C.c_double()
-        check(_lib.lib().drm_work(self._h, C.byref(f), C.byref(b)))
+        check(self._L.drm_work(self._h, C.byref(f), C.byref(b)))
         return f.value, b.value
 
 

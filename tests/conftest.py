@@ -22,6 +22,21 @@ def trained_blob(root):
     return os.path.join(root, "weights", "tandem_va.tdmw")
 
 
+@pytest.fixture
+def parity_hooks():
+    """Run the test against the PARITY build (tandem_amd/libdr_mi355x_hooks.so = the same sources with -DDR_PARITY_HOOKS): the product
+    library does not contain superseded kernel generations, so the cases that compare generations (DR_RAYCAST_V1, DR_RAYCAST_SAMPLER,
+    DR_OUT3_FOLDED=0, DR_NO_SKIP_FUSION, ...) load this one for their duration."""
+    from tandem_amd import _lib
+    if not os.path.isfile(_lib.HOOKS_LIB_PATH):
+        pytest.skip("tandem_amd/libdr_mi355x_hooks.so not built")
+    _lib.switch(_lib.HOOKS_LIB_PATH)
+    try:
+        yield _lib.HOOKS_LIB_PATH
+    finally:
+        _lib.switch(None)
+
+
 def launch_gloo_ranks(script_path, world=2, timeout=600, attempts=3, extra_env=None):
     """Run `script_path` as `world` processes with the torch.distributed.run environment on 127.0.0.1 and return each
     rank's last stdout line parsed as JSON, sorted by rank.  The rendezvous port is found by bind-and-release, which

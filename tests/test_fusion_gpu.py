@@ -353,7 +353,7 @@ def test_exact_fast_division_is_verified_at_construction(vs, f):
     fu.close()
 
 
-def test_raycast_generations_agree_and_ieee_fallback(monkeypatch):
+def test_raycast_generations_agree_and_ieee_fallback(monkeypatch, parity_hooks):
     """k_raycast2 (dense-grid look-ups, exact fast division, shared corner coordinates, empty-superblock skip, the paired-gather
     sampler of round 4) against the literal k_raycast, against k_raycast2 with IEEE division, without the skip, with round 3's
     two-round-trip sampler (DR_RAYCAST_SAMPLER=1) and with round 2's four-stage sampler (0), on the same volume: bit-identical depth

@@ -286,7 +286,7 @@ def test_autotuned_plan_stays_within_tolerance(trained_blob):
     m.close()
 
 
-def test_fused_skip_equals_the_two_kernel_path(trained_blob, monkeypatch):
+def test_fused_skip_equals_the_two_kernel_path(trained_blob, monkeypatch, parity_hooks):
     """FeatureNet stage 3 (module.py:524-529): skip.stage3 + upsample computed inside out.stage3's staging step gives
     bit-for-bit what k_skip_up followed by the plain convolution gives (a second shape with partial tiles)."""
     from synth import scene
@@ -309,7 +309,7 @@ def test_fused_skip_equals_the_two_kernel_path(trained_blob, monkeypatch):
         assert np.array_equal(a.depth, b.depth) and np.array_equal(a.confidence, b.confidence)
 
 
-def test_fused_skip_on_the_marching_kernel(trained_blob, monkeypatch):
+def test_fused_skip_on_the_marching_kernel(trained_blob, monkeypatch, parity_hooks):
     """out.stage3 with the skip computed by k_conv_m's producer waves (conv_march.h, march_producer_fz) against the same
     layer on k_conv's fused staging: same fmaf chain in the skip, same channel-pass and tap order in the 3x3 layer, so
     feat3 agrees to fp32 reassociation at most (tolerance 2e-5 of the tensor's range; observed: bit-identical)."""
@@ -374,7 +374,7 @@ def test_register_regression_equals_the_three_pass_kernel(trained_blob, tmp_path
             assert np.array_equal(a.depth, b.depth) and np.array_equal(a.confidence, b.confidence)
 
 
-def test_folded_out_stage3_equals_the_literal_order(trained_blob, monkeypatch):
+def test_folded_out_stage3_equals_the_literal_order(trained_blob, monkeypatch, parity_hooks):
     """Round 3's default for FeatureNet's stage-3 head: out.stage3(up(inter2) + skip.stage3(c3)) evaluated as conv3x3(c3; Wout.Wskip)
     + conv3x3 over the upsampled inter2 at half resolution (ConvLayer::up2) + a border-corrected bias, against the fused-skip form
     that follows the reference's order (module.py:524-529).  Linear algebra only, so feat3 agrees to fp32 reassociation:
