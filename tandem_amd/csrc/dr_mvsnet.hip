@@ -189,6 +189,7 @@ struct MvsSwitches {
   int prob_zchunk = num("DR_PROB_ZCHUNK", 0);            // tuning: z-march chunk of k_prob2 (0: default)
   int hist_blocks = std::max(1, num("DR_HIST_BLOCKS", 128));  // workgroups of a histogram level (each flushes its bins with atomics on a few hot addresses)
   bool costvol_v2 = on("DR_COSTVOL_V2");                 // k_costvol2 (the fallback for depth chunks that are not multiples of 4) everywhere
+  bool costvol_v3 = on("DR_COSTVOL_V3");                 // k_costvol3 (global gathers; the fallback of the LDS-staged k_costvol4 for partial tiles / plain-variance models) everywhere
   bool regress_generic = on("DR_REGRESS_GENERIC");       // k_regress (the fallback for other plane counts) everywhere
   bool shard_allreduce = on("DR_SHARD_ALLREDUCE");       // view shard: round 2's all-reduce form instead of reduce + broadcast
 #ifdef DR_PARITY_HOOKS
@@ -459,7 +460,13 @@ class MvsEngine {
       else if (o.kind == Op::CONV && o.conv.async) snprintf(kn, sizeof kn, "k_conv_a<%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt);
       else if (o.kind == Op::CONV && o.conv.bf3) snprintf(kn, sizeof kn, "k_conv_b<%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt);
       else if (o.kind == Op::CONV) snprintf(kn, sizeof kn, "k_conv<%d,%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt, o.conv.fz);
-      else if (o.kind == Op::COSTVOL) snprintf(kn, sizeof kn, sw_.costvol_v1 ? "k_costvol<%d>" : (sw_.costvol_v2 ? "k_costvol2<%d>" : "k_costvol3<%d>"), 32 >> (o.stage - 1));
+      else if (o.kind == Op::COSTVOL) {
+        const CostVolArgs &ca = cv_[o.stage - 1];
+        const int Cc = 32 >> (o.stage - 1), tw = Cc == 8 ? 16 : 8, th = (1024 / Cc) / tw, dch = ca.planes.D >= 8 ? 8 : 4;
+        const bool v4 = !sw_.costvol_v1 && !sw_.costvol_v2 && !sw_.costvol_v3 && ca.view_aggregation && ca.V > 1 && ca.w % tw == 0 && ca.h % th == 0 && ca.planes.D % dch == 0;
+        if (v4) snprintf(kn, sizeof kn, "k_costvol4<%d,%d>", Cc, dch);
+        else snprintf(kn, sizeof kn, sw_.costvol_v1 ? "k_costvol<%d>" : (sw_.costvol_v2 ? "k_costvol2<%d>" : "k_costvol3<%d>"), Cc);
+      }
       else if (o.kind == Op::PROB) snprintf(kn, sizeof kn, sw_.prob_v1 ? "k_prob" : "k_prob2");
       else if (o.kind == Op::REGRESS) snprintf(kn, sizeof kn, "k_regress");
       else if (o.kind == Op::PREPROCESS) snprintf(kn, sizeof kn, "k_preprocess");
@@ -987,6 +994,20 @@ class MvsEngine {
           {  // bordered feature maps: 4 channels per lane, no per-tap validity logic
             b.gx = cdiv(a.w, 1024 / C); b.nwg = b.gx * b.gz * a.h;
             const dim3 grid(8 * cdiv(b.nwg, 8));
+            // k_costvol4 (source taps staged through LDS): view-aggregation models, whole pixel tiles, depth chunks of 8 (4 when D = 4)
+            const int dch = a.planes.D >= 8 ? 8 : 4;
+            const int tw = C == 8 ? 16 : 8, th = (1024 / C) / tw;
+            if (!sw_.costvol_v2 && !sw_.costvol_v3 && a.view_aggregation && a.V > 1 && a.w % tw == 0 && a.h % th == 0 && a.planes.D % dch == 0) {
+              CostVolArgs c4 = a;
+              c4.gx = a.w / tw; c4.gz = a.planes.D / dch; c4.nwg = c4.gx * (a.h / th) * c4.gz;
+              const dim3 g4(8 * cdiv(c4.nwg, 8));
+              if (C == 32 && dch == 8) hipLaunchKernelGGL((k_costvol4<32, 8>), g4, dim3(256), 0, stream_, c4);
+              else if (C == 32) hipLaunchKernelGGL((k_costvol4<32, 4>), g4, dim3(256), 0, stream_, c4);
+              else if (C == 16 && dch == 8) hipLaunchKernelGGL((k_costvol4<16, 8>), g4, dim3(256), 0, stream_, c4);
+              else if (C == 16) hipLaunchKernelGGL((k_costvol4<16, 4>), g4, dim3(256), 0, stream_, c4);
+              else if (dch == 8) hipLaunchKernelGGL((k_costvol4<8, 8>), g4, dim3(256), 0, stream_, c4);
+              else hipLaunchKernelGGL((k_costvol4<8, 4>), g4, dim3(256), 0, stream_, c4);
+            } else {
             // k_costvol3 (the lanes of a pixel share the per-sample set-up) needs whole batches of 4 iterations per depth chunk
             const bool v3 = !sw_.costvol_v2 && a.dchunk % 4 == 0 && a.planes.D % 4 == 0;
             if (v3 && C == 32) hipLaunchKernelGGL((k_costvol3<32>), grid, dim3(256), 0, stream_, b);
@@ -995,6 +1016,7 @@ class MvsEngine {
             else if (C == 32) hipLaunchKernelGGL((k_costvol2<32>), grid, dim3(256), 0, stream_, b);
             else if (C == 16) hipLaunchKernelGGL((k_costvol2<16>), grid, dim3(256), 0, stream_, b);
             else hipLaunchKernelGGL((k_costvol2<8>), grid, dim3(256), 0, stream_, b);
+            }
           }
           if (comm_ && shard_nsrc_ && !phase_mode_) {  // view shard: sum the partial volumes of all ranks, in place, in stream order
             const DevTensor &vol = T("volume" + std::to_string(o.stage));

@@ -12,6 +12,9 @@
 // Coalesced float4 channels-last accesses, no re-materialised intermediates (the reference writes and re-reads a
 // (C,D,h,w) volume ~7 times per source view); k_costvol walks the image in XCD-aware bands so that its gathers hit L2.
 #pragma once
+#include <climits>
+#include <utility>
+
 #include "dr_common.h"
 
 namespace dr {
@@ -282,7 +285,7 @@ __device__ inline float cv_dpp_add(float s, int ctrl) {  // s + s[dpp permutatio
 }
 // The arithmetic of one (plane, view) sample, shared by k_costvol2 and k_costvol3 with every multiply-add spelled out: the two
 // kernels then agree bit for bit whatever the compiler would have contracted in either context.
-struct CvProj { int o; float w00, w01, w10, w11; };
+struct CvProj { int o; float w00, w01, w10, w11; int ix, iy, inside; };  // (ix, iy) = the sample's upper-left tap, -1 .. w-1 / h-1
 __device__ __forceinline__ CvProj cv_project(const float *m, float depth, float xf, float yf, float fw, float fh, int wp, int C) {
   const float rx = __builtin_fmaf(m[0], xf, __builtin_fmaf(m[1], yf, m[2])), ry = __builtin_fmaf(m[4], xf, __builtin_fmaf(m[5], yf, m[6])),
               rz = __builtin_fmaf(m[8], xf, __builtin_fmaf(m[9], yf, m[10]));
@@ -295,7 +298,8 @@ __device__ __forceinline__ CvProj cv_project(const float *m, float depth, float 
   const float ax = uc - fx0, ay = vc - fy0, bx = 1.f - ax, by = 1.f - ay;
   CvProj r;
   r.w00 = bx * by; r.w01 = ax * by; r.w10 = bx * ay; r.w11 = ax * ay;
-  r.o = ((int)fy0 * wp + (int)fx0) * C;
+  r.ix = (int)fx0; r.iy = (int)fy0; r.inside = inside ? 1 : 0;
+  r.o = (r.iy * wp + r.ix) * C;
   return r;
 }
 __device__ __forceinline__ float cv_tap4(float t00, float t01, float t10, float t11, const CvTaps &T) {
@@ -502,6 +506,178 @@ __global__ __launch_bounds__(256) void k_costvol3(const CostVolArgs a) {
       if (++v == nsrc) { v = 0; ++d; }
     }
     P = Pn;
+  }
+}
+
+// k_costvol4 (round 4): k_costvol3 with the source taps STAGED THROUGH LDS -- north_star's "LDS staging of per-pixel feature slices".
+// What bounds k_costvol2/3 is the L1's tag path, not bytes and not ALU issue: every (pixel, plane, view) sample is four gathers of the
+// pixel's whole channel record, i.e. four cache-line look-ups per sample, although the taps of neighbouring pixels and of neighbouring
+// planes are the same few lines (a pixel's right tap is its neighbour's left tap; rows y0 / y0 + 1 serve two output rows; consecutive
+// planes of the fine stages move the sample by a fraction of a pixel).  Here a workgroup owns a small pixel TILE (256 / (C / 4) pixels)
+// and a depth chunk, and walks (view, group of LPB planes) steps: the union footprint of the tile's samples of a step -- their bounding
+// box in the source view, known once the lanes have projected their own sample -- is fetched ONCE, row by row, by LDS-DMA
+// (global_load_lds_dwordx4: coalesced 16-byte pieces, no staging registers) into one of two LDS buffers while the previous step is
+// consumed out of the other; the four taps of a sample are then ds_read_b128.  One line look-up per staged line instead of one per tap:
+// 3-4x fewer at the fine stages.  A step whose box does not fit the buffer (planes of the uniform stage that are metres apart, a strongly
+// rotated view) gathers from global memory exactly as k_costvol3 does -- decided per step, uniformly for the workgroup.
+// Arithmetic: cv_project / cv_warp / the gate / the accumulation are k_costvol3's, per (pixel, plane) in the same view order, on the same
+// tap values: the volume is bit-identical (test_lds_staged_cost_volume_is_bit_identical).  View-aggregation models only (the plain-
+// variance form needs a second accumulator set per plane; it stays on k_costvol3).
+constexpr int kCv4Slots = 1024;  // float4 slots per LDS buffer (16 KiB; two buffers)
+template <int C> struct Cv4Shape {
+  static constexpr int LPV = C / 4, NPX = 256 / LPV, TW = C == 8 ? 16 : 8, TH = NPX / TW, LPB = LPV >= 4 ? 4 : 2;
+};
+// min over the wave of a (DPP inside the rows of 16, four readlanes across them); wave-uniform result
+__device__ __forceinline__ int cv4_wave_min(int v) {
+  v = min(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v = min(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v = min(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v = min(v, __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true));   // row_mirror
+  return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+template <int C, int DCH>
+__global__ __launch_bounds__(256) void k_costvol4(const CostVolArgs a) {
+  constexpr int LPV = Cv4Shape<C>::LPV, TW = Cv4Shape<C>::TW, TH = Cv4Shape<C>::TH, LPB = Cv4Shape<C>::LPB;
+  constexpr int SP = 4, SPL = SP / LPB, NG = DCH / SP;  // a step = SP planes of one view; a lane projects SPL of them (the C / 4 lanes of a pixel share the rest)
+  static_assert(DCH % SP == 0, "depth chunks are whole steps");
+  __shared__ float4 buf[2][kCv4Slots];
+  __shared__ int bb[2][4];            // per step parity: min ix, min iy, -max ix, -max iy over the samples that lie inside the view
+  __shared__ float sM[kMaxSrc * 12];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = tid % LPV, qb = q & (LPB - 1), pix = tid / LPV;
+  for (int i = tid; i < kMaxSrc * 12; i += 256) sM[i] = a.M[i / 12][i % 12];
+  if (tid < 8) bb[tid >> 2][tid & 3] = INT_MAX;
+  const int per = (a.nwg + 7) >> 3;   // XCD-aware order: XCD k walks the k-th band of tile rows, depth chunks of a tile innermost
+  const int nid = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+  if (nid >= a.nwg) return;           // (uniform: before the first barrier)
+  __syncthreads();
+  const int bz = nid % a.gz, bxy = nid / a.gz;
+  const int x = (bxy % a.gx) * TW + pix % TW, y = (bxy / a.gx) * TH + pix / TW;   // the host launches this kernel for whole tiles only
+  const int d0 = bz * DCH;
+  const int h = a.h, w = a.w, nsrc = a.V - 1, wp = w + 2;
+  const size_t vplane = (size_t)(h + 2) * wp * C;  // floats per padded view
+  const float fw = (float)w, fh = (float)h, xf = (float)x, yf = (float)y;
+  const float4 ref = ld4(a.feat + ((size_t)(y + 1) * wp + x + 1) * C + q * 4);
+  const float4 gw = make_float4(a.gw[q * 4], a.gw[q * 4 + 1], a.gw[q * 4 + 2], a.gw[q * 4 + 3]);
+  const PixelPlanes pp = make_planes(a.planes, y, x);
+  const float rcp_n = 1.f / a.nsrc_f;
+  const float *f00 = a.feat + ((size_t)wp + 1) * C;  // pixel (0, 0) of view 0 (tap coordinates start at -1: the zero border)
+
+  struct Box { int x0, y0, bw, fits; };  // wave-uniform (scalar registers): origin and width of the staged box; fits = 0: this step gathers from global memory
+  struct Proj { CvProj s[SPL]; };
+  // this lane's own samples of step (v, g): planes d0 + g * SP + b * LPB + qb
+  auto project = [&](int v, int g) {
+    Proj P;
+#pragma unroll
+    for (int b = 0; b < SPL; ++b) P.s[b] = cv_project(sM + 12 * v, plane_depth(pp, a.planes, d0 + g * SP + b * LPB + qb), xf, yf, fw, fh, wp, C);
+    return P;
+  };
+  auto post_box = [&](const Proj &P, int par) {  // min / max of the inside samples' tap coordinates: the wave's, then (LDS atomics) the workgroup's
+    int mnx = INT_MAX, mny = INT_MAX, nmx = INT_MAX, nmy = INT_MAX;  // (the maxima as minima of the negated coordinate)
+#pragma unroll
+    for (int b = 0; b < SPL; ++b)
+      if (P.s[b].inside) { mnx = min(mnx, P.s[b].ix); mny = min(mny, P.s[b].iy); nmx = min(nmx, -P.s[b].ix); nmy = min(nmy, -P.s[b].iy); }
+    mnx = cv4_wave_min(mnx); mny = cv4_wave_min(mny); nmx = cv4_wave_min(nmx); nmy = cv4_wave_min(nmy);
+    if (lane == 0) { atomicMin(&bb[par][0], mnx); atomicMin(&bb[par][1], mny); atomicMin(&bb[par][2], nmx); atomicMin(&bb[par][3], nmy); }
+  };
+  // the agreed box of a step -> origin / width, and the staging of its rows as 16-byte pieces (element e = row r, float4 c of the row)
+  auto read_and_stage = [&](int v, int par) {
+    Box b;
+    const int x0 = __builtin_amdgcn_readfirstlane(bb[par][0]), y0 = __builtin_amdgcn_readfirstlane(bb[par][1]);
+    const int nx1 = __builtin_amdgcn_readfirstlane(bb[par][2]), ny1 = __builtin_amdgcn_readfirstlane(bb[par][3]);
+    const bool any = x0 != INT_MAX;
+    const int bw = any ? -nx1 - x0 + 2 : 1, bh = any ? -ny1 - y0 + 2 : 0;  // + the right / lower tap
+    b.x0 = any ? x0 : 0; b.y0 = any ? y0 : 0; b.bw = bw;
+    b.fits = bw * bh * LPV <= kCv4Slots ? 1 : 0;  // (no sample inside the view: nothing to stage, every tap is the border's zero)
+    if (any && b.fits) {
+      const int rowlen = bw * LPV, total = rowlen * bh;
+      const float inv = 1.0f / (float)rowlen;
+      const float *src0 = f00 + (size_t)(v + 1) * vplane + ((ptrdiff_t)y0 * wp + x0) * C;  // (tap coordinates start at -1: still inside the padded view)
+      for (int p0 = wave * 64; p0 < total; p0 += 256) {
+        const int e = p0 + lane;
+        int r = (int)((float)e * inv);
+        if (r * rowlen > e) --r;
+        if ((r + 1) * rowlen <= e) ++r;
+        const int c = e - r * rowlen;
+        const float *src = e < total ? src0 + ((size_t)r * wp * C + (size_t)c * 4) : a.feat;  // (a.feat: 16 zero bytes of the border; never read back)
+        conv_a_dma16(src, __builtin_amdgcn_readfirstlane(conv_a_lds_addr(&buf[par][p0])));
+      }
+    }
+    return b;
+  };
+  // Steps run plane group by plane group, the views of a group innermost (per (pixel, plane) the views are still accumulated in their
+  // order): the accumulators of a step are the SP planes of ONE group -- SP registers, written out when the group's last view is done.
+  float4 acc[SP];
+#pragma unroll
+  for (int j = 0; j < SP; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto consume = [&](const Proj &PP, const Box &b, int v, int par) {
+    const float *r0 = f00 + q * 4 + (size_t)(v + 1) * vplane, *r1 = r0 + (size_t)wp * C;  // the global fall-back's row bases (k_costvol3's)
+#pragma unroll
+    for (int bi = 0; bi < SPL; ++bi)
+#pragma unroll
+    for (int j = 0; j < LPB; ++j) {
+      const CvProj &P = PP.s[bi];
+      CvTaps T;
+      const int o = cv_bcast_i(P.o, LPB, j), ix = cv_bcast_i(P.ix, LPB, j), iy = cv_bcast_i(P.iy, LPB, j);
+      const bool in = cv_bcast_i(P.inside, LPB, j) != 0;
+      T.w00 = cv_bcast_f(P.w00, LPB, j); T.w01 = cv_bcast_f(P.w01, LPB, j); T.w10 = cv_bcast_f(P.w10, LPB, j); T.w11 = cv_bcast_f(P.w11, LPB, j);
+      if (b.fits) {  // (uniform) taps out of the staged box; a sample outside the view reads the border's zeros, as it does in memory
+        const int row = b.bw * LPV, off = in ? ((iy - b.y0) * b.bw + (ix - b.x0)) * LPV + q : 0;
+        const float4 t00 = buf[par][off], t01 = buf[par][off + LPV], t10 = buf[par][off + row], t11 = buf[par][off + row + LPV];
+        auto keep = [in](const float4 &t) { return make_float4(in ? t.x : 0.f, in ? t.y : 0.f, in ? t.z : 0.f, in ? t.w : 0.f); };  // (component selects: a float4 select goes through scratch)
+        T.t00 = keep(t00); T.t01 = keep(t01); T.t10 = keep(t10); T.t11 = keep(t11);
+      } else {
+        T.t00 = ld4(r0 + o); T.t01 = ld4(r0 + o + C); T.t10 = ld4(r1 + o); T.t11 = ld4(r1 + o + C);
+      }
+      const float4 wv = cv_warp(T);
+      const float4 df = make_float4(wv.x - ref.x, wv.y - ref.y, wv.z - ref.z, wv.w - ref.w);
+      const float4 d2 = make_float4(df.x * df.x, df.y * df.y, df.z * df.z, df.w * df.w);
+      float sg = cv_gate_dot(gw, d2);
+      if constexpr (LPV >= 2) sg = cv_dpp_add(sg, 0);
+      if constexpr (LPV >= 4) sg = cv_dpp_add(sg, 1);
+      if constexpr (LPV >= 8) sg = cv_dpp_add(sg, 2);
+      const float g1 = fmaxf(__builtin_fmaf(a.gA1, sg, a.gB1), 0.f);
+      const float gg = fmaxf(__builtin_fmaf(a.gA2, g1, a.gB2), 0.f) + 1.f;
+      float4 &A = acc[bi * LPB + j];
+      A.x = __builtin_fmaf(gg, d2.x, A.x); A.y = __builtin_fmaf(gg, d2.y, A.y); A.z = __builtin_fmaf(gg, d2.z, A.z); A.w = __builtin_fmaf(gg, d2.w, A.w);
+    }
+  };
+  const int S = NG * nsrc;  // step s = (group s / nsrc, view s % nsrc)
+  if (S > 0) {
+    // prologue: step 0 projected, boxed and staged
+    Proj P = project(0, 0);
+    post_box(P, 0);
+    __syncthreads();
+    Box B = read_and_stage(0, 0);
+    conv_a_wait_dma();
+    __syncthreads();
+    int g = 0, v = 0;
+    for (int s = 0; s < S; ++s) {
+      // the NEXT step's samples are projected and its box is agreed on and requested while this step's taps are read
+      const int par = s & 1;
+      const bool last = s == S - 1;
+      const int vn = v + 1 < nsrc ? v + 1 : 0, gn = v + 1 < nsrc ? g : g + 1;
+      Proj Pn = P;
+      if (!last) { Pn = project(vn, gn); post_box(Pn, par ^ 1); }
+      __syncthreads();
+      Box Bn = B;
+      if (!last) Bn = read_and_stage(vn, par ^ 1);
+      consume(P, B, v, par);
+      if (v == nsrc - 1) {  // the group's planes are complete
+#pragma unroll
+        for (int j = 0; j < SP; ++j) {
+          const float4 o4 = make_float4(acc[j].x * rcp_n, acc[j].y * rcp_n, acc[j].z * rcp_n, acc[j].w * rcp_n);
+          *reinterpret_cast<float4 *>(a.vol + ((size_t)(d0 + g * SP + j) * h * w + (size_t)y * w + x) * C + q * 4) = o4;
+          acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+      conv_a_wait_dma();
+      if (tid < 4) bb[par][tid] = INT_MAX;  // this parity's box was read a barrier ago; it is posted again after the next one
+      __syncthreads();
+      P = Pn; B = Bn; v = vn; g = gn;
+    }
+  } else {  // (no source view on this rank: the host zeroes the volume instead of launching; kept for completeness)
+    for (int i = 0; i < DCH; ++i)
+      *reinterpret_cast<float4 *>(a.vol + ((size_t)(d0 + i) * h * w + (size_t)y * w + x) * C + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 

@@ -418,8 +418,7 @@ def test_shared_setup_cost_volume_is_bit_identical(trained_blob, tmp_path, monke
     for blob in (trained_blob, plain):
         vols = []
         for old in (False, True):
-            if old:
-                monkeypatch.setenv("DR_COSTVOL_V2", "1")
+            monkeypatch.setenv("DR_COSTVOL_V2" if old else "DR_COSTVOL_V3", "1")  # (the default since round 4 is the LDS-staged k_costvol4, tested below)
             m = DrMvsnet(blob)
             res = []
             for (h, w) in ((96, 160), (64, 224)):
@@ -430,12 +429,44 @@ def test_shared_setup_cost_volume_is_bit_identical(trained_blob, tmp_path, monke
                 res.append(([m.tensor("volume%d" % s).copy() for s in (1, 2, 3)], kern["s2.costvol"]))
             vols.append(res)
             m.close()
-            if old:
-                monkeypatch.delenv("DR_COSTVOL_V2")
+            monkeypatch.delenv("DR_COSTVOL_V2" if old else "DR_COSTVOL_V3")
         for (va, ka), (vb, kb) in zip(*vols):
             assert ka.startswith("k_costvol3") and kb.startswith("k_costvol2"), (ka, kb)
             for a, b in zip(va, vb):
                 assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), np.abs(a - b).max()
+
+
+@pytest.mark.parametrize("views,dmin,dmax", [(7, 0.5, 5.0), (7, 0.01, 10.0), (3, 0.5, 5.0), (2, 0.3, 1.2), (5, 2.0, 40.0)])
+def test_lds_staged_cost_volume_is_bit_identical(trained_blob, monkeypatch, views, dmin, dmax):
+    """k_costvol4 (round 4: the taps of a pixel tile's samples staged once per (view, 4 planes) step into LDS by LDS-DMA, read from there)
+    against k_costvol3 (every tap a gather from global memory): the same arithmetic on the same tap values in the same view order, so the
+    three cost volumes are equal bit for bit.  The depth ranges make the kernel take every path: boxes that fit (the scene's own range),
+    steps whose planes lie metres apart or in front of the cameras so that the box does not fit or no sample falls inside the view
+    (0.01 .. 10 as the headline runs it, 2 .. 40), a narrow range (sub-pixel steps), 1 to 6 source views, two shapes."""
+    from synth import scene
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    vols = []
+    for old in (False, True):
+        if old:
+            monkeypatch.setenv("DR_COSTVOL_V3", "1")
+        m = DrMvsnet(trained_blob)
+        res = []
+        for (h, w) in ((96, 160), (64, 224), (256, 320)):
+            win = scene.make_window(h, w, views, seed=13)
+            m.upload(h, w, views, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), dmin, dmax, 2.5)
+            m.forward(1)
+            kern = {r["op"]: r["kernel"] for r in m.profile()}
+            res.append(([m.tensor("volume%d" % s).copy() for s in (1, 2, 3)], [kern["s%d.costvol" % s] for s in (1, 2, 3)], m.download().depth_dense.copy()))
+        vols.append(res)
+        m.close()
+        if old:
+            monkeypatch.delenv("DR_COSTVOL_V3")
+    for (va, ka, da), (vb, kb, db) in zip(*vols):
+        assert all(k.startswith("k_costvol4") for k in ka) and all(k.startswith("k_costvol3") for k in kb), (ka, kb)
+        for a, b in zip(va, vb):
+            assert np.isfinite(a).all()
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (np.abs(a - b).max(), (a != b).mean())
+        assert np.array_equal(da.view(np.uint32), db.view(np.uint32))
 
 
 # ---- the opt-in bf16 x 3 precision mode (csrc/conv_bf3.h, DR_CONV_BF16X3=1; first run on a GPU in round 4: green) ----
