@@ -320,7 +320,7 @@ __device__ inline void march_consumer(const ConvArgs &a, const MarchArgs &m, flo
           for (int pi = 0; pi < NPI; ++pi, ++rel, slot = slot + 1 == R ? 0 : slot + 1) {
             if (!there) continue;
             const int idx = L + rel;
-#if !defined(DR_MABL_NO_WAIT) && !defined(DR_MABL_FREE)  // (timing ablations, tools/gpu_r3_ablate.sh: results are wrong by design)
+#if !defined(DR_MABL_NO_WAIT) && !defined(DR_MABL_FREE)  // (timing-ablation builds of round 3: results are wrong by design)
             if (!march_wait_ready<NPW>(flags, idx, cached, m.err, lane)) return;
 #endif
             asm volatile("" ::: "memory");

@@ -944,7 +944,7 @@ class MvsEngine {
         }
         case Op::PROB: {
           // z-march chunk: long chunks amortise the 2 halo planes, but the launch needs ~1000 waves to fill the chip
-          // (tools/gpu_sweep_chunks.sh: 48x120x160 -> 4, 32x240x320 -> 8, 8x480x640 -> 8)
+          // (round-2 sweep: 48x120x160 -> 4, 32x240x320 -> 8, 8x480x640 -> 8)
 #ifdef DR_PARITY_HOOKS
           if (sw_.prob_v1) {  // round 2's L1-gather kernel: one output column per lane (r2 sweep: 4x the waves beats the 4-column variant)
             int zchunk = std::min(o.d0, 8);
