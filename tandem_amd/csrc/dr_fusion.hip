@@ -917,7 +917,10 @@ __device__ inline Voxel interp_voxel3(const FusionDev &d, F3 pos, bool far_block
     gz[j] = f2i(div_by<FAST>(az, vs, y) + signf_(az) * 0.5f);
   }
   const bool mx = g0x == gx[1], my = g0y == gy[1], mz = g0z == gz[1];  // which corner is the centre voxel
-  if ((!mx && g0x != gx[0]) || (!my && g0y != gy[0]) || (!mz && g0z != gz[0])) { bail = true; return zero; }
+  // A float tie at a cell boundary can round the centre coordinate to a voxel that is neither corner (measured: 8e-6 per axis and
+  // sample).  Such a lane looks its centre up explicitly below, under a branch hardly any wave ever takes -- NOT through the literal
+  // pass: one flagged pixel costs a whole literal ray (a millisecond-long dependent chain in k_raycast_fix).
+  const bool match = (mx || g0x == gx[0]) && (my || g0y == gy[0]) && (mz || g0z == gz[0]);
   auto pick = [&](const int (&a)[8]) {
     const int a0 = mz ? a[4] : a[0], a1 = mz ? a[5] : a[1], a2 = mz ? a[6] : a[2], a3 = mz ? a[7] : a[3];
     const int b0 = my ? a2 : a0, b1 = my ? a3 : a1;
@@ -933,10 +936,15 @@ __device__ inline Voxel interp_voxel3(const FusionDev &d, F3 pos, bool far_block
   for (int c = 0; c < 8; ++c) P[c] = d.grid[ic[c]];
 #pragma unroll
   for (int c = 0; c < 8; ++c) P[c] = okc[c] ? P[c] - 1 : -1;
-  const int b0 = pick(P);
-  const bool ok0 = pick(oki) != 0;
+  int b0 = pick(P), i0 = pick(ic);
+  bool ok0 = pick(oki) != 0;
+  if (!match) {
+    const unsigned im = cell_of(g0x >> 3, g0y >> 3, g0z >> 3, ok0);
+    i0 = (int)im;
+    b0 = ok0 ? d.grid[im] - 1 : -1;
+  }
   if (!ok0 && far_blocks) bail = true;
-  if (empty_cell) *empty_cell = (b0 < 0 && ok0) ? pick(ic) : -1;
+  if (empty_cell) *empty_cell = (b0 < 0 && ok0) ? i0 : -1;
   if (b0 < 0) return zero;
   // ---- round trip 2: the eight corner voxels ----
   int ilo[8], ihi[8];
@@ -946,7 +954,12 @@ __device__ inline Voxel interp_voxel3(const FusionDev &d, F3 pos, bool far_block
     const Voxel8 t = *reinterpret_cast<const Voxel8 *>(d.vox + (size_t)(P[c] >= 0 ? P[c] : b0) * 512 + local);
     ilo[c] = (int)t.lo; ihi[c] = (int)t.hi;
   }
-  const Voxel v0 = unpack_voxel((unsigned)pick(ilo), (unsigned)pick(ihi));  // (b0 >= 0: the centre's corner was loaded from its own block)
+  int c0lo = pick(ilo), c0hi = pick(ihi);  // (b0 >= 0: the centre's corner was loaded from its own block)
+  if (!match) {
+    const Voxel8 t = *reinterpret_cast<const Voxel8 *>(d.vox + (size_t)b0 * 512 + (((g0x & 7) << 6) | ((g0y & 7) << 3) | (g0z & 7)));
+    c0lo = (int)t.lo; c0hi = (int)t.hi;
+  }
+  const Voxel v0 = unpack_voxel((unsigned)c0lo, (unsigned)c0hi);
   if (v0.weight == 0) return v0;
 #pragma unroll
   for (int c = 0; c < 8; ++c) if (!okc[c] && far_blocks) bail = true;

@@ -189,6 +189,8 @@ struct MvsSwitches {
   int prob_zchunk = num("DR_PROB_ZCHUNK", 0);            // tuning: z-march chunk of k_prob2 (0: default)
   int hist_blocks = std::max(1, num("DR_HIST_BLOCKS", 128));  // workgroups of a histogram level (each flushes its bins with atomics on a few hot addresses)
   bool costvol_v2 = on("DR_COSTVOL_V2");                 // k_costvol2 (the fallback for depth chunks that are not multiples of 4) everywhere
+  int cv4_stages = num("DR_CV4_STAGES", 7);              // tuning: bit s-1 set = stage s builds its cost volume with k_costvol4 (LDS-staged taps) where it applies
+  int cv4_sp8 = num("DR_CV4_SP8", 2);                    // tuning: bit s-1 set = 8 planes per k_costvol4 step at stage s (else 4)
   bool costvol_v3 = on("DR_COSTVOL_V3");                 // k_costvol3 (global gathers; the fallback of the LDS-staged k_costvol4 for partial tiles / plain-variance models) everywhere
   bool regress_generic = on("DR_REGRESS_GENERIC");       // k_regress (the fallback for other plane counts) everywhere
   bool shard_allreduce = on("DR_SHARD_ALLREDUCE");       // view shard: round 2's all-reduce form instead of reduce + broadcast
@@ -462,8 +464,8 @@ class MvsEngine {
       else if (o.kind == Op::CONV) snprintf(kn, sizeof kn, "k_conv<%d,%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt, o.conv.fz);
       else if (o.kind == Op::COSTVOL) {
         const CostVolArgs &ca = cv_[o.stage - 1];
-        const int Cc = 32 >> (o.stage - 1), tw = Cc == 8 ? 16 : 8, th = (1024 / Cc) / tw, dch = ca.planes.D >= 8 ? 8 : 4;
-        const bool v4 = !sw_.costvol_v1 && !sw_.costvol_v2 && !sw_.costvol_v3 && ca.view_aggregation && ca.V > 1 && ca.w % tw == 0 && ca.h % th == 0 && ca.planes.D % dch == 0;
+        const int Cc = 32 >> (o.stage - 1), dch = ca.planes.D >= 8 ? 8 : 4;
+        const bool v4 = cv4_applies(o.stage);
         if (v4) snprintf(kn, sizeof kn, "k_costvol4<%d,%d>", Cc, dch);
         else snprintf(kn, sizeof kn, sw_.costvol_v1 ? "k_costvol<%d>" : (sw_.costvol_v2 ? "k_costvol2<%d>" : "k_costvol3<%d>"), Cc);
       }
@@ -997,16 +999,20 @@ class MvsEngine {
             // k_costvol4 (source taps staged through LDS): view-aggregation models, whole pixel tiles, depth chunks of 8 (4 when D = 4)
             const int dch = a.planes.D >= 8 ? 8 : 4;
             const int tw = C == 8 ? 16 : 8, th = (1024 / C) / tw;
-            if (!sw_.costvol_v2 && !sw_.costvol_v3 && a.view_aggregation && a.V > 1 && a.w % tw == 0 && a.h % th == 0 && a.planes.D % dch == 0) {
+            if (cv4_applies(o.stage)) {
               CostVolArgs c4 = a;
               c4.gx = a.w / tw; c4.gz = a.planes.D / dch; c4.nwg = c4.gx * (a.h / th) * c4.gz;
               const dim3 g4(8 * cdiv(c4.nwg, 8));
-              if (C == 32 && dch == 8) hipLaunchKernelGGL((k_costvol4<32, 8>), g4, dim3(256), 0, stream_, c4);
-              else if (C == 32) hipLaunchKernelGGL((k_costvol4<32, 4>), g4, dim3(256), 0, stream_, c4);
-              else if (C == 16 && dch == 8) hipLaunchKernelGGL((k_costvol4<16, 8>), g4, dim3(256), 0, stream_, c4);
-              else if (C == 16) hipLaunchKernelGGL((k_costvol4<16, 4>), g4, dim3(256), 0, stream_, c4);
-              else if (dch == 8) hipLaunchKernelGGL((k_costvol4<8, 8>), g4, dim3(256), 0, stream_, c4);
-              else hipLaunchKernelGGL((k_costvol4<8, 4>), g4, dim3(256), 0, stream_, c4);
+              // planes per step: 8 where neighbouring planes move a sample by a fraction of a pixel (the box hardly grows), else 4
+              const bool sp8 = dch == 8 && C != 32 && ((sw_.cv4_sp8 >> (o.stage - 1)) & 1);
+              if (C == 32 && dch == 8) hipLaunchKernelGGL((k_costvol4<32, 8, 4>), g4, dim3(256), 0, stream_, c4);
+              else if (C == 32) hipLaunchKernelGGL((k_costvol4<32, 4, 4>), g4, dim3(256), 0, stream_, c4);
+              else if (C == 16 && sp8) hipLaunchKernelGGL((k_costvol4<16, 8, 8>), g4, dim3(256), 0, stream_, c4);
+              else if (C == 16 && dch == 8) hipLaunchKernelGGL((k_costvol4<16, 8, 4>), g4, dim3(256), 0, stream_, c4);
+              else if (C == 16) hipLaunchKernelGGL((k_costvol4<16, 4, 4>), g4, dim3(256), 0, stream_, c4);
+              else if (sp8) hipLaunchKernelGGL((k_costvol4<8, 8, 8>), g4, dim3(256), 0, stream_, c4);
+              else if (dch == 8) hipLaunchKernelGGL((k_costvol4<8, 8, 4>), g4, dim3(256), 0, stream_, c4);
+              else hipLaunchKernelGGL((k_costvol4<8, 4, 4>), g4, dim3(256), 0, stream_, c4);
             } else {
             // k_costvol3 (the lanes of a pixel share the per-sample set-up) needs whole batches of 4 iterations per depth chunk
             const bool v3 = !sw_.costvol_v2 && a.dchunk % 4 == 0 && a.planes.D % 4 == 0;
@@ -1075,6 +1081,13 @@ class MvsEngine {
     DR_HIP(hipGetLastError());
   }
 
+  // k_costvol4 (taps staged through LDS): view-aggregation models, bordered feature maps, whole pixel tiles, whole depth chunks
+  bool cv4_applies(int stage) const {
+    const CostVolArgs &a = cv_[stage - 1];
+    const int C = 32 >> (stage - 1), tw = C == 8 ? 16 : 8, th = (1024 / C) / tw, dch = a.planes.D >= 8 ? 8 : 4;
+    return !sw_.costvol_v1 && !sw_.costvol_v2 && !sw_.costvol_v3 && ((sw_.cv4_stages >> (stage - 1)) & 1) && a.fpad && a.view_aggregation && a.V > 1 &&
+           a.w % tw == 0 && a.h % th == 0 && a.planes.D % dch == 0;
+  }
   hipStream_t side_ = nullptr;
   hipEvent_t ev_fork_ = nullptr, ev_feat2_ = nullptr, ev_feat3_ = nullptr;
   bool side_enabled_ = true;

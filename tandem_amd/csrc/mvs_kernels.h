@@ -535,11 +535,13 @@ __device__ __forceinline__ int cv4_wave_min(int v) {
   v = min(v, __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true));   // row_mirror
   return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
-template <int C, int DCH>
+// SP = planes per step (4 or 8): more planes amortise the step's fixed work (projection of the lane's own samples, the box, the
+// staging requests, two barriers) but widen the box; the host picks 8 for the fine stages and 4 for the uniform stage.
+template <int C, int DCH, int SP>
 __global__ __launch_bounds__(256) void k_costvol4(const CostVolArgs a) {
   constexpr int LPV = Cv4Shape<C>::LPV, TW = Cv4Shape<C>::TW, TH = Cv4Shape<C>::TH, LPB = Cv4Shape<C>::LPB;
-  constexpr int SP = 4, SPL = SP / LPB, NG = DCH / SP;  // a step = SP planes of one view; a lane projects SPL of them (the C / 4 lanes of a pixel share the rest)
-  static_assert(DCH % SP == 0, "depth chunks are whole steps");
+  constexpr int SPL = SP / LPB, NG = DCH / SP;  // a step = SP planes of one view; a lane projects SPL of them (the C / 4 lanes of a pixel share the rest)
+  static_assert(DCH % SP == 0 && SP % LPB == 0, "depth chunks are whole steps, steps whole batches");
   __shared__ float4 buf[2][kCv4Slots];
   __shared__ int bb[2][4];            // per step parity: min ix, min iy, -max ix, -max iy over the samples that lie inside the view
   __shared__ float sM[kMaxSrc * 12];
@@ -563,31 +565,43 @@ __global__ __launch_bounds__(256) void k_costvol4(const CostVolArgs a) {
   const float *f00 = a.feat + ((size_t)wp + 1) * C;  // pixel (0, 0) of view 0 (tap coordinates start at -1: the zero border)
 
   struct Box { int x0, y0, bw, fits; };  // wave-uniform (scalar registers): origin and width of the staged box; fits = 0: this step gathers from global memory
-  struct Proj { CvProj s[SPL]; };
-  // this lane's own samples of step (v, g): planes d0 + g * SP + b * LPB + qb
-  auto project = [&](int v, int g) {
+  // A lane's own sample of a step, as the consumers need it: where the upper-left tap lies and the four weights.  A sample outside the
+  // view gets four ZERO weights (k_costvol3 gives it weight 1 on the border's zero): the warped value is then +-0 instead of +0, and
+  // only its squared difference to the reference feature is ever used -- the same bits.
+  struct Samp { int o, ix, iy, off; float w00, w01, w10, w11; };
+  struct Proj { Samp s[SPL]; };
+  auto project = [&](int v, int g) {  // planes d0 + g * SP + b * LPB + qb
     Proj P;
 #pragma unroll
-    for (int b = 0; b < SPL; ++b) P.s[b] = cv_project(sM + 12 * v, plane_depth(pp, a.planes, d0 + g * SP + b * LPB + qb), xf, yf, fw, fh, wp, C);
+    for (int b = 0; b < SPL; ++b) {
+      const CvProj c = cv_project(sM + 12 * v, plane_depth(pp, a.planes, d0 + g * SP + b * LPB + qb), xf, yf, fw, fh, wp, C);
+      Samp &t = P.s[b];
+      t.o = c.o; t.off = 0;
+      t.ix = c.inside ? c.ix : INT_MAX; t.iy = c.iy;
+      t.w00 = c.inside ? c.w00 : 0.f; t.w01 = c.inside ? c.w01 : 0.f; t.w10 = c.inside ? c.w10 : 0.f; t.w11 = c.inside ? c.w11 : 0.f;
+    }
     return P;
   };
   auto post_box = [&](const Proj &P, int par) {  // min / max of the inside samples' tap coordinates: the wave's, then (LDS atomics) the workgroup's
     int mnx = INT_MAX, mny = INT_MAX, nmx = INT_MAX, nmy = INT_MAX;  // (the maxima as minima of the negated coordinate)
 #pragma unroll
     for (int b = 0; b < SPL; ++b)
-      if (P.s[b].inside) { mnx = min(mnx, P.s[b].ix); mny = min(mny, P.s[b].iy); nmx = min(nmx, -P.s[b].ix); nmy = min(nmy, -P.s[b].iy); }
+      if (P.s[b].ix != INT_MAX) { mnx = min(mnx, P.s[b].ix); mny = min(mny, P.s[b].iy); nmx = min(nmx, -P.s[b].ix); nmy = min(nmy, -P.s[b].iy); }
     mnx = cv4_wave_min(mnx); mny = cv4_wave_min(mny); nmx = cv4_wave_min(nmx); nmy = cv4_wave_min(nmy);
     if (lane == 0) { atomicMin(&bb[par][0], mnx); atomicMin(&bb[par][1], mny); atomicMin(&bb[par][2], nmx); atomicMin(&bb[par][3], nmy); }
   };
-  // the agreed box of a step -> origin / width, and the staging of its rows as 16-byte pieces (element e = row r, float4 c of the row)
-  auto read_and_stage = [&](int v, int par) {
+  // the agreed box of a step -> origin / width, the staging of its rows as 16-byte pieces (element e = row r, float4 c of the row), and
+  // every lane's own tap offset inside the box (float4 slots, without its channel quad)
+  auto read_and_stage = [&](Proj &P, int v, int par) {
     Box b;
     const int x0 = __builtin_amdgcn_readfirstlane(bb[par][0]), y0 = __builtin_amdgcn_readfirstlane(bb[par][1]);
     const int nx1 = __builtin_amdgcn_readfirstlane(bb[par][2]), ny1 = __builtin_amdgcn_readfirstlane(bb[par][3]);
     const bool any = x0 != INT_MAX;
-    const int bw = any ? -nx1 - x0 + 2 : 1, bh = any ? -ny1 - y0 + 2 : 0;  // + the right / lower tap
+    const int bw = any ? -nx1 - x0 + 2 : 1, bh = any ? -ny1 - y0 + 2 : 1;  // + the right / lower tap
     b.x0 = any ? x0 : 0; b.y0 = any ? y0 : 0; b.bw = bw;
-    b.fits = bw * bh * LPV <= kCv4Slots ? 1 : 0;  // (no sample inside the view: nothing to stage, every tap is the border's zero)
+    b.fits = bw * bh * LPV <= kCv4Slots ? 1 : 0;  // (no sample inside the view: nothing to stage -- every weight is zero, any slot will do)
+#pragma unroll
+    for (int s = 0; s < SPL; ++s) P.s[s].off = P.s[s].ix != INT_MAX ? ((P.s[s].iy - b.y0) * bw + (P.s[s].ix - b.x0)) * LPV : 0;
     if (any && b.fits) {
       const int rowlen = bw * LPV, total = rowlen * bh;
       const float inv = 1.0f / (float)rowlen;
@@ -611,21 +625,20 @@ __global__ __launch_bounds__(256) void k_costvol4(const CostVolArgs a) {
   for (int j = 0; j < SP; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   auto consume = [&](const Proj &PP, const Box &b, int v, int par) {
     const float *r0 = f00 + q * 4 + (size_t)(v + 1) * vplane, *r1 = r0 + (size_t)wp * C;  // the global fall-back's row bases (k_costvol3's)
+    const float4 *tile = &buf[par][q];
+    const int row = b.bw * LPV;
 #pragma unroll
     for (int bi = 0; bi < SPL; ++bi)
 #pragma unroll
     for (int j = 0; j < LPB; ++j) {
-      const CvProj &P = PP.s[bi];
+      const Samp &P = PP.s[bi];
       CvTaps T;
-      const int o = cv_bcast_i(P.o, LPB, j), ix = cv_bcast_i(P.ix, LPB, j), iy = cv_bcast_i(P.iy, LPB, j);
-      const bool in = cv_bcast_i(P.inside, LPB, j) != 0;
       T.w00 = cv_bcast_f(P.w00, LPB, j); T.w01 = cv_bcast_f(P.w01, LPB, j); T.w10 = cv_bcast_f(P.w10, LPB, j); T.w11 = cv_bcast_f(P.w11, LPB, j);
-      if (b.fits) {  // (uniform) taps out of the staged box; a sample outside the view reads the border's zeros, as it does in memory
-        const int row = b.bw * LPV, off = in ? ((iy - b.y0) * b.bw + (ix - b.x0)) * LPV + q : 0;
-        const float4 t00 = buf[par][off], t01 = buf[par][off + LPV], t10 = buf[par][off + row], t11 = buf[par][off + row + LPV];
-        auto keep = [in](const float4 &t) { return make_float4(in ? t.x : 0.f, in ? t.y : 0.f, in ? t.z : 0.f, in ? t.w : 0.f); };  // (component selects: a float4 select goes through scratch)
-        T.t00 = keep(t00); T.t01 = keep(t01); T.t10 = keep(t10); T.t11 = keep(t11);
+      if (b.fits) {  // (uniform) taps out of the staged box
+        const float4 *t = tile + cv_bcast_i(P.off, LPB, j);
+        T.t00 = t[0]; T.t01 = t[LPV]; T.t10 = t[row]; T.t11 = t[row + LPV];
       } else {
+        const int o = cv_bcast_i(P.o, LPB, j);
         T.t00 = ld4(r0 + o); T.t01 = ld4(r0 + o + C); T.t10 = ld4(r1 + o); T.t11 = ld4(r1 + o + C);
       }
       const float4 wv = cv_warp(T);
@@ -647,7 +660,7 @@ __global__ __launch_bounds__(256) void k_costvol4(const CostVolArgs a) {
     Proj P = project(0, 0);
     post_box(P, 0);
     __syncthreads();
-    Box B = read_and_stage(0, 0);
+    Box B = read_and_stage(P, 0, 0);
     conv_a_wait_dma();
     __syncthreads();
     int g = 0, v = 0;
@@ -660,7 +673,7 @@ __global__ __launch_bounds__(256) void k_costvol4(const CostVolArgs a) {
       if (!last) { Pn = project(vn, gn); post_box(Pn, par ^ 1); }
       __syncthreads();
       Box Bn = B;
-      if (!last) Bn = read_and_stage(vn, par ^ 1);
+      if (!last) Bn = read_and_stage(Pn, vn, par ^ 1);
       consume(P, B, v, par);
       if (v == nsrc - 1) {  // the group's planes are complete
 #pragma unroll

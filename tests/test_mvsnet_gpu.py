@@ -493,4 +493,5 @@ def test_bf16x3_mode_stays_inside_the_fp32_bounds(path, trained_blob, tmp_path, 
     ref = {k: g[f"ref_s3_{k}"] for k in ("depth", "confidence", "depth_dense", "confidence_dense")}
     compare(outs[0], ref, "bf16x3 " + os.path.basename(path))
     assert not np.array_equal(outs[0].depth_dense, outs[1].depth_dense)  # the mode really ran
-    assert np.abs(outs[0].depth_dense - outs[1].depth_dense).max() < 2e-3
+    # (2e-3 m at the scene's 4.5 m depth range; the bound scales with the range, i.e. with the spacing of the hypothesis planes)
+    assert np.abs(outs[0].depth_dense - outs[1].depth_dense).max() < 4.5e-4 * (float(g["depth_max"]) - float(g["depth_min"]))
