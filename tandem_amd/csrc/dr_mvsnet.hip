@@ -189,8 +189,7 @@ struct MvsSwitches {
   int prob_zchunk = num("DR_PROB_ZCHUNK", 0);            // tuning: z-march chunk of k_prob2 (0: default)
   int hist_blocks = std::max(1, num("DR_HIST_BLOCKS", 128));  // workgroups of a histogram level (each flushes its bins with atomics on a few hot addresses)
   bool costvol_v2 = on("DR_COSTVOL_V2");                 // k_costvol2 (the fallback for depth chunks that are not multiples of 4) everywhere
-  int cv4_stages = num("DR_CV4_STAGES", 7);              // tuning: bit s-1 set = stage s builds its cost volume with k_costvol4 (LDS-staged taps) where it applies
-  int cv4_sp8 = num("DR_CV4_SP8", 2);                    // tuning: bit s-1 set = 8 planes per k_costvol4 step at stage s (else 4)
+  bool costvol_no_borrow = on("DR_COSTVOL_NO_BORROW");   // A/B: k_costvol3 without the neighbour-tap borrowing (every tap loaded)
   bool costvol_v3 = on("DR_COSTVOL_V3");                 // k_costvol3 (global gathers; the fallback of the LDS-staged k_costvol4 for partial tiles / plain-variance models) everywhere
   bool regress_generic = on("DR_REGRESS_GENERIC");       // k_regress (the fallback for other plane counts) everywhere
   bool shard_allreduce = on("DR_SHARD_ALLREDUCE");       // view shard: round 2's all-reduce form instead of reduce + broadcast
@@ -203,10 +202,14 @@ struct MvsSwitches {
   bool skip_on_conv = on("DR_SKIP_ON_CONV"), no_skip_fusion = on("DR_NO_SKIP_FUSION");
   bool out3_folded = num("DR_OUT3_FOLDED", 1) != 0;      // 0: FeatureNet's stage-3 head in its literal order (fused-skip kernel)
   bool d2h_copy = getenv("DR_MVS_D2H") && !strcmp(getenv("DR_MVS_D2H"), "copy");  // four copy-engine transfers instead of k_publish4
+  // k_costvol4 (round 4: source taps staged through LDS -- north_star's "LDS staging of per-pixel feature slices"): bit-identical to
+  // k_costvol3 and measured 8-15 % SLOWER (0.121 / 0.163 / 0.105 against 0.106 / 0.150 / 0.099 ms per stage), so it is not in the product
+  int cv4_stages = num("DR_CV4_STAGES", 0);              // bit s-1 set = stage s builds its cost volume with k_costvol4 where it applies
+  int cv4_sp8 = num("DR_CV4_SP8", 0);                    // bit s-1 set = 8 planes per k_costvol4 step at stage s (else 4)
 #else
   static constexpr bool costvol_v1 = false, prob_v1 = false, prob_launch_order = false, prob_on_conv = false, skip_on_conv = false,
                         no_skip_fusion = false, out3_folded = true, d2h_copy = false;
-  static constexpr int costvol_cpl = 4, prob_block = 256, prob_xo = 1;
+  static constexpr int costvol_cpl = 4, prob_block = 256, prob_xo = 1, cv4_stages = 0, cv4_sp8 = 0;
 #endif
 };
 
@@ -996,7 +999,7 @@ class MvsEngine {
           {  // bordered feature maps: 4 channels per lane, no per-tap validity logic
             b.gx = cdiv(a.w, 1024 / C); b.nwg = b.gx * b.gz * a.h;
             const dim3 grid(8 * cdiv(b.nwg, 8));
-            // k_costvol4 (source taps staged through LDS): view-aggregation models, whole pixel tiles, depth chunks of 8 (4 when D = 4)
+#ifdef DR_PARITY_HOOKS  // k_costvol4 (source taps staged through LDS): view-aggregation models, whole pixel tiles, depth chunks of 8 (4 when D = 4)
             const int dch = a.planes.D >= 8 ? 8 : 4;
             const int tw = C == 8 ? 16 : 8, th = (1024 / C) / tw;
             if (cv4_applies(o.stage)) {
@@ -1013,9 +1016,16 @@ class MvsEngine {
               else if (sp8) hipLaunchKernelGGL((k_costvol4<8, 8, 8>), g4, dim3(256), 0, stream_, c4);
               else if (dch == 8) hipLaunchKernelGGL((k_costvol4<8, 8, 4>), g4, dim3(256), 0, stream_, c4);
               else hipLaunchKernelGGL((k_costvol4<8, 4, 4>), g4, dim3(256), 0, stream_, c4);
-            } else {
+            } else
+#endif
+            {
             // k_costvol3 (the lanes of a pixel share the per-sample set-up) needs whole batches of 4 iterations per depth chunk
             const bool v3 = !sw_.costvol_v2 && a.dchunk % 4 == 0 && a.planes.D % 4 == 0;
+            if (v3 && sw_.costvol_no_borrow) {
+              if (C == 32) hipLaunchKernelGGL((k_costvol3<32, false>), grid, dim3(256), 0, stream_, b);
+              else if (C == 16) hipLaunchKernelGGL((k_costvol3<16, false>), grid, dim3(256), 0, stream_, b);
+              else hipLaunchKernelGGL((k_costvol3<8, false>), grid, dim3(256), 0, stream_, b);
+            } else
             if (v3 && C == 32) hipLaunchKernelGGL((k_costvol3<32>), grid, dim3(256), 0, stream_, b);
             else if (v3 && C == 16) hipLaunchKernelGGL((k_costvol3<16>), grid, dim3(256), 0, stream_, b);
             else if (v3) hipLaunchKernelGGL((k_costvol3<8>), grid, dim3(256), 0, stream_, b);

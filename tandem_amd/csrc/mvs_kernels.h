@@ -277,6 +277,7 @@ __global__ __launch_bounds__(256) void k_costvol(const CostVolArgs a) {
 struct CvTaps {
   float4 t00, t01, t10, t11;
   float w00, w01, w10, w11;
+  bool bor;  // k_costvol3: the right-hand taps (t01, t11) are the NEIGHBOURING pixel's left-hand taps and are taken from its lanes
 };
 __device__ inline float cv_dpp_add(float s, int ctrl) {  // s + s[dpp permutation of the row]
   if (ctrl == 0) return s + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
@@ -413,8 +414,20 @@ __device__ __forceinline__ int cv_bcast_i(int x, int lpb, int j) {  // value of 
   return j == 0 ? __builtin_amdgcn_mov_dpp(x, 0xA0, 0xF, 0xF, true) : __builtin_amdgcn_mov_dpp(x, 0xF5, 0xF, 0xF, true);  // [0,0,2,2] / [1,1,3,3]
 }
 __device__ __forceinline__ float cv_bcast_f(float x, int lpb, int j) { return __builtin_bit_cast(float, cv_bcast_i(__builtin_bit_cast(int, x), lpb, j)); }
+// value of lane (l + N) of the same row of 16 lanes (row_shl:N); lanes whose source falls off the row read 0
+template <int N>
+__device__ __forceinline__ int cv_row_shl_i(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x100 + N, 0xF, 0xF, true); }
+template <int N>
+__device__ __forceinline__ float cv_row_shl_f(float x) { return __builtin_bit_cast(float, cv_row_shl_i<N>(__builtin_bit_cast(int, x))); }
 
-template <int C>
+// BORROW (round 4): the kernel is bound by the L1's tag path -- 64 line look-ups per wave and sample (16 pixels x 4 taps), PMC: 72 % of
+// its time -- and most of those look-ups fetch a line the SAME instruction sequence fetches for the neighbouring pixel: with a scale
+// near one, pixel p's right-hand taps (x0 + 1) are pixel p + 1's left-hand taps (its x0).  When the neighbour's tap offset says so
+// (o[p + 1] == o[p] + C: same source row, next column), the lanes of pixel p take t01 / t11 from the neighbour's t00 / t10 registers
+// (DPP row_shl by one pixel) and send their own two loads to ONE fixed address (pixel (0, 0) of the view), which costs the instruction a
+// single line look-up however many lanes do it.  The last pixel of a row of 16 lanes has no neighbour inside the row and always loads.
+// Same values from the same addresses: bit-identical; 3 of 4 pixels can borrow at C = 16, 1 of 2 at C = 32, 7 of 8 at C = 8.
+template <int C, bool BORROW = true>
 __global__ __launch_bounds__(256) void k_costvol3(const CostVolArgs a) {
   constexpr int LPV = C / 4;            // lanes per pixel, 4 channels each
   constexpr int PXB = 256 / LPV;        // pixels per block
@@ -445,11 +458,18 @@ __global__ __launch_bounds__(256) void k_costvol3(const CostVolArgs a) {
   auto project = [&](int d, int v) {  // k_costvol2's `issue` up to the tap offset and weights, for this lane's own (plane, view)
     return cv_project(sM + 12 * v, plane_depth(pp, a.planes, d), xf, yf, fw, fh, wp, C);
   };
+  const bool has_right = BORROW && ((tid & 15) + LPV < 16);  // the next pixel's lanes lie in the same row of 16 lanes
   auto gather = [&](const CvProj &P, int j, int v, CvTaps &T) {  // iteration j of the batch: lane j's set-up, view v (uniform)
     const int o = cv_bcast_i(P.o, LPB, j);
     T.w00 = cv_bcast_f(P.w00, LPB, j); T.w01 = cv_bcast_f(P.w01, LPB, j); T.w10 = cv_bcast_f(P.w10, LPB, j); T.w11 = cv_bcast_f(P.w11, LPB, j);
     const float *r0 = f00 + (size_t)(v + 1) * vplane, *r1 = r0 + (size_t)wp * C;  // wave-uniform bases: rows y0 and y0 + 1
-    T.t00 = ld4(r0 + o); T.t01 = ld4(r0 + o + C); T.t10 = ld4(r1 + o); T.t11 = ld4(r1 + o + C);
+    T.bor = false;
+    int o1 = o;
+    if constexpr (BORROW && LPV < 16) {
+      T.bor = has_right && cv_row_shl_i<LPV>(o) == o + C;
+      o1 = T.bor ? -C : o;  // borrowing lanes: r0 + 0 / r1 + 0, one line for all of them (the value is not used)
+    }
+    T.t00 = ld4(r0 + o); T.t01 = ld4(r0 + o1 + C); T.t10 = ld4(r1 + o); T.t11 = ld4(r1 + o1 + C);
   };
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), s1 = acc;
   auto consume = [&](int d, int v, const CvTaps &T) {
@@ -457,7 +477,14 @@ __global__ __launch_bounds__(256) void k_costvol3(const CostVolArgs a) {
       acc = a.view_aggregation ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(ref.x * ref.x, ref.y * ref.y, ref.z * ref.z, ref.w * ref.w);
       s1 = ref;
     }
-    const float4 wv = cv_warp(T);
+    CvTaps Tb = T;
+    if constexpr (BORROW && LPV < 16) {  // the neighbouring pixel's left-hand taps, where this pixel's right-hand taps are the same addresses
+      const float4 n0 = make_float4(cv_row_shl_f<LPV>(T.t00.x), cv_row_shl_f<LPV>(T.t00.y), cv_row_shl_f<LPV>(T.t00.z), cv_row_shl_f<LPV>(T.t00.w));
+      const float4 n1 = make_float4(cv_row_shl_f<LPV>(T.t10.x), cv_row_shl_f<LPV>(T.t10.y), cv_row_shl_f<LPV>(T.t10.z), cv_row_shl_f<LPV>(T.t10.w));
+      Tb.t01 = make_float4(T.bor ? n0.x : T.t01.x, T.bor ? n0.y : T.t01.y, T.bor ? n0.z : T.t01.z, T.bor ? n0.w : T.t01.w);
+      Tb.t11 = make_float4(T.bor ? n1.x : T.t11.x, T.bor ? n1.y : T.t11.y, T.bor ? n1.z : T.t11.z, T.bor ? n1.w : T.t11.w);
+    }
+    const float4 wv = cv_warp(Tb);
     if (a.view_aggregation) {
       const float4 df = make_float4(wv.x - ref.x, wv.y - ref.y, wv.z - ref.z, wv.w - ref.w);
       const float4 d2 = make_float4(df.x * df.x, df.y * df.y, df.z * df.z, df.w * df.w);
@@ -509,6 +536,7 @@ __global__ __launch_bounds__(256) void k_costvol3(const CostVolArgs a) {
   }
 }
 
+#ifdef DR_PARITY_HOOKS  // measured slower than k_costvol3 (see MvsSwitches::cv4_stages): built into the parity library only
 // k_costvol4 (round 4): k_costvol3 with the source taps STAGED THROUGH LDS -- north_star's "LDS staging of per-pixel feature slices".
 // What bounds k_costvol2/3 is the L1's tag path, not bytes and not ALU issue: every (pixel, plane, view) sample is four gathers of the
 // pixel's whole channel record, i.e. four cache-line look-ups per sample, although the taps of neighbouring pixels and of neighbouring
@@ -521,7 +549,11 @@ __global__ __launch_bounds__(256) void k_costvol3(const CostVolArgs a) {
 // 3-4x fewer at the fine stages.  A step whose box does not fit the buffer (planes of the uniform stage that are metres apart, a strongly
 // rotated view) gathers from global memory exactly as k_costvol3 does -- decided per step, uniformly for the workgroup.
 // Arithmetic: cv_project / cv_warp / the gate / the accumulation are k_costvol3's, per (pixel, plane) in the same view order, on the same
-// tap values: the volume is bit-identical (test_lds_staged_cost_volume_is_bit_identical).  View-aggregation models only (the plain-
+// tap values: the volume is bit-identical (test_lds_staged_cost_volume_is_bit_identical).
+// MEASURED (MI355X, 640 x 480 x 7, profiles/r04_experiments.txt 5): 0.121 / 0.163 / 0.105 ms per stage against k_costvol3's 0.106 / 0.150 /
+// 0.099 (first version, before the per-sample instruction diet: 0.143 / 0.181 / 0.114) -- the staged form removes three quarters of the
+// line look-ups but pays 27 % more vector instructions per sample, two barriers per step and an LDS-DMA latency that four samples of
+// arithmetic do not cover.  Kept, with its test, in the parity build; the product runs k_costvol3 with neighbour-tap borrowing.  View-aggregation models only (the plain-
 // variance form needs a second accumulator set per plane; it stays on k_costvol3).
 constexpr int kCv4Slots = 1024;  // float4 slots per LDS buffer (16 KiB; two buffers)
 template <int C> struct Cv4Shape {
@@ -693,6 +725,8 @@ __global__ __launch_bounds__(256) void k_costvol4(const CostVolArgs a) {
       *reinterpret_cast<float4 *>(a.vol + ((size_t)(d0 + i) * h * w + (size_t)y * w + x) * C + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
+
+#endif  // DR_PARITY_HOOKS
 
 // ------------------------------------------------------------------ prob conv (Cout = 1)
 // CostRegNet.prob = Conv3d(8, 1, 3, padding=1, bias=False) (module.py:575): 216 MACs per voxel and a single output
