@@ -189,7 +189,6 @@ struct MvsSwitches {
   int prob_zchunk = num("DR_PROB_ZCHUNK", 0);            // tuning: z-march chunk of k_prob2 (0: default)
   int hist_blocks = std::max(1, num("DR_HIST_BLOCKS", 128));  // workgroups of a histogram level (each flushes its bins with atomics on a few hot addresses)
   bool costvol_v2 = on("DR_COSTVOL_V2");                 // k_costvol2 (the fallback for depth chunks that are not multiples of 4) everywhere
-  bool costvol_no_borrow = on("DR_COSTVOL_NO_BORROW");   // A/B: k_costvol3 without the neighbour-tap borrowing (every tap loaded)
   bool costvol_v3 = on("DR_COSTVOL_V3");                 // k_costvol3 (global gathers; the fallback of the LDS-staged k_costvol4 for partial tiles / plain-variance models) everywhere
   bool regress_generic = on("DR_REGRESS_GENERIC");       // k_regress (the fallback for other plane counts) everywhere
   bool shard_allreduce = on("DR_SHARD_ALLREDUCE");       // view shard: round 2's all-reduce form instead of reduce + broadcast
@@ -1021,11 +1020,6 @@ class MvsEngine {
             {
             // k_costvol3 (the lanes of a pixel share the per-sample set-up) needs whole batches of 4 iterations per depth chunk
             const bool v3 = !sw_.costvol_v2 && a.dchunk % 4 == 0 && a.planes.D % 4 == 0;
-            if (v3 && sw_.costvol_no_borrow) {
-              if (C == 32) hipLaunchKernelGGL((k_costvol3<32, false>), grid, dim3(256), 0, stream_, b);
-              else if (C == 16) hipLaunchKernelGGL((k_costvol3<16, false>), grid, dim3(256), 0, stream_, b);
-              else hipLaunchKernelGGL((k_costvol3<8, false>), grid, dim3(256), 0, stream_, b);
-            } else
             if (v3 && C == 32) hipLaunchKernelGGL((k_costvol3<32>), grid, dim3(256), 0, stream_, b);
             else if (v3 && C == 16) hipLaunchKernelGGL((k_costvol3<16>), grid, dim3(256), 0, stream_, b);
             else if (v3) hipLaunchKernelGGL((k_costvol3<8>), grid, dim3(256), 0, stream_, b);

@@ -277,7 +277,6 @@ __global__ __launch_bounds__(256) void k_costvol(const CostVolArgs a) {
 struct CvTaps {
   float4 t00, t01, t10, t11;
   float w00, w01, w10, w11;
-  bool bor;  // k_costvol3: the right-hand taps (t01, t11) are the NEIGHBOURING pixel's left-hand taps and are taken from its lanes
 };
 __device__ inline float cv_dpp_add(float s, int ctrl) {  // s + s[dpp permutation of the row]
   if (ctrl == 0) return s + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
@@ -414,20 +413,10 @@ __device__ __forceinline__ int cv_bcast_i(int x, int lpb, int j) {  // value of 
   return j == 0 ? __builtin_amdgcn_mov_dpp(x, 0xA0, 0xF, 0xF, true) : __builtin_amdgcn_mov_dpp(x, 0xF5, 0xF, 0xF, true);  // [0,0,2,2] / [1,1,3,3]
 }
 __device__ __forceinline__ float cv_bcast_f(float x, int lpb, int j) { return __builtin_bit_cast(float, cv_bcast_i(__builtin_bit_cast(int, x), lpb, j)); }
-// value of lane (l + N) of the same row of 16 lanes (row_shl:N); lanes whose source falls off the row read 0
-template <int N>
-__device__ __forceinline__ int cv_row_shl_i(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x100 + N, 0xF, 0xF, true); }
-template <int N>
-__device__ __forceinline__ float cv_row_shl_f(float x) { return __builtin_bit_cast(float, cv_row_shl_i<N>(__builtin_bit_cast(int, x))); }
-
-// BORROW (round 4): the kernel is bound by the L1's tag path -- 64 line look-ups per wave and sample (16 pixels x 4 taps), PMC: 72 % of
-// its time -- and most of those look-ups fetch a line the SAME instruction sequence fetches for the neighbouring pixel: with a scale
-// near one, pixel p's right-hand taps (x0 + 1) are pixel p + 1's left-hand taps (its x0).  When the neighbour's tap offset says so
-// (o[p + 1] == o[p] + C: same source row, next column), the lanes of pixel p take t01 / t11 from the neighbour's t00 / t10 registers
-// (DPP row_shl by one pixel) and send their own two loads to ONE fixed address (pixel (0, 0) of the view), which costs the instruction a
-// single line look-up however many lanes do it.  The last pixel of a row of 16 lanes has no neighbour inside the row and always loads.
-// Same values from the same addresses: bit-identical; 3 of 4 pixels can borrow at C = 16, 1 of 2 at C = 32, 7 of 8 at C = 8.
-template <int C, bool BORROW = true>
+// Round 4 tried to take a pixel's right-hand taps from the NEIGHBOURING pixel's lanes (DPP) where they are the same addresses, sending
+// the now redundant loads to one shared line: 0.116 / 0.158 / 0.106 ms per stage against 0.105 / 0.149 / 0.100 -- slower, removed
+// (profiles/r04_experiments.txt, 6).
+template <int C>
 __global__ __launch_bounds__(256) void k_costvol3(const CostVolArgs a) {
   constexpr int LPV = C / 4;            // lanes per pixel, 4 channels each
   constexpr int PXB = 256 / LPV;        // pixels per block
@@ -458,18 +447,11 @@ __global__ __launch_bounds__(256) void k_costvol3(const CostVolArgs a) {
   auto project = [&](int d, int v) {  // k_costvol2's `issue` up to the tap offset and weights, for this lane's own (plane, view)
     return cv_project(sM + 12 * v, plane_depth(pp, a.planes, d), xf, yf, fw, fh, wp, C);
   };
-  const bool has_right = BORROW && ((tid & 15) + LPV < 16);  // the next pixel's lanes lie in the same row of 16 lanes
   auto gather = [&](const CvProj &P, int j, int v, CvTaps &T) {  // iteration j of the batch: lane j's set-up, view v (uniform)
     const int o = cv_bcast_i(P.o, LPB, j);
     T.w00 = cv_bcast_f(P.w00, LPB, j); T.w01 = cv_bcast_f(P.w01, LPB, j); T.w10 = cv_bcast_f(P.w10, LPB, j); T.w11 = cv_bcast_f(P.w11, LPB, j);
     const float *r0 = f00 + (size_t)(v + 1) * vplane, *r1 = r0 + (size_t)wp * C;  // wave-uniform bases: rows y0 and y0 + 1
-    T.bor = false;
-    int o1 = o;
-    if constexpr (BORROW && LPV < 16) {
-      T.bor = has_right && cv_row_shl_i<LPV>(o) == o + C;
-      o1 = T.bor ? -C : o;  // borrowing lanes: r0 + 0 / r1 + 0, one line for all of them (the value is not used)
-    }
-    T.t00 = ld4(r0 + o); T.t01 = ld4(r0 + o1 + C); T.t10 = ld4(r1 + o); T.t11 = ld4(r1 + o1 + C);
+    T.t00 = ld4(r0 + o); T.t01 = ld4(r0 + o + C); T.t10 = ld4(r1 + o); T.t11 = ld4(r1 + o + C);
   };
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), s1 = acc;
   auto consume = [&](int d, int v, const CvTaps &T) {
@@ -477,14 +459,7 @@ __global__ __launch_bounds__(256) void k_costvol3(const CostVolArgs a) {
       acc = a.view_aggregation ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(ref.x * ref.x, ref.y * ref.y, ref.z * ref.z, ref.w * ref.w);
       s1 = ref;
     }
-    CvTaps Tb = T;
-    if constexpr (BORROW && LPV < 16) {  // the neighbouring pixel's left-hand taps, where this pixel's right-hand taps are the same addresses
-      const float4 n0 = make_float4(cv_row_shl_f<LPV>(T.t00.x), cv_row_shl_f<LPV>(T.t00.y), cv_row_shl_f<LPV>(T.t00.z), cv_row_shl_f<LPV>(T.t00.w));
-      const float4 n1 = make_float4(cv_row_shl_f<LPV>(T.t10.x), cv_row_shl_f<LPV>(T.t10.y), cv_row_shl_f<LPV>(T.t10.z), cv_row_shl_f<LPV>(T.t10.w));
-      Tb.t01 = make_float4(T.bor ? n0.x : T.t01.x, T.bor ? n0.y : T.t01.y, T.bor ? n0.z : T.t01.z, T.bor ? n0.w : T.t01.w);
-      Tb.t11 = make_float4(T.bor ? n1.x : T.t11.x, T.bor ? n1.y : T.t11.y, T.bor ? n1.z : T.t11.z, T.bor ? n1.w : T.t11.w);
-    }
-    const float4 wv = cv_warp(Tb);
+    const float4 wv = cv_warp(T);
     if (a.view_aggregation) {
       const float4 df = make_float4(wv.x - ref.x, wv.y - ref.y, wv.z - ref.z, wv.w - ref.w);
       const float4 d2 = make_float4(df.x * df.x, df.y * df.y, df.z * df.z, df.w * df.w);
