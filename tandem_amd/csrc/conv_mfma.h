@@ -192,6 +192,59 @@ __device__ inline void conv_kloop(const float *lds, const float4 *wl, const int 
   if (u < NU) conv_chunk_mfma<CT, PT>(a0, b0, acc);  // odd chunk count: set 0 holds the last chunk
 }
 
+// The K loop for NARROW waves (CT * PT <= 2: the coarse and strided layers, ~25 launches per forward).  Two things the loop above leaves
+// on the table there: (1) a chunk is 4 or 8 MFMAs = 128-256 cycles, about one LDS round trip, so operands fetched ONE chunk ahead arrive
+// late -- here they are fetched two chunks ahead (three register sets in rotation, the loop unrolled by three); (2) with a single
+// accumulator tile the four MFMAs of a chunk depend on each other (40-cycle dependent latency against a 32-cycle issue interval) --
+// here they alternate between two accumulators that are added at the end (k_conv_m does the same, conv_march.h).
+// `load(tap offset, chunk, av, bv)` fetches one chunk's operands (k_conv and k_conv_a address their tiles differently).
+template <int CT, int PT>
+__device__ inline void conv_chunk_mfma2(const float4 (&av)[CT], const float4 (&bv)[PT], floatx4 (&acc)[CT][PT], floatx4 (&acc2)[CT][PT]) {
+  if constexpr (CT * PT == 1) {
+    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].x, bv[0].x, acc[0][0], 0, 0, 0);
+    acc2[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].y, bv[0].y, acc2[0][0], 0, 0, 0);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].z, bv[0].z, acc[0][0], 0, 0, 0);
+    acc2[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].w, bv[0].w, acc2[0][0], 0, 0, 0);
+  } else conv_chunk_mfma<CT, PT>(av, bv, acc);
+}
+template <int CT, int PT, class Load>
+__device__ inline void conv_kloop_narrow(const int *tp, int TPC, int NU, floatx4 (&acc)[CT][PT], Load load) {
+  float4 a0[CT], b0[PT], a1[CT], b1[PT], a2[CT], b2[PT];
+  floatx4 acc2[CT][PT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc2[ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
+  auto tap = [&](int u) { return tp[min(u, NU - 1) * TPC]; };  // (the tap offset of a chunk is itself an LDS read: fetched a chunk before its operands)
+  int t0 = tap(0), t1 = tap(1), t2 = tap(2);
+  load(t0, 0, a0, b0);
+  load(t1, min(1, NU - 1), a1, b1);
+  int u = 0;
+  for (; u + 2 < NU; u += 3) {  // invariant: set 0 holds chunk u, set 1 chunk u + 1
+    load(t2, u + 2, a2, b2);
+    t0 = tap(u + 3);
+    __builtin_amdgcn_sched_barrier(0);
+    conv_chunk_mfma2<CT, PT>(a0, b0, acc, acc2);
+    __builtin_amdgcn_sched_barrier(0);
+    conv_chunk_anchor<CT, PT>(a1, b1, t0);
+    load(t0, min(u + 3, NU - 1), a0, b0);
+    t1 = tap(u + 4);
+    __builtin_amdgcn_sched_barrier(0);
+    conv_chunk_mfma2<CT, PT>(a1, b1, acc, acc2);
+    __builtin_amdgcn_sched_barrier(0);
+    conv_chunk_anchor<CT, PT>(a2, b2, t1);
+    load(t1, min(u + 4, NU - 1), a1, b1);
+    t2 = tap(u + 5);
+    __builtin_amdgcn_sched_barrier(0);
+    conv_chunk_mfma2<CT, PT>(a2, b2, acc, acc2);
+    __builtin_amdgcn_sched_barrier(0);
+    conv_chunk_anchor<CT, PT>(a0, b0, t2);
+  }
+  if (u < NU) conv_chunk_mfma2<CT, PT>(a0, b0, acc, acc2);      // one or two chunks left: sets 0 and 1 hold them
+  if (u + 1 < NU) conv_chunk_mfma2<CT, PT>(a1, b1, acc, acc2);
+  if constexpr (CT * PT == 1) acc[0][0] += acc2[0][0];
+}
+
 // grid = (tiles, parity classes, output-row groups).  PT = position tiles (16 positions each) per wave.
 // FZ > 0: fused FeatureNet skip -- the staged tile is computed (1x1 conv of an FZ-channel tensor + bias + nearest
 // upsample of the coarser level) instead of copied; the arithmetic is k_skip_up's, so the result is bit-identical to
@@ -393,7 +446,14 @@ __global__ __launch_bounds__(kConvThreads, DR_KCONV_MIN_WAVES(CT, FZ)) void k_co
     __builtin_amdgcn_s_setprio(0);
     __syncthreads();
 #ifndef DR_ABL_NO_KLOOP
-    conv_kloop<CT, PT>(lds, wl, tp, TPC, NU, lane, base, acc);
+#ifdef DR_NO_NARROW_KLOOP  // A/B build
+    if constexpr (false) {
+#else
+    if constexpr (CT * PT <= 2) {
+#endif
+      const float4 *wp = wl + lane;
+      conv_kloop_narrow<CT, PT>(tp, TPC, NU, acc, [&](int toff, int u, float4 (&av)[CT], float4 (&bv)[PT]) { conv_chunk_load<CT, PT>(lds, wp, toff, u, base, av, bv); });
+    } else conv_kloop<CT, PT>(lds, wl, tp, TPC, NU, lane, base, acc);
 #endif
     __syncthreads();
   }
@@ -565,7 +625,14 @@ __global__ __launch_bounds__(kConvAThreads) void k_conv_a(const ConvArgs a) {
     if (i + 1 < n_units) issue(i + 1);
 #endif
 #ifndef DR_ABL_NO_KLOOP
-    conv_a_kloop<CI, CT, PT>((i & 1) ? tile1 : tile0, wb0 + (size_t)((i % a.npass) % a.a_wbufs) * n_w, tp, TPC, NU, lane, c4, bpos, acc);
+#ifdef DR_NO_NARROW_KLOOP
+    if constexpr (false) {
+#else
+    if constexpr (CT * PT <= 2) {
+#endif
+      const float4 *tile = (i & 1) ? tile1 : tile0, *wp = wb0 + (size_t)((i % a.npass) % a.a_wbufs) * n_w + lane;
+      conv_kloop_narrow<CT, PT>(tp, TPC, NU, acc, [&](int toff, int u, float4 (&av)[CT], float4 (&bv)[PT]) { conv_a_load<CI, CT, PT>(tile, wp, toff, u, c4, bpos, av, bv); });
+    } else conv_a_kloop<CI, CT, PT>((i & 1) ? tile1 : tile0, wb0 + (size_t)((i % a.npass) % a.a_wbufs) * n_w, tp, TPC, NU, lane, c4, bpos, acc);
 #endif
     if ((i + 1) % a.npass == 0) done_tile = i / a.npass;
   }
