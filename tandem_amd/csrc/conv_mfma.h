@@ -645,6 +645,7 @@ __global__ __launch_bounds__(kConvAThreads) void k_conv_a(const ConvArgs a) {
 
 }  // namespace dr
 #include "conv_march.h"  // k_conv_m: marching producer/consumer kernel for the stride-1 3x3 / 3x3x3 layers
+#include "conv_wino.h"   // k_conv_w: k_conv with the y axis of a 3-tap stride-1 layer in Winograd F(2,3) form (two thirds of the MFMAs)
 namespace dr {
 
 // ------------------------------------------------------------------------------------------------
@@ -848,6 +849,20 @@ inline MarchShape march_shape(int KZ, int ntp, int Cin, int ci, int ct, int pt, 
   m.ok = true;
   return m;
 }
+// k_conv_w instances (CI, CT, PT): 16-channel passes with one or two row tiles, 8-channel passes (Cin = 8) with one
+inline bool conv_w_instance_exists(int ci, int ct, int pt) {
+  return (pt == 1 || pt == 2) && ((ci == 16 && (ct == 1 || ct == 2)) || (ci == 8 && ct == 1));  // (PT = 4 needs more than 256 registers: 64 accumulators + two operand sets of 80)
+}
+// DR_CONV_WINO: 0 = never plan k_conv_w, 1 = rank it with the other families (default), 2 = prefer it wherever it applies (A/B hook, tests)
+inline int conv_wino_policy() {
+  if (const char *e = getenv("DR_CONV_WINO")) return atoi(e);
+  return 0;  // (until it has been measured on the GPU)
+}
+// Winograd F(2,3) weight transform along one 3-tap axis: point p of (g0, g1, g2)
+inline double conv_wino_g(int p, int k) {
+  static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+  return G[p][k];
+}
 inline size_t conv_a_slots(int np, int ci) { return (size_t)cdiv(((np + 1) & ~1) * (ci / 4), 512) * 512; }
 // Form of a stride-2 transposed layer (see axis_classes): 0 = every strided axis dense (8 * Cout rows, 27 of 64 products useful),
 // 1 = x dense, z and y split (2 * Cout rows in 4 classes, 3 of 4 useful), 2 = every axis split (Cout rows in 8 classes, all
@@ -936,8 +951,10 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
     X.s = shifts; X.npos = outWv;
   }
   // geometry shared by all parity classes: strides, padding, extents = union over classes
-  const int SZ = cz[0].s, SY = cy[0].s, SX = cx[0].s, PZ = cz[0].p, PY = cy[0].p, PX = cx[0].p;
-  const int nPD = cz[0].npos, nPH = cy[0].npos, nPW = cx[0].npos;
+  const int SZ = cz[0].s, SX = cx[0].s, PZ = cz[0].p, PX = cx[0].p;
+  int SY = cy[0].s, PY = cy[0].p;  // (a k_conv_w plan re-describes the y axis once it is chosen)
+  const int nPD = cz[0].npos, nPW = cx[0].npos;
+  int nPH = cy[0].npos;
   int exz = 0, exy = 0, exx = 0;
   for (auto &c : cz) for (int o : c.off) exz = std::max(exz, o + 1);
   for (auto &c : cy) for (int o : c.off) exy = std::max(exy, o + 1);
@@ -1045,6 +1062,47 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
         }
     }
   }
+  // k_conv_w: k_conv's launch form with the y axis in Winograd F(2,3) form (conv_wino.h).  A position tile is 16 x by one row PAIR:
+  // to the tile geometry the layer has stride 2 and a 4-row kernel in y; a K chunk is 4 points x 4 MFMAs per (row tile, position tile).
+  const int wino_policy = (!fz && !bf3) ? conv_wino_policy() : 0;
+  const bool wino_ok = wino_policy >= 1 && ncls == 1 && !L.transposed && !L.up2 && mode != CONV_X8 && L.kh == 3 && L.sh == 1 && (R.outH & 1) == 0 && R.outH >= 2;
+  if (wino_ok) {
+    static const int cand8[][3] = {{1, 1, 8}, {1, 2, 4}, {1, 4, 2}, {1, 8, 1}, {2, 1, 4}, {2, 2, 2}, {2, 4, 1}, {4, 1, 2}, {4, 2, 1}, {8, 1, 1}};
+    const int nPHw = R.outH / 2, ntw = (int)(cz[0].t.size() * cx[0].t.size());
+    for (int ci : {16, 8}) {
+      if (L.Cin % ci || (ci == 8 && L.Cin != 8)) continue;
+      const int npass = L.Cin / ci, tpc = 16 / ci, nr = cdiv(ntw, tpc);
+      for (int pt : {2, 1}) {
+        const int (*cand)[3] = pt == 2 ? cand8 : cand4;
+        const int ncand = pt == 2 ? 10 : 6;
+        for (int k = 0; k < ncand; ++k) {
+          const int *c = cand[k];
+          if ((c[0] > 1 && c[0] / 2 >= nPD) || (c[1] > 1 && c[1] / 2 >= nPHw) || (c[2] > 1 && (c[2] / 2) * 16 >= nPW)) continue;  // more than half of the tile outside
+          const int tzi = (c[0] - 1) * SZ + exz, tyi = (c[1] - 1) * 2 + 4, txi = (c[2] * 16 - 1) * SX + exx;
+          if ((size_t)tzi * tyi * txi >= 65536) continue;
+          const double tiles = (double)cdiv(nPD, c[0]) * cdiv(nPHw, c[1]) * cdiv(nPW, c[2] * 16);
+          for (int ct : {2, 1}) {
+            if (CTtot % ct || !conv_w_instance_exists(ci, ct, pt)) continue;
+            const size_t bytes = (size_t)tzi * tyi * txi * (ci + 4) * 4 + (size_t)4 * nr * ct * 1024 + (size_t)4 * nr * tpc * 4 + 64;
+            if (bytes > kConvMaxLds) continue;
+            const int split = CTtot / ct;
+            const double waves_simd = ct * pt == 1 ? 4.0 : (ct * pt == 2 ? 3.0 : 2.0);  // register budget of the instance
+            const double wg_per_cu = std::max(1.0, std::min({(double)(kConvMaxLds / bytes), waves_simd}));
+            const double stage = npass * (((double)tzi * tyi * txi * (ci / 4) + 4.0 * nr * ct * 64.0) / 256.0 * 60.0 + 900.0);
+            const double chunk_mfma = 16.0 * ct * pt * 32.0;
+            const double n_wg = tiles * split;
+            const double mfma_total = n_wg * npass * nr * chunk_mfma, stage_total = n_wg * stage;
+            const double lat_wg = npass * nr * chunk_mfma + stage;
+            const double waves = std::ceil(n_wg / (256.0 * wg_per_cu));
+            const double thr = (mfma_total + stage_total) / 256.0 / (wg_per_cu >= 2 ? 0.8 : 0.5);
+            double cost = std::max(thr, waves * lat_wg) * 1.25;  // not calibrated against the direct kernels yet: an untuned shape moves here only with some margin
+            if (wino_policy >= 2) cost *= 1e-3;
+            cands.push_back({cost, ci, pt, ct, c[0], c[1], c[2], tzi, tyi, txi, 4});
+          }
+        }
+      }
+    }
+  }
   const bool sync_too = policy != 1 || cands.empty();
   for (int ci : {16, 8, 4}) {
     if (!sync_too) break;
@@ -1102,6 +1160,13 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   }
   if (!CI) fail(DR_ERR_ARG, "plan_conv: no kernel instance / tile shape for Cin=%d Cout=%d", L.Cin, L.Cout);
   const int npass = L.Cin / CI, TPC = (bf3 ? 32 : 16) / CI, CIS = CI + 4;
+  const bool wino = ASYNC == 4;
+  if (wino) {  // the y axis as k_conv_w sees it: positions are row pairs, the tap table carries row 0 only (the kernel adds rows 1..3 itself)
+    DimTaps &Y = cy[0];
+    Y.t = {0}; Y.off = {0}; Y.s = 2; Y.p = 1; Y.om = 2; Y.oo = 0; Y.npos = R.outH / 2;
+    SY = 2; PY = 1; nPH = Y.npos;
+    classes[0].ntaps = (int)(cz[0].t.size() * cx[0].t.size());
+  }
 
   // per-row epilogue affine
   std::vector<float> sc(rows, 1.f), bi(rows, 0.f);
@@ -1123,12 +1188,12 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   for (int ic = 0; ic < ncls; ++ic) {
     const DimTaps &Z = *classes[ic].z, &Y = *classes[ic].y, &X = *classes[ic].x;
     const int ntz = (int)Z.t.size(), nty = (int)Y.t.size(), ntx = (int)X.t.size(), ntaps = classes[ic].ntaps;
-    const int NU = cdiv(ntaps, TPC);
+    const int NR = cdiv(ntaps, TPC), NU = wino ? 4 * NR : NR;  // k_conv_w: four weight chunks (one per Winograd point) per chunk of taps
     cls[ic].NU = NU; cls[ic].tap_base = (int)tapoff.size(); cls[ic].w_base = (int)(pk.size() / 4);
     cls[ic].ooz = Z.oo; cls[ic].ooy = Y.oo; cls[ic].oox = X.oo;
     std::vector<int> tz(ntaps), ty(ntaps), tx(ntaps);
     const size_t t0 = tapoff.size();
-    tapoff.resize(t0 + (size_t)NU * TPC, 0);
+    tapoff.resize(t0 + (size_t)NR * TPC, 0);
     {
       int n = 0;
       for (int iz = 0; iz < ntz; ++iz) for (int iy = 0; iy < nty; ++iy) for (int ix = 0; ix < ntx; ++ix, ++n) {
@@ -1137,7 +1202,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
       }
     }
     const size_t w0 = pk.size();
-    auto weight_of = [&](int tap, int cin, int row) -> float {  // the weight that multiplies input channel `cin` of tap `tap` for output row `row`
+    auto weight_of = [&](int tap, int cin, int row, int ky = -1) -> float {  // the weight that multiplies input channel `cin` of tap `tap` for output row `row` (ky >= 0: that kernel row instead of the tap's)
       float v = 0.f;
       if (tap < ntaps && row < rows_valid) {
         if (L.up2) {  // sum of the kernel entries that fall on this (parity, input offset) pair, per axis
@@ -1159,11 +1224,11 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
             ok = ok && kk[d] >= 0;
           }
           if (ok) v = weight_at(co, cin, kk[0], kk[1], kk[2]);
-        } else if (mode == CONV_NORMAL) v = weight_at(row, cin, tz[tap], ty[tap], tx[tap]);
+        } else if (mode == CONV_NORMAL) v = weight_at(row, cin, tz[tap], ky >= 0 ? ky : ty[tap], tx[tap]);
         else {
           const int shift = mode == CONV_XPAIR ? (row >> 3) : row, co = mode == CONV_XPAIR ? (row & 7) : 0;
           const int kx = tx[tap] - shift;
-          if (kx >= 0 && kx < L.kw) v = weight_at(co, cin, tz[tap], ty[tap], kx);
+          if (kx >= 0 && kx < L.kw) v = weight_at(co, cin, tz[tap], ky >= 0 ? ky : ty[tap], kx);
         }
       }
       return v;
@@ -1180,6 +1245,14 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
           pb[((frag + 0) * 64 + l) * 8 + s] = hi;
           pb[((frag + 1) * 64 + l) * 8 + s] = lo;
         }
+    } else if (wino) {  // [pass][chunk of taps][point][row tile][lane]: u_p = sum_ky G[p][ky] w[ky], formed in double, rounded once
+      for (int p = 0; p < npass; ++p) for (int u = 0; u < NR; ++u) for (int pp = 0; pp < 4; ++pp) for (int ct = 0; ct < CTtot; ++ct)
+        for (int l = 0; l < 64; ++l) for (int s = 0; s < 4; ++s) {
+          const int g = l >> 4, i = l & 15, k16 = 4 * g + s;
+          double v = 0;
+          for (int ky = 0; ky < 3; ++ky) v += conv_wino_g(pp, ky) * (double)weight_of(u * TPC + k16 / CI, p * CI + k16 % CI, ct * 16 + i, ky);
+          pk[w0 + ((((size_t)p * NU + u * 4 + pp) * CTtot + ct) * 64 + l) * 4 + s] = (float)v;
+        }
     } else
     for (int p = 0; p < npass; ++p) for (int u = 0; u < NU; ++u) for (int ct = 0; ct < CTtot; ++ct)
       for (int l = 0; l < 64; ++l) for (int s = 0; s < 4; ++s) {
@@ -1188,7 +1261,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
       }
     if (L.up2) flops += ic == 0 ? 2.0 * nPD * nPH * nPW * 16.0 * L.Cin * L.Cout : 0.0;  // 4 output pixels x (2 x 2 input pixels) per input position
     else if (L.transposed) flops += ic == 0 ? 2.0 * nPD * nPH * nPW * (double)L.kd * L.kh * L.kw * L.Cin * L.Cout : 0.0;
-    else flops += 2.0 * nPD * nPH * nPW * (mode == CONV_NORMAL ? 1 : shifts) * (double)ntz * nty * (mode == CONV_NORMAL ? ntx : L.kw) * L.Cin * L.Cout;
+    else flops += 2.0 * nPD * (wino ? 2 * nPH : nPH) * nPW * (mode == CONV_NORMAL ? 1 : shifts) * (double)ntz * (wino ? 3 : nty) * (mode == CONV_NORMAL ? ntx : L.kw) * L.Cin * L.Cout;  // (algorithmic: the direct form's)
   }
 
   ConvLaunch cl{};
@@ -1227,6 +1300,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   cl.lds_bytes = (size_t)TZI * TYI * TXI * CIS * 4 + (size_t)nu_max * CT * (bf3 ? 2048 : 1024) + (size_t)nu_max * TPC * 4 + 64;
   cl.bf3 = bf3 ? 1 : 0;
   a.zero16 = nullptr; a.a_slots = 0; a.a_wbufs = 1;
+  if (wino) cl.async = 4;  // (k_conv's LDS layout and grid: the tile, nuMax weight chunks, the tap table)
   if (ASYNC == 1) {
     cl.async = 1;
     a.zero16 = arena.upload(std::vector<float>(4, 0.f));
@@ -1242,7 +1316,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
     const int want = std::max(1, std::min(ntiles, 256 * wpc / split));
     cl.grid = dim3(8 * cdiv(want, 8), 1, split);
   }
-  if (ASYNC >= 2) {
+  if (ASYNC == 2 || ASYNC == 3) {
     const bool rm = ASYNC == 3;
     const MarchShape ms = rm ? march_shape(L.kd, row_ntp, L.Cin, CI, CT, PT, 1, TXT, SX, exy, exx, nPD, nPH, nPW, CTtot, true)
                              : march_shape(L.kd, march_ntp, L.Cin, CI, CT, PT, TY, TXT, SX, exy, exx, nPD, nPH, nPW, CTtot);
@@ -1313,6 +1387,12 @@ inline void launch_conv_a_inst(const ConvLaunch &c, hipStream_t st) {
   conv_allow_big_lds(reinterpret_cast<const void *>(&k_conv_a<CI, CT, PT>), done, c.lds_bytes);
   hipLaunchKernelGGL((k_conv_a<CI, CT, PT>), c.grid, dim3(kConvAThreads), c.lds_bytes, st, c.args);
 }
+template <int CI, int CT, int PT>
+inline void launch_conv_w_inst(const ConvLaunch &c, hipStream_t st) {
+  static std::atomic<unsigned long long> done{0};
+  conv_allow_big_lds(reinterpret_cast<const void *>(&k_conv_w<CI, CT, PT>), done, c.lds_bytes);
+  hipLaunchKernelGGL((k_conv_w<CI, CT, PT>), c.grid, dim3(kConvThreads), c.lds_bytes, st, c.args);
+}
 template <int CI, int NUP, int CT, int PT, int FZ = 0, int NCW = 8>
 inline void launch_conv_m_inst(const ConvLaunch &c, hipStream_t st) {
   static std::atomic<unsigned long long> done{0};
@@ -1352,6 +1432,13 @@ inline void launch_conv(const ConvLaunch &c, hipStream_t st) {
     DR_MARCH_INSTANCES(DR_X)
 #undef DR_X
     fail(DR_ERR_ARG, "launch_conv: no marching instance CI=%d NUP=%d CT=%d PT=%d waves=%d", c.ci, c.nup, c.ct, c.pt, c.ncw);
+  }
+  if (c.async == 4) {
+#define DR_CONV_W_CASE(CI_, CT_, PT_) if (c.ci == CI_ && c.ct == CT_ && c.pt == PT_) { launch_conv_w_inst<CI_, CT_, PT_>(c, st); return; }
+    DR_CONV_W_CASE(16, 1, 1) DR_CONV_W_CASE(16, 1, 2) DR_CONV_W_CASE(16, 2, 1) DR_CONV_W_CASE(16, 2, 2)
+    DR_CONV_W_CASE(8, 1, 1) DR_CONV_W_CASE(8, 1, 2)
+#undef DR_CONV_W_CASE
+    fail(DR_ERR_ARG, "launch_conv: no Winograd instance CI=%d CT=%d PT=%d", c.ci, c.ct, c.pt);
   }
   if (c.async) {
 #define DR_CONV_A_CASE(CI_, CT_)                                                \

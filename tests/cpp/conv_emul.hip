@@ -150,6 +150,97 @@ static bool emulate(const ConvLaunch &c, const float *in, float *out, const floa
   return true;
 }
 
+// k_conv_w (conv_wino.h): k_conv's staging, then per chunk of taps the four rows d0..d3 of every lane's column, the input transform in
+// fp32 as the kernel does it, four implicit GEMMs (one per Winograd point, weights [chunk][point][row tile][lane]), the output transform and
+// two output rows per position.
+static bool emulate_wino(const ConvLaunch &c, const float *in, float *out, const float *add) {
+  const ConvArgs &a = c.args;
+  const int CI = c.ci, CT = c.ct, PT = c.pt, TPC = 16 / CI;
+  const int NP = a.TZI * a.TYI * a.TXI;
+  const ConvClass &cls = a.cls[0];
+  const int NU = cls.NU, NR = NU / 4;
+  if (c.grid.y != 1 || a.sy != 2 || a.omy != 2 || (NU & 3)) { printf("emul: not a k_conv_w launch\n"); return false; }
+  std::vector<float> tile((size_t)NP * CI);
+  for (unsigned bz = 0; bz < c.grid.z; ++bz) {
+    const int ct0 = (int)bz * CT;
+    for (int td = 0; td < a.tilesD; ++td) for (int th = 0; th < a.tilesH; ++th) for (int tw = 0; tw < a.tilesW; ++tw) {
+      const int pz0 = td * a.TZ, py0 = th * a.TY, px0 = tw * a.TXT * 16;
+      const int iz0 = pz0 * a.sz - a.pz, iy0 = py0 * a.sy - a.py, ix0 = px0 * a.sx - a.px;
+      std::vector<float> acc((size_t)4 * 4 * CT * PT * 64 * 4, 0.f);  // [point][wave][ct][pt][lane][4]
+      auto A = [&](int pp, int wave, int ct, int pt, int lane, int r) -> float & { return acc[(((((size_t)pp * 4 + wave) * CT + ct) * PT + pt) * 64 + lane) * 4 + r]; };
+      for (int p = 0; p < a.npass; ++p) {
+        for (int pos = 0; pos < NP; ++pos) {
+          const int x = pos % a.TXI, y = (pos / a.TXI) % a.TYI, z = pos / (a.TXI * a.TYI);
+          const int gz = iz0 + z, gy = iy0 + y, gx = ix0 + x;
+          const bool inside = gz >= 0 && gz < a.inD && gy >= 0 && gy < a.inH && gx >= 0 && gx < a.inW;
+          for (int ch = 0; ch < CI; ++ch) tile[(size_t)pos * CI + ch] = inside ? in[(((size_t)gz * a.inH + gy) * a.inW + gx) * a.inC + p * CI + ch] : 0.f;
+        }
+        for (int wave = 0; wave < 4; ++wave)
+          for (int r = 0; r < NR; ++r)
+            for (int ct = 0; ct < CT; ++ct)
+              for (int pt = 0; pt < PT; ++pt) {
+                float av[4][64][4], v[4][64][4];
+                for (int lane = 0; lane < 64; ++lane) {
+                  const int j = lane & 15, g = lane >> 4;
+                  for (int pp = 0; pp < 4; ++pp) {
+                    const float4 w = a.wpk[cls.w_base + (((size_t)p * NU + r * 4 + pp) * a.ctTot + ct0 + ct) * 64 + lane];
+                    av[pp][lane][0] = w.x; av[pp][lane][1] = w.y; av[pp][lane][2] = w.z; av[pp][lane][3] = w.w;
+                  }
+                  const int tau = wave * PT + pt, xt = tau % a.TXT, yt = (tau / a.TXT) % a.TY, zt = tau / (a.TXT * a.TY);
+                  const int base = ((zt * a.sz) * a.TYI + yt * a.sy) * a.TXI + (xt * 16 + j) * a.sx;
+                  const int tap = r * TPC + (4 * g) / CI, c0 = (4 * g) % CI;
+                  float d[4][4];
+                  for (int q = 0; q < 4; ++q) {
+                    const int tpos = base + a.tapoff[cls.tap_base + tap] + q * a.TXI;
+                    for (int s = 0; s < 4; ++s) d[q][s] = (tpos >= 0 && tpos < NP) ? tile[(size_t)tpos * CI + c0 + s] : NAN;
+                  }
+                  for (int s = 0; s < 4; ++s) { v[0][lane][s] = d[0][s] - d[2][s]; v[1][lane][s] = d[1][s] + d[2][s]; v[2][lane][s] = d[2][s] - d[1][s]; v[3][lane][s] = d[1][s] - d[3][s]; }
+                }
+                for (int pp = 0; pp < 4; ++pp)
+                  for (int col = 0; col < 16; ++col)
+                    for (int row = 0; row < 16; ++row) {
+                      float &dd = A(pp, wave, ct, pt, (row >> 2) * 16 + col, row & 3);
+                      for (int s = 0; s < 4; ++s)
+                        for (int g = 0; g < 4; ++g) {
+                          const float wv = av[pp][g * 16 + row][s];
+                          if (wv != 0.f) dd = std::fmaf(wv, v[pp][g * 16 + col][s], dd);
+                        }
+                    }
+              }
+      }
+      for (int wave = 0; wave < 4; ++wave)
+        for (int pt = 0; pt < PT; ++pt)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int j = lane & 15, g = lane >> 4;
+            const int tau = wave * PT + pt, xt = tau % a.TXT, yt = (tau / a.TXT) % a.TY, zt = tau / (a.TXT * a.TY);
+            const int qz = pz0 + zt, qy = py0 + yt, qx = px0 + xt * 16 + j;
+            if (qz >= a.nPD || qy >= a.nPH || qx >= a.nPW) continue;
+            for (int ct = 0; ct < CT; ++ct) {
+              const int c0 = (ct0 + ct) * 16 + 4 * g;
+              if (c0 >= a.rows_valid) continue;
+              const int oz = qz * a.omz + cls.ooz, ox = qx * a.omx + cls.oox;
+              for (int ro = 0; ro < 2; ++ro) {
+                const int oy = qy * 2 + ro;
+                const size_t ob = (((size_t)oz * a.outH + oy) * a.outW + ox) * a.outC + c0;
+                size_t ab = ob;
+                if (a.add_mode == 2) ab = (((size_t)oz * a.addH + (oy >> 1)) * a.addW + (ox >> 1)) * a.outC + c0;
+                for (int r = 0; r < 4; ++r) {
+                  const float m0 = A(0, wave, ct, pt, lane, r), m1 = A(1, wave, ct, pt, lane, r), m2 = A(2, wave, ct, pt, lane, r), m3 = A(3, wave, ct, pt, lane, r);
+                  float vv = ro == 0 ? (m0 + m1) + m2 : (m1 - m2) - m3;
+                  vv = vv * a.scale[c0 + r] + a.bias[c0 + r];
+                  if (a.relu) vv = std::max(vv, 0.f);
+                  if (a.add_mode) vv += add[ab + r];
+                  if (std::isnan(vv)) { printf("emul: an operand outside the staged tile reached a non-zero weight\n"); return false; }
+                  out[ob + r] = vv;
+                }
+              }
+            }
+          }
+    }
+  }
+  return true;
+}
+
 // The persistent LDS-DMA kernel k_conv_a: the tile image every DMA piece produces (conv_a_slot: slot -> staged element, zeros from the
 // zero buffer), the workgroups' tile lists (XCD ranges, round-robin inside), operands through conv_a_unit, 8 waves of PT position tiles.
 template <int CI>
@@ -299,7 +390,7 @@ static int run_case(const Case &cs, int max_plans) {
   L.Cin = cs.Cin; L.Cout = cs.Cout; L.kd = cs.kd; L.kh = cs.kh; L.kw = cs.kw; L.sd = cs.sd; L.sh = cs.sh; L.sw = cs.sw;
   L.transposed = cs.kind == 1; L.weight = w.data(); L.scale = sc; L.bias = bi; L.relu = cs.relu;
   const ConvMode mode = (cs.kind == 0 && cs.sw == 1 && cs.Cout == 8) ? CONV_XPAIR : ((cs.kind == 0 && cs.sw == 1 && cs.Cout == 1) ? CONV_X8 : CONV_NORMAL);
-  int done = 0, fails = 0, n_async = 0;
+  int done = 0, fails = 0, n_async = 0, n_wino = 0;
   for (int rank = 0; rank < 400 && done < max_plans; rank += 3) {
     std::vector<float> out(on, -777.f);
     DeviceArena arena;
@@ -319,13 +410,14 @@ static int run_case(const Case &cs, int max_plans) {
                        : (c.ci == 8 ? emulate_async<8>(c, in.data(), out.data(), add.data(), &seen) : emulate_async<16>(c, in.data(), out.data(), add.data(), &seen));
         if (ok && seen != (long long)c.args.tilesD * c.args.tilesH * c.args.tilesW) { ok = false; printf("emul: the workgroups' tile lists cover %lld of %d tiles\n", seen, c.args.tilesD * c.args.tilesH * c.args.tilesW); }
         ++n_async;
-      } else ok = emulate(c, in.data(), out.data(), add.data());
+      } else if (c.async == 4) { ok = emulate_wino(c, in.data(), out.data(), add.data()); ++n_wino; }
+      else ok = emulate(c, in.data(), out.data(), add.data());
     }
     if (rank >= ncand) break;
     double worst = 0;
     for (size_t i = 0; i < on; ++i) worst = std::max(worst, (double)std::fabs(out[i] - ref[i]) / (1.0 + std::fabs(ref[i])));
     const bool pass = ok && worst < (c.bf3 ? 1e-4 : 2e-5) && (c.bf3 != 0) == (conv_bf3_policy() && cs.Cin % 8 == 0);  // (bf16 x 3: the dropped w_l x_l term and the lo terms' rounding, ~2^-16 per product)
-    printf("%-26s plan rank %3d %s ci=%d ct=%d pt=%d tile %dx%dx%d classes %u rows %d: %s (max rel err %.2e)\n", cs.name, rank, c.async ? "k_conv_a" : (c.bf3 ? "k_conv_b" : "k_conv"), c.ci, c.ct, c.pt, c.args.TZ, c.args.TY,
+    printf("%-26s plan rank %3d %s ci=%d ct=%d pt=%d tile %dx%dx%d classes %u rows %d: %s (max rel err %.2e)\n", cs.name, rank, c.async == 4 ? "k_conv_w" : (c.async ? "k_conv_a" : (c.bf3 ? "k_conv_b" : "k_conv")), c.ci, c.ct, c.pt, c.args.TZ, c.args.TY,
            c.args.TXT * 16, c.grid.y, c.args.rows_valid, pass ? "ok" : "FAIL", worst);
     ++done;
     if (!pass) ++fails;
@@ -339,6 +431,7 @@ int main(int argc, char **argv) {
   // DR_CONV_BF16X3=1 in the environment: every layer with Cin % 8 == 0 is planned for and emulated as k_conv_b (three bf16 terms).
   // (k_conv_m has its own emulation: march_emul.hip)
   setenv("DR_CONV_ASYNC", argc > 2 && !strcmp(argv[2], "async") ? "1" : "0", 1);
+  setenv("DR_CONV_WINO", argc > 2 && !strcmp(argv[2], "wino") ? "2" : "0", 1);  // "wino": rank k_conv_w's plans first wherever the Winograd form applies
   setenv("DR_CONV_MARCH", "0", 1);
   setenv("DR_CONV_ROWMARCH", "0", 1);
   setenv("DR_CONV_NO_TUNED", "1", 1);
@@ -363,6 +456,11 @@ int main(int argc, char **argv) {
       {"conv2d_3x3_32_16", 0, 2, 16, 40, 32, 16, 1, 3, 3, 1, 1, 1, false, 0},          // fn.out2: two channel passes
       {"conv3d_16_16_skip", 0, 6, 12, 32, 16, 16, 3, 3, 3, 1, 1, 1, true, 1},          // conv2 (+ a residual add)
       {"xpair3d_16_8", 0, 5, 10, 70, 16, 8, 3, 3, 3, 1, 1, 1, true, 0},                // conv0
+      // k_conv_w shapes (even H): Cin = 8 XPAIR, two channel passes, two row tiles, an upsample add
+      {"xpair2d_8_8", 0, 2, 12, 36, 8, 8, 1, 3, 3, 1, 1, 1, true, 0},                  // fn.conv0.1
+      {"conv2d_3x3_32_32_up2add", 0, 2, 8, 24, 32, 32, 1, 3, 3, 1, 1, 1, false, 2},    // fn.conv2.x shape with an upsample add
+      {"conv3d_32_32", 0, 4, 6, 20, 32, 32, 3, 3, 3, 1, 1, 1, true, 0},                // conv4
+      {"xpair3d_32_8", 0, 4, 8, 40, 32, 8, 3, 3, 3, 1, 1, 1, true, 0},                 // s1.conv0
   };
   int fails = 0;
   for (const Case &cs : cases) fails += run_case(cs, max_plans);

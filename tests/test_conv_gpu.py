@@ -170,6 +170,49 @@ def test_row_march_candidates(case, monkeypatch, capfd):
     assert kinds and kinds[0] == "rowmarch" and kinds.count("rowmarch") >= 2, kinds
 
 
+# ---- k_conv_w (conv_wino.h): the y axis of the stride-1 3-tap layers in Winograd F(2,3) form.  DR_CONV_WINO=2 ranks its candidates first;
+# the reference and the bound are the direct kernels' (torch fp32, 2e-5 of the value range): the transform may not cost accuracy.
+WINO = [
+    ("wino xpair 3x3 8->8, 7 views", (7, 64, 192), 8, 8, (1, 3, 3), (1, 1, 1), False, True, "none"),
+    ("wino 3x3 16->16 +skip, 7 views", (7, 48, 112), 16, 16, (1, 3, 3), (1, 1, 1), False, True, "same"),
+    ("wino 3x3 32->32 (two passes)", (3, 40, 80), 32, 32, (1, 3, 3), (1, 1, 1), False, True, "none"),
+    ("wino 3x3 32->16 +up2", (2, 32, 96), 32, 16, (1, 3, 3), (1, 1, 1), False, False, "up2"),
+    ("wino xpair 3x3 32->8", (2, 34, 128), 32, 8, (1, 3, 3), (1, 1, 1), False, False, "none"),
+    ("wino 3x3x3 16->16 +skip", (10, 24, 48), 16, 16, (3, 3, 3), (1, 1, 1), False, True, "same"),
+    ("wino xpair 3x3x3 16->8", (8, 36, 70), 16, 8, (3, 3, 3), (1, 1, 1), False, True, "none"),
+    ("wino xpair 3x3x3 32->8", (6, 20, 64), 32, 8, (3, 3, 3), (1, 1, 1), False, True, "none"),
+    ("wino xpair 3x3x3 8->8", (4, 30, 96), 8, 8, (3, 3, 3), (1, 1, 1), False, True, "none"),
+    ("wino 3x3x3 32->32", (4, 12, 40), 32, 32, (3, 3, 3), (1, 1, 1), False, True, "none"),
+    ("wino 3x3x3 64->64", (3, 8, 20), 64, 64, (3, 3, 3), (1, 1, 1), False, True, "none"),
+    ("wino ragged 3x3 16->16", (3, 22, 300), 16, 16, (1, 3, 3), (1, 1, 1), False, True, "none"),
+    ("wino two-row image 3x3 16->16", (4, 2, 64), 16, 16, (1, 3, 3), (1, 1, 1), False, True, "none"),
+]
+
+
+@pytest.mark.parametrize("case", WINO, ids=[c[0] for c in WINO])
+def test_winograd_kernel_candidates(case, monkeypatch, capfd):
+    monkeypatch.setenv("DR_CONV_WINO", "2")
+    monkeypatch.setenv("DR_CONV_PRINT", "1")
+    kinds = []
+    for rank in range(0, 36):
+        monkeypatch.setenv("DR_CONV_RANK", str(rank))
+        run_case(case)
+        kinds += [l.split()[1].split("<")[0] for l in capfd.readouterr().err.splitlines() if l.startswith("debug_conv:")]
+    assert kinds and kinds[0] == "wino" and kinds.count("wino") >= 4, kinds
+
+
+def test_winograd_form_is_not_planned_where_it_does_not_apply(monkeypatch, capfd):
+    """Odd output height, strided, transposed and 5x5 layers stay on the direct kernels even when the Winograd form is preferred."""
+    monkeypatch.setenv("DR_CONV_WINO", "2")
+    monkeypatch.setenv("DR_CONV_PRINT", "1")
+    monkeypatch.setenv("DR_CONV_RANK", "0")
+    for name in ("cr.conv5 32->64 s2 odd", "fn.conv1.0 5x5s2 8->16", "cr.conv9 deconv 32->16 +skip", "cr.prob 8->1 x8"):
+        run_case([c for c in CASES if c[0] == name][0])
+    run_case(("odd rows 3x3 16->16", (2, 15, 48), 16, 16, (1, 3, 3), (1, 1, 1), False, True, "none"))
+    kinds = [l.split()[1].split("<")[0] for l in capfd.readouterr().err.splitlines() if l.startswith("debug_conv:")]
+    assert len(kinds) == 5 and "wino" not in kinds, kinds
+
+
 # ---- transposed stride-2 layers: the three parity forms (conv_mfma.h axis_classes: dense rows / x dense + (z, y) classes / one class per
 # parity) compute the same layer; every plan candidate of each form.
 DECONV = [c for c in CASES if c[6]] + [

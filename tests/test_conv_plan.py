@@ -79,6 +79,24 @@ def test_persistent_kernel_emulation_matches_the_layer_definitions(conv_emul):
         assert any(needle in l for l in a), needle
 
 
+def test_winograd_kernel_emulation_matches_the_layer_definitions(conv_emul):
+    """The same layers with k_conv_w's plans ranked first (DR_CONV_WINO=2 inside the program; csrc/conv_wino.h): the y axis re-described as
+    row pairs (stride 2, 4-row window, tap table without y), the weights transformed per Winograd point ([chunk][point][row tile][lane],
+    XPAIR shifts included), the four rows every lane reads per chunk, the fp32 input / output transforms and the two output rows per
+    position.  The error against the layer's definition must stay at the direct kernel's level (fp32 reassociation), not the 1e-4 of a
+    reduced-precision form; layers the form does not apply to (strided, transposed, 5x5, odd heights, X8) fall back to k_conv."""
+    out = subprocess.run([conv_emul, "12", "wino"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if " plan rank " in l]
+    assert all(": ok " in l for l in lines), out.stdout[-4000:]
+    w = [l for l in lines if " k_conv_w " in l]
+    assert len(w) >= 30, len(w)
+    for needle in ("xpair2d_8_8", "conv2d_3x3_32_32_up2add", "conv3d_16_16_skip", "xpair3d_32_8", "conv3d_32_32", "ct=2 ", "pt=2 ", "ci=8 "):
+        assert any(needle in l for l in w), needle
+    assert not any(n in l for l in w for n in ("conv2d_5x5", "deconv_", "up2_32_8", "x8_prob", "conv3d_s2", "xpair2d_4_8 "))  # (xpair2d_4_8: H = 9 is odd)
+    assert max(float(l.split("max rel err ")[1].rstrip(")")) for l in w) < 6e-6
+
+
 def test_every_tuned_row_names_a_plan_the_planner_can_build(tmp_path):
     """conv_tuned.h rows are matched by layer signature and then by plan parameters; a row whose plan no longer exists (an instance
     removed, a tile rule changed) is silently ignored and the layer falls back to the cost model.  tests/cpp/tuned_rows.hip plans

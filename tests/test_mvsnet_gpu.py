@@ -495,3 +495,31 @@ def test_bf16x3_mode_stays_inside_the_fp32_bounds(path, trained_blob, tmp_path, 
     assert not np.array_equal(outs[0].depth_dense, outs[1].depth_dense)  # the mode really ran
     # (2e-3 m at the scene's 4.5 m depth range; the bound scales with the range, i.e. with the spacing of the hypothesis planes)
     assert np.abs(outs[0].depth_dense - outs[1].depth_dense).max() < 4.5e-4 * (float(g["depth_max"]) - float(g["depth_min"]))
+
+
+# ---- the Winograd F(2,3) form of the stride-1 3-tap layers (csrc/conv_wino.h) ----
+@pytest.mark.parametrize("path", [p for p in GOLD if "novar" not in p], ids=lambda p: os.path.basename(p))
+def test_winograd_form_stays_inside_the_fp32_bounds(path, trained_blob, tmp_path, monkeypatch):
+    """DR_CONV_WINO=2 puts every layer the form applies to (3-tap stride-1 y axis, even output height) on k_conv_w -- far more layers than
+    the tuned plan table does by default -- and the depth maps must still pass the bounds of the direct kernels against the reference's
+    outputs: the transform is fp32-exact algebra, it may only reassociate.  The engines must differ (the form really ran) and agree to
+    the level the autotuned-plan test allows for any re-tiling."""
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    g = np.load(path)
+    blob = blob_for(g, trained_blob, tmp_path)
+    bgrs = [np.ascontiguousarray(b) for b in g["bgrs"]]
+    H, W = bgrs[0].shape[:2]
+    args = (H, W, len(bgrs), int(g["ref_index"]), bgrs, g["K"], list(g["c2ws"]), float(g["depth_min"]), float(g["depth_max"]), float(g["discard"]))
+    outs = []
+    for mode in ("2", "0"):
+        monkeypatch.setenv("DR_CONV_WINO", mode)
+        m = DrMvsnet(blob)
+        m.CallAsync(*args)
+        outs.append(m.GetResult())
+        m.close()
+    ref = {k: g[f"ref_s3_{k}"] for k in ("depth", "confidence", "depth_dense", "confidence_dense")}
+    compare(outs[0], ref, "winograd " + os.path.basename(path))
+    compare(outs[1], ref, "direct " + os.path.basename(path))
+    assert not np.array_equal(outs[0].depth_dense, outs[1].depth_dense)
+    d = np.abs(outs[0].depth_dense - outs[1].depth_dense)
+    assert d.mean() < 2e-5 * (float(g["depth_max"]) - float(g["depth_min"])), d.mean()
