@@ -856,7 +856,7 @@ inline bool conv_w_instance_exists(int ci, int ct, int pt) {
 // DR_CONV_WINO: 0 = never plan k_conv_w, 1 = rank it with the other families (default), 2 = prefer it wherever it applies (A/B hook, tests)
 inline int conv_wino_policy() {
   if (const char *e = getenv("DR_CONV_WINO")) return atoi(e);
-  return 0;  // (until it has been measured on the GPU)
+  return 1;
 }
 // Winograd F(2,3) weight transform along one 3-tap axis: point p of (g0, g1, g2)
 inline double conv_wino_g(int p, int k) {
@@ -1095,7 +1095,10 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
             const double lat_wg = npass * nr * chunk_mfma + stage;
             const double waves = std::ceil(n_wg / (256.0 * wg_per_cu));
             const double thr = (mfma_total + stage_total) / 256.0 / (wg_per_cu >= 2 ? 0.8 : 0.5);
-            double cost = std::max(thr, waves * lat_wg) * 1.25;  // not calibrated against the direct kernels yet: an untuned shape moves here only with some margin
+            // measured (r4, profiles/r04_winograd.txt): 14-17 % faster than the best direct plan on every 2-D 3x3 layer of both tuned shapes, 5-7 % on the
+            // 16- to 64-channel 3-D layers, slower than the marching kernel on the conv0 layers.  The model below overstates the gain (it has no term
+            // for the smaller tiles' halo), so an untuned shape moves here with a margin, and a 3-D layer only when a tuned row says so.
+            double cost = std::max(thr, waves * lat_wg) * (L.kd == 1 ? 1.25 : 2.5);
             if (wino_policy >= 2) cost *= 1e-3;
             cands.push_back({cost, ci, pt, ct, c[0], c[1], c[2], tzi, tyi, txi, 4});
           }
