@@ -326,18 +326,25 @@ def boundary_leg(args, dev):
     blob = model_blob()
     out = {}
     per = max(10, min(60, args.steps // 3))
-    for E in (1, 3):
+    for E, pinned in ((1, False), (3, False), (1, True)):
         engines = [DrMvsnet(blob, device=dev) for _ in range(E)]
         wins = [scene.make_window(H, W, V, seed=40 + e) for e in range(E)]
         call_ms = [0.0] * E
+        imgs = [w["bgrs"] for w in wins]
+        if pinned:  # the extensions of include/dr_mi355x.h: key-frame images in page-locked memory (uploaded in place), results as views
+            imgs = []
+            for m, w in zip(engines, wins):
+                imgs.append(m.alloc_images(V, H, W))
+                for dst, src in zip(imgs[-1], w["bgrs"]):
+                    dst[...] = src
 
         def loop(e, n):
             m, w = engines[e], wins[e]
             for _ in range(n):
                 t0 = time.perf_counter()
-                m.CallAsync(H, W, V, w["ref_index"], w["bgrs"], w["K"], list(w["c2ws"]), DEPTH_MIN, DEPTH_MAX, DISCARD)
+                m.CallAsync(H, W, V, w["ref_index"], imgs[e], w["K"], list(w["c2ws"]), DEPTH_MIN, DEPTH_MAX, DISCARD)
                 call_ms[e] += 1e3 * (time.perf_counter() - t0)
-                m.GetResult()
+                m.GetResultView() if pinned else m.GetResult()
         for e in range(E):
             loop(e, 3)  # warm-up (plans, pinned buffers)
         call_ms = [0.0] * E
@@ -348,11 +355,13 @@ def boundary_leg(args, dev):
         for t in threads:
             t.join()
         dt = time.perf_counter() - t0
-        out["engines_%d" % E] = dict(depth_maps_per_s=E * per / dt, ms_per_depth_map_per_engine=1e3 * dt / per,
+        out["engines_%d%s" % (E, "_pinned" if pinned else "")] = dict(depth_maps_per_s=E * per / dt, ms_per_depth_map_per_engine=1e3 * dt / per,
                                      call_async_ms=sum(call_ms) / (E * per), windows=E * per)
         for m in engines:
             m.close()
-    out["note"] = "CallAsync(host u8 BGR x7, K, poses) -> GetResult (4 float maps) per window; host reorder + H2D + forward + D2H"
+    out["note"] = ("CallAsync(host u8 BGR x7, K, poses) -> GetResult (4 float maps) per window; host reorder + H2D + forward + D2H.  "
+                   "engines_1_pinned: the same through the extensions drm_host_alloc (images in page-locked memory, uploaded in place) and "
+                   "drm_get_result_view (the maps as views of the engine's pinned block): no host copy on either side")
     return out
 
 
@@ -725,6 +734,7 @@ def main():
         if bd is not None and "engines_1" in bd:
             out["boundary_single_engine_ms"] = bd["engines_1"]["ms_per_depth_map_per_engine"]
             out["boundary_single_engine_depth_maps_per_s"] = bd["engines_1"]["depth_maps_per_s"]
+            out["boundary_pinned_single_engine_ms"] = bd["engines_1_pinned"]["ms_per_depth_map_per_engine"]
         if ts is not None:
             out["tsdf"] = ts
         if bd is not None:

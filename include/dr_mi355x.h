@@ -61,6 +61,16 @@ int drm_wait(drm_t *h);
  * DrMvsnetOutput, dr_mvsnet.h:12-34).  A second call without a new drm_call_async returns
  * DR_ERR_PROTOCOL (reference: exit, dr_mvsnet.cpp:100-103). */
 int drm_get_result(drm_t *h, float *depth, float *confidence, float *depth_dense, float *confidence_dense);
+/* The operator boundary without its two host copies (no reference counterpart; DrMvsnet::GetResultView / AllocImage in the shim):
+ * drm_get_result_view = drm_get_result returning POINTERS into the page-locked block the device wrote the four maps to (no 4.9 MB copy).
+ * Two blocks alternate: the maps stay valid while the next drm_call_async is processed and are overwritten by the one after it; they
+ * die with the engine and with a change of resolution.  Same protocol errors as drm_get_result.
+ * drm_host_alloc / drm_host_free = page-locked host memory.  When EVERY image of a drm_call_async lives in page-locked memory (from
+ * here, hipHostMalloc or hipHostRegister) the upload reads it in place instead of gathering the window into the engine's own staging
+ * block first; the call still returns only after the copies have completed, so the caller may reuse the images at once. */
+int drm_get_result_view(drm_t *h, const float **depth, const float **confidence, const float **depth_dense, const float **confidence_dense);
+void *drm_host_alloc(size_t bytes);
+void drm_host_free(void *p);
 
 /* --- device-resident / measurement / introspection hooks (no reference counterpart) --- */
 /* Upload a window (same arguments as drm_call_async) and keep it resident in HBM. Synchronous. */

@@ -44,6 +44,9 @@ SIGNATURES = {
     "drm_ready": (C.c_int, [vp]),
     "drm_wait": (C.c_int, [vp]),
     "drm_get_result": (C.c_int, [vp, f32p, f32p, f32p, f32p]),
+    "drm_get_result_view": (C.c_int, [vp, C.POINTER(f32p), C.POINTER(f32p), C.POINTER(f32p), C.POINTER(f32p)]),
+    "drm_host_alloc": (vp, [C.c_size_t]),
+    "drm_host_free": (None, [vp]),
     "drm_upload": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(u8p), f32p, C.POINTER(f32p),
                              C.c_float, C.c_float, C.c_float]),
     "drm_forward": (C.c_int, [vp, C.c_int, f32p]),

@@ -1614,10 +1614,10 @@ class FusionEngine {
   int raycast_sampler_ = getenv("DR_RAYCAST_SAMPLER") ? std::max(0, std::min(1, atoi(getenv("DR_RAYCAST_SAMPLER")))) : (getenv("DR_RAYCAST_UNSTAGED") ? 0 : 1);
   bool render_copy_ = getenv("DR_RENDER_D2H") && !strcmp(getenv("DR_RENDER_D2H"), "copy");
   bool raycast_stats_ = getenv("DR_RAYCAST_STATS") != nullptr;     // measuring hook: iteration statistics of k_raycast2 on stderr
+  unsigned long long *d_rstats_ = nullptr;
 #else
   static constexpr bool render_copy_ = false;
 #endif
-  unsigned long long *d_rstats_ = nullptr;
   std::vector<Render> renders_;
   int free_slot_ = 0;
   Next next_ = kIntegrate;

@@ -245,8 +245,9 @@ class MvsEngine {
     (void)hipStreamSynchronize(stream_);
     if (comm_) { Rccl::get().CommDestroy(comm_); comm_ = nullptr; }
     release();
-    if (h_out_) (void)hipHostFree(h_out_);
+    for (float *&h : h_out_) if (h) (void)hipHostFree(h);
     if (h_in_) (void)hipHostFree(h_in_);
+    if (ev_h2d_) (void)hipEventDestroy(ev_h2d_);
     if (march_err_) (void)hipHostFree(march_err_);
     (void)hipStreamSynchronize(side_);
     for (auto e : {ev_fork_, ev_feat2_, ev_feat3_}) (void)hipEventDestroy(e);
@@ -276,8 +277,24 @@ class MvsEngine {
     rethrow_worker_error();
     if (!has_output_) fail(DR_ERR_PROTOCOL, "Output should be valid. Maybe you called GetResult more than once?");
     const size_t n = (size_t)H_ * W_;
-    memcpy(depth, h_out_, n * 4); memcpy(conf, h_out_ + n, n * 4);
-    memcpy(depth_dense, h_out_ + 2 * n, n * 4); memcpy(conf_dense, h_out_ + 3 * n, n * 4);
+    const float *src = h_out_[out_cur_];
+    memcpy(depth, src, n * 4); memcpy(conf, src + n, n * 4);
+    memcpy(depth_dense, src + 2 * n, n * 4); memcpy(conf_dense, src + 3 * n, n * 4);
+    has_output_ = false;
+  }
+  // The same result WITHOUT the 4.9 MB host copy: pointers into the page-locked block the device wrote it to.  Two blocks alternate,
+  // so the maps stay valid while the NEXT call is processed and die when the call after that one starts.
+  void get_result_view(const float **depth, const float **conf, const float **depth_dense, const float **conf_dense) {
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [&] { return !unprocessed_; });
+    rethrow_worker_error();
+    if (!has_output_) fail(DR_ERR_PROTOCOL, "Output should be valid. Maybe you called GetResult more than once?");
+    const size_t n = (size_t)H_ * W_;
+    const float *src = h_out_[out_cur_];
+    if (depth) *depth = src;
+    if (conf) *conf = src + n;
+    if (depth_dense) *depth_dense = src + 2 * n;
+    if (conf_dense) *conf_dense = src + 3 * n;
     has_output_ = false;
   }
 
@@ -521,17 +538,20 @@ class MvsEngine {
           DR_HIP(hipSetDevice(device_));
           forward(nullptr);
           const size_t n = (size_t)H_ * W_ * 4;
+          const int blk = out_cur_ ^ 1;  // the block the previous result does NOT live in (drm_get_result_view: that one may still be read)
+          float *ho = h_out_[blk];
           if (sw_.d2h_copy) {  // DR_MVS_D2H=copy: the four copy-engine transfers of round 2 (A/B hook)
-            DR_HIP(hipMemcpyAsync(h_out_, T("depth").d, n, hipMemcpyDeviceToHost, stream_));
-            DR_HIP(hipMemcpyAsync(h_out_ + n / 4, T("confidence").d, n, hipMemcpyDeviceToHost, stream_));
-            DR_HIP(hipMemcpyAsync(h_out_ + 2 * (n / 4), T("depth3").d, n, hipMemcpyDeviceToHost, stream_));
-            DR_HIP(hipMemcpyAsync(h_out_ + 3 * (n / 4), T("conf3").d, n, hipMemcpyDeviceToHost, stream_));
+            DR_HIP(hipMemcpyAsync(ho, T("depth").d, n, hipMemcpyDeviceToHost, stream_));
+            DR_HIP(hipMemcpyAsync(ho + n / 4, T("confidence").d, n, hipMemcpyDeviceToHost, stream_));
+            DR_HIP(hipMemcpyAsync(ho + 2 * (n / 4), T("depth3").d, n, hipMemcpyDeviceToHost, stream_));
+            DR_HIP(hipMemcpyAsync(ho + 3 * (n / 4), T("conf3").d, n, hipMemcpyDeviceToHost, stream_));
           } else {  // (H and W are multiples of 32: whole float4s)
             hipLaunchKernelGGL(k_publish4, dim3(256), dim3(256), 0, stream_, (const float4 *)T("depth").d, (const float4 *)T("confidence").d,
-                               (const float4 *)T("depth3").d, (const float4 *)T("conf3").d, (float4 *)h_out_dev_, n / 16);
+                               (const float4 *)T("depth3").d, (const float4 *)T("conf3").d, (float4 *)h_out_dev_[blk], n / 16);
           }
           DR_HIP(hipStreamSynchronize(stream_));
           check_march();
+          out_cur_ = blk;
           has_output_ = true;
         } catch (const std::exception &e) { worker_error_ = e.what(); }
         unprocessed_ = false;
@@ -686,10 +706,13 @@ class MvsEngine {
   void build_plan(int H, int W, int V) {
     plan_arena_.reset(new DeviceArena());
     plan_arena_->err_flag = march_err_;
-    if (h_out_) { (void)hipHostFree(h_out_); h_out_ = nullptr; }
+    for (float *&h : h_out_) if (h) { (void)hipHostFree(h); h = nullptr; }
     if (h_in_) { (void)hipHostFree(h_in_); h_in_ = nullptr; }
-    DR_HIP(hipHostMalloc((void **)&h_out_, (size_t)H * W * 16, hipHostMallocDefault));
-    DR_HIP(hipHostGetDevicePointer((void **)&h_out_dev_, h_out_, 0));
+    for (int b = 0; b < 2; ++b) {
+      DR_HIP(hipHostMalloc((void **)&h_out_[b], (size_t)H * W * 16, hipHostMallocDefault));
+      DR_HIP(hipHostGetDevicePointer((void **)&h_out_dev_[b], h_out_[b], 0));
+    }
+    has_output_ = false;
     DR_HIP(hipHostMalloc((void **)&h_in_, (size_t)V * H * W * 3, hipHostMallocDefault));
     d_bgr_ = dalloc<uint8_t>((size_t)V * H * W * 3); misc_.push_back(d_bgr_);
     d_state_ = dalloc<unsigned>(8); misc_.push_back(d_state_);
@@ -826,9 +849,24 @@ class MvsEngine {
     for (int i = 0; i < V; ++i) if (i != ref) order.push_back(i);
     // view by view: the copy engine moves view v to the device while the host gathers view v + 1 into the pinned block (one 6.45 MB
     // transfer behind seven memcpys cost their sum: 0.3 + 0.2 ms at 640 x 480 x 7 on the operator boundary's critical path)
+    // Images that already live in page-locked memory (drm_host_alloc, hipHostMalloc, hipHostRegister) go to the device straight from
+    // where they are -- no gather into the pinned block, which is the 0.3-0.4 ms memcpy on the operator boundary's critical path; the
+    // call still returns only when the copies have completed ("inputs are copied before return": the caller may reuse its buffers).
+    bool pinned = true;
+    for (int v = 0; v < V && pinned; ++v) {
+      hipPointerAttribute_t at;
+      if (hipPointerGetAttributes(&at, bgrs[v]) != hipSuccess) { (void)hipGetLastError(); pinned = false; }
+      else pinned = at.type == hipMemoryTypeHost;
+    }
     for (int v = 0; v < V; ++v) {
-      memcpy(h_in_ + v * img_bytes, bgrs[order[v]], img_bytes);
-      DR_HIP(hipMemcpyAsync(d_bgr_ + v * img_bytes, h_in_ + v * img_bytes, img_bytes, hipMemcpyHostToDevice, stream_));
+      const uint8_t *src = bgrs[order[v]];
+      if (!pinned) { memcpy(h_in_ + v * img_bytes, src, img_bytes); src = h_in_ + v * img_bytes; }
+      DR_HIP(hipMemcpyAsync(d_bgr_ + v * img_bytes, src, img_bytes, hipMemcpyHostToDevice, stream_));
+    }
+    if (pinned) {
+      if (!ev_h2d_) DR_HIP(hipEventCreateWithFlags(&ev_h2d_, hipEventDisableTiming));
+      DR_HIP(hipEventRecord(ev_h2d_, stream_));
+      DR_HIP(hipEventSynchronize(ev_h2d_));
     }
 
     // stage intrinsics: rows 0-1 x 0.25 / 0.5 / 1 (the C++ rule, dr_mvsnet.cpp:226-247)
@@ -1125,7 +1163,9 @@ class MvsEngine {
   CostVolArgs cv_[3];
   RegressArgs rg_[3];
   uint8_t *d_bgr_ = nullptr, *h_in_ = nullptr;
-  float *h_out_ = nullptr, *h_out_dev_ = nullptr;  // pinned result block (4 maps) and the address the device uses for it
+  float *h_out_[2] = {nullptr, nullptr}, *h_out_dev_[2] = {nullptr, nullptr};  // two pinned result blocks (4 maps each), used alternately, and the addresses the device uses for them
+  int out_cur_ = 0;                // the block the last result is in
+  hipEvent_t ev_h2d_ = nullptr;    // completion of a window uploaded straight from the caller's page-locked images
   unsigned *d_state_ = nullptr, *d_hist_ = nullptr;
   unsigned filter_rank_ = 0;
   int H_ = 0, W_ = 0, V_ = 0;
@@ -1184,6 +1224,15 @@ int drm_wait(drm_t *h) { return guarded([&] { eng(h)->wait(); }); }
 int drm_get_result(drm_t *h, float *depth, float *confidence, float *depth_dense, float *confidence_dense) {
   return guarded([&] { eng(h)->get_result(depth, confidence, depth_dense, confidence_dense); });
 }
+int drm_get_result_view(drm_t *h, const float **depth, const float **confidence, const float **depth_dense, const float **confidence_dense) {
+  return guarded([&] { eng(h)->get_result_view(depth, confidence, depth_dense, confidence_dense); });
+}
+void *drm_host_alloc(size_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+void drm_host_free(void *p) { if (p) (void)hipHostFree(p); }
 int drm_upload(drm_t *h, int height, int width, int view_num, int ref_index, const uint8_t *const *bgrs, const float *K9,
                const float *const *c2ws, float depth_min, float depth_max, float discard_percentage) {
   return guarded([&] { eng(h)->upload(height, width, view_num, ref_index, bgrs, K9, c2ws, depth_min, depth_max, discard_percentage); });

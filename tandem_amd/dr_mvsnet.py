@@ -53,6 +53,9 @@ class DrMvsnet:
         if getattr(self, "_h", None) and self._h.value:
             self._L.drm_destroy(self._h)
             self._h = C.c_void_p()
+        for ptr in getattr(self, "_pinned", []):
+            self._L.drm_host_free(ptr)
+        self._pinned = []
 
     __del__ = close
 
@@ -79,6 +82,29 @@ class DrMvsnet:
         check(self._L.drm_get_result(self._h, fptr(out.depth), fptr(out.confidence), fptr(out.depth_dense),
                                         fptr(out.confidence_dense)))
         return out
+
+    def GetResultView(self):
+        """GetResult without the host copy (include/dr_mi355x.h drm_get_result_view): the four maps are numpy VIEWS of the page-locked block
+        the device wrote them to -- valid while the next call is processed, overwritten by the one after it."""
+        if self._hw is None:
+            raise _lib.DrError(2, "GetResult before CallAsync")
+        p = [f32p() for _ in range(4)]
+        check(self._L.drm_get_result_view(self._h, *[C.byref(q) for q in p]))
+        out = DrMvsnetOutput.__new__(DrMvsnetOutput)
+        out.height, out.width = self._hw
+        out.depth, out.confidence, out.depth_dense, out.confidence_dense = [np.ctypeslib.as_array(q, shape=self._hw) for q in p]
+        return out
+
+    def alloc_images(self, view_num, height, width):
+        """`view_num` (H, W, 3) u8 arrays in page-locked memory (drm_host_alloc): CallAsync uploads such images in place, without the
+        gather into the engine's staging block.  Freed when the engine is closed."""
+        n = view_num * height * width * 3
+        ptr = self._L.drm_host_alloc(n)
+        if not ptr:
+            raise MemoryError("drm_host_alloc(%d)" % n)
+        self._pinned = getattr(self, "_pinned", []) + [ptr]
+        flat = np.ctypeslib.as_array(C.cast(ptr, u8p), shape=(n,))
+        return [flat[v * height * width * 3:(v + 1) * height * width * 3].reshape(height, width, 3) for v in range(view_num)]
 
     # ---- device-resident / introspection hooks (no reference counterpart) ----
     def upload(self, height, width, view_num, ref_index, bgrs, intrinsic_matrix, cam_to_worlds, depth_min, depth_max,

@@ -27,7 +27,10 @@ public:
     depth_dense = (float *) malloc(sizeof(float) * width * height);
     confidence_dense = (float *) malloc(sizeof(float) * width * height);
   }
-  ~DrMvsnetOutput() { free(depth); free(confidence); free(depth_dense); free(confidence_dense); }
+  // A VIEW of the engine's page-locked result block (DrMvsnet::GetResultView; no reference counterpart): the arrays are not owned.
+  DrMvsnetOutput(int height, int width, float *d, float *c, float *dd, float *cd)
+      : depth(d), confidence(c), depth_dense(dd), confidence_dense(cd), height(height), width(width), view_(true) {}
+  ~DrMvsnetOutput() { if (!view_) { free(depth); free(confidence); free(depth_dense); free(confidence_dense); } }
   DrMvsnetOutput(const DrMvsnetOutput &) = delete;
   DrMvsnetOutput &operator=(const DrMvsnetOutput &) = delete;
 
@@ -37,6 +40,9 @@ public:
   float *confidence_dense;
   const int height;
   const int width;
+
+private:
+  const bool view_ = false;
 };
 
 class DrMvsnet {  // dr_mvsnet.h:36-66
@@ -73,6 +79,19 @@ public:
     }
     return out;
   }
+  // ---- extensions (no reference counterpart): the operator boundary without its two host copies ----
+  // GetResult() whose maps are VIEWS of the page-locked block the device wrote them to (no 4.9 MB copy at 640 x 480).  Valid while the
+  // next CallAsync is processed; overwritten by the one after it.  Delete the object as usual (the arrays are not freed).
+  DrMvsnetOutput *GetResultView() {
+    const float *d, *c, *dd, *cd;
+    check(drm_get_result_view(impl, &d, &c, &dd, &cd));
+    return new DrMvsnetOutput(height_, width_, const_cast<float *>(d), const_cast<float *>(c), const_cast<float *>(dd), const_cast<float *>(cd));
+  }
+  // Page-locked memory for key-frame images: CallAsync uploads windows whose images ALL live in such memory in place, skipping the
+  // gather into the engine's staging block (6.45 MB at 640 x 480 x 7).
+  static unsigned char *AllocImage(size_t bytes) { return static_cast<unsigned char *>(drm_host_alloc(bytes)); }
+  static void FreeImage(unsigned char *p) { drm_host_free(p); }
+
   // Blocking
   void Wait() { check(drm_wait(impl)); }
   // Non-blocking

@@ -28,6 +28,20 @@ int main(int argc, char **argv) {
   mvsnet.CallAsync(H, W, V, ref, bgrs.data(), K, c2ws.data(), sc[0], sc[1], sc[2]);
   DrMvsnetOutput *out = mvsnet.GetResult();
 
+  // the boundary extensions: the same window from page-locked images, the result as a view of the engine's pinned block -- same maps
+  {
+    std::vector<unsigned char *> pb(V);
+    for (int v = 0; v < V; v++) { pb[v] = DrMvsnet::AllocImage((size_t) H * W * 3); if (!pb[v]) return 3; memcpy(pb[v], bgrs[v], (size_t) H * W * 3); }
+    mvsnet.CallAsync(H, W, V, ref, pb.data(), K, c2ws.data(), sc[0], sc[1], sc[2]);
+    for (int v = 0; v < V; v++) memset(pb[v], 0, (size_t) H * W * 3);  // inputs are copied before CallAsync returns
+    DrMvsnetOutput *view = mvsnet.GetResultView();
+    const bool same = !memcmp(view->depth, out->depth, sizeof(float) * H * W) && !memcmp(view->confidence_dense, out->confidence_dense, sizeof(float) * H * W);
+    printf("mvsnet: pinned upload + result view %s the copying path\n", same ? "equal" : "DIFFER FROM");
+    delete view;
+    for (int v = 0; v < V; v++) DrMvsnet::FreeImage(pb[v]);
+    if (!same) return 4;
+  }
+
   DrFusionOptions o;
   o.voxel_size = 0.01f; o.num_buckets = 50000; o.bucket_size = 10; o.num_blocks = 100000; o.block_size = 8; o.max_sdf_weight = 64;
   o.truncation_distance = 0.04f; o.max_sensor_depth = 10.f; o.min_sensor_depth = 0.1f; o.num_render_streams = 1;

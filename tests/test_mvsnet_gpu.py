@@ -523,3 +523,39 @@ def test_winograd_form_stays_inside_the_fp32_bounds(path, trained_blob, tmp_path
     assert not np.array_equal(outs[0].depth_dense, outs[1].depth_dense)
     d = np.abs(outs[0].depth_dense - outs[1].depth_dense)
     assert d.mean() < 2e-5 * (float(g["depth_max"]) - float(g["depth_min"])), d.mean()
+
+
+def test_pinned_upload_and_result_view_equal_the_copying_boundary(trained_blob):
+    """The boundary extensions (include/dr_mi355x.h: drm_host_alloc, drm_get_result_view): a window whose images live in page-locked memory
+    is uploaded in place -- and may be overwritten as soon as CallAsync returns -- and the result comes back as views of the engine's two
+    alternating pinned blocks: bit-identical maps, a view survives exactly one further call."""
+    from synth import scene
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    H, W, V = 128, 160, 4
+    w = scene.make_window(H, W, V, seed=3)
+    args = lambda imgs: (H, W, V, w["ref_index"], imgs, w["K"], list(w["c2ws"]), w["depth_min"], w["depth_max"], 10.0)
+    m = DrMvsnet(trained_blob)
+    m.CallAsync(*args(w["bgrs"]))
+    ref = m.GetResult()
+    pinned = m.alloc_images(V, H, W)
+    for p, b in zip(pinned, w["bgrs"]):
+        p[...] = b
+    m.CallAsync(*args(pinned))
+    for p in pinned:
+        p[...] = 0  # the upload has completed: the caller's buffers are its own again
+    v1 = m.GetResultView()
+    for k in ("depth", "confidence", "depth_dense", "confidence_dense"):
+        assert np.array_equal(getattr(v1, k), getattr(ref, k)), k
+    with pytest.raises(Exception):
+        m.GetResultView()  # one result per call, as GetResult
+    w2 = scene.make_window(H, W, V, seed=4)
+    m.CallAsync(H, W, V, w2["ref_index"], w2["bgrs"], w2["K"], list(w2["c2ws"]), w2["depth_min"], w2["depth_max"], 10.0)
+    v2 = m.GetResultView()
+    assert np.array_equal(v1.depth_dense, ref.depth_dense)      # the first view is still intact after one further call ...
+    assert not np.array_equal(v2.depth_dense, ref.depth_dense)  # ... which went to the other block
+    mixed = [pinned[0]] + list(w["bgrs"][1:])                   # one pageable image: the staging path, same answer
+    pinned[0][...] = w["bgrs"][0]
+    m.CallAsync(*args(mixed))
+    v3 = m.GetResult()
+    assert np.array_equal(v3.depth_dense, ref.depth_dense)
+    m.close()
