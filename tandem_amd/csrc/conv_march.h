@@ -45,6 +45,7 @@ struct MarchArgs {
   int depth;           // loads a producer wave keeps in flight (1: publish every load before issuing the next)
   int inHp;            // rows a plane has inside the tensor (inH, or 1 for the row march)
   int rm;              // row march
+  int wino;            // 1: the y axis in Winograd F(2,3) form (march_consumer_w): a position is a row PAIR, a.sy = 2, the in-plane tap table lists the x taps only
   int *err;            // raised when a wait gave up (nullptr: not reported)
 };
 
@@ -64,7 +65,7 @@ __device__ inline int march_uniform(int v) { return __builtin_amdgcn_readfirstla
 // staged position of output position j of position tile (wave, pt)
 DR_HD inline int march_bpos(const ConvArgs &a, int wave, int pt, int PT, int j) {
   const int tau = wave * PT + pt, xt = tau % a.TXT, yt = tau / a.TXT;
-  return yt * a.TXI + (xt * 16 + j) * a.sx;
+  return yt * a.sy * a.TXI + (xt * 16 + j) * a.sx;  // (a.sy = 1, or 2 in the Winograd form: position tile yt starts at row 2 * yt of the staged plane)
 }
 // column -> tile origin (output positions) and, for 2-D layers, the image the column belongs to
 DR_HD inline void march_tile_origin(const ConvArgs &a, const MarchArgs &m, int col, int &zc, int &py0, int &px0) {
@@ -345,6 +346,182 @@ __device__ inline void march_consumer(const ConvArgs &a, const MarchArgs &m, flo
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The Winograd F(2,3) form of the marching consumer (conv_wino.h has the algebra): a position tile is 16 x by one ROW PAIR, a step
+// computes two output rows per position from the four rows around them with 4 products per (x tap, plane, channel) instead of 6.
+// What makes it fit the marching kernel's LDS budget is that the TRANSFORMED weights are never stored: the ring's weight area holds the
+// raw kernel rows g0, g1 / 2, g2 (the direct form's 36 KB for a 16-channel XPAIR layer -- four transformed fragments would be 48 KB and,
+// with a three-slot ring of 40 KB planes, 172 KB), and every lane derives u1 = (g0 + g2) / 2 + g1 / 2 and u2 = (g0 + g2) / 2 - g1 / 2
+// for its fragment in registers (12 VALU per chunk, beside the 16 of the input transform, under 16 MFMAs = 512 cycles).
+// Weight chunk order inside a section: [chunk of x taps r][kernel row k = 0..2][row tile]; NUP = 3 * NRP as in the direct form.
+template <int NRP, int CT, int PT>
+struct MarchWSet {  // operands of one chunk: three raw weight fragments per row tile, four raw input rows per position tile
+  float4 g[3][CT], d[4][PT];
+};
+template <int NRP, int CT, int PT>
+__device__ inline void march_w_load(const float4 *tile, const float4 *wsec, const int (&sw)[NRP][4][PT], int r, MarchWSet<NRP, CT, PT> &o) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) o.g[k][ct] = wsec[((r * 3 + k) * CT + ct) * 64];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o.d[q][pt] = tile[sw[r][q][pt]];
+}
+template <int NRP, int CT, int PT>
+__device__ inline void march_w_anchor(const MarchWSet<NRP, CT, PT> &o) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) asm volatile("" ::"v"(o.g[k][ct].x), "v"(o.g[k][ct].y), "v"(o.g[k][ct].z), "v"(o.g[k][ct].w));
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) asm volatile("" ::"v"(o.d[q][pt].x), "v"(o.d[q][pt].y), "v"(o.d[q][pt].z), "v"(o.d[q][pt].w));
+}
+DR_HD inline float march_w_u1(float g0, float g1h, float g2) { return fmaf(g0 + g2, 0.5f, g1h); }   // shared with the host emulation
+DR_HD inline float march_w_u2(float g0, float g1h, float g2) { return fmaf(g0 + g2, 0.5f, -g1h); }
+template <int NRP, int CT, int PT>
+__device__ inline void march_w_compute(MarchWSet<NRP, CT, PT> &o, floatx4 (&acc)[4][CT][PT]) {
+  float4 u[4][CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const float4 g0 = o.g[0][ct], gh = o.g[1][ct], g2 = o.g[2][ct];
+    u[0][ct] = g0; u[3][ct] = g2;
+    u[1][ct] = make_float4(march_w_u1(g0.x, gh.x, g2.x), march_w_u1(g0.y, gh.y, g2.y), march_w_u1(g0.z, gh.z, g2.z), march_w_u1(g0.w, gh.w, g2.w));
+    u[2][ct] = make_float4(march_w_u2(g0.x, gh.x, g2.x), march_w_u2(g0.y, gh.y, g2.y), march_w_u2(g0.z, gh.z, g2.z), march_w_u2(g0.w, gh.w, g2.w));
+  }
+  conv_w_transform<PT>(o.d);
+  conv_w_mfma<CT, PT>(u, o.d, acc);
+}
+
+template <int CT, int PT>
+__device__ inline void march_epilogue_w(const ConvArgs &a, const MarchArgs &m, floatx4 (&acc)[4][CT][PT], const float4 (&scv)[CT], const float4 (&biv)[CT], int raw,
+                                        int wave, int j, int g, int ct0, int zc, int z, int py0, int px0) {
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const int tau = wave * PT + pt;
+    const int xt = tau % a.TXT, yt = tau / a.TXT;
+    const int qy = py0 + yt, qx = px0 + xt * 16 + j;
+    if (qy >= a.nPH || qx >= a.nPW) continue;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int c0 = (ct0 + ct) * 16 + 4 * g;
+      if (c0 >= a.rows_valid) continue;
+      const floatx4 m0 = acc[0][ct][pt], m1 = acc[1][ct][pt], m2 = acc[2][ct][pt], m3 = acc[3][ct][pt];
+      const floatx4 o[2] = {(m0 + m1) + m2, (m1 - m2) - m3};
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int oy = 2 * qy + r;
+        const size_t obase = march_out_index(a, m, zc, z, oy, qx, c0);
+        float4 v = make_float4(o[r][0], o[r][1], o[r][2], o[r][3]);
+        if (raw == 2) {
+          const float4 p = *reinterpret_cast<const float4 *>(a.out + obase);
+          v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        if (raw != 1) {
+          const float4 sc = scv[ct], bi = biv[ct];
+          v.x = v.x * sc.x + bi.x; v.y = v.y * sc.y + bi.y; v.z = v.z * sc.z + bi.z; v.w = v.w * sc.w + bi.w;
+          if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          if (a.add_mode) {
+            size_t abase = obase;
+            if (a.add_mode == 2) abase = (((size_t)(zc + z) * a.addH + (oy >> 1)) * a.addW + (qx >> 1)) * a.outC + c0;
+            const float4 p = *reinterpret_cast<const float4 *>(a.add + abase);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+          }
+        }
+        *reinterpret_cast<float4 *>(a.out + obase) = v;
+      }
+    }
+  }
+}
+
+// 3-D layers only (KZ = 3, one channel slice per plane: NPI = 1).  The sections of a step that exist (planes inside the volume) are a
+// contiguous range [lo, hi); their chunks run as ONE software pipeline (operands of the next chunk, of this or the next section, fetched
+// under the MFMAs of the current one), every index a compile-time constant so that the two operand sets stay in registers.
+template <int CI, int NUP, int CT, int PT, int NPW>
+__device__ inline void march_consumer_w(const ConvArgs &a, const MarchArgs &m, float4 *lds4, march_flag_t *flags, const float4 *wl, int wave, int lane,
+                                        int s0, int s1) {
+  static_assert(NUP % 3 == 0, "three kernel rows per chunk of x taps");
+  constexpr int TPC = 16 / CI, NRP = NUP / 3;
+  const int j = lane & 15, g = lane >> 4;
+  const int sub = (4 * g) / CI, c4 = ((4 * g) % CI) / 4, ct0 = blockIdx.z * CT;
+  int sw[NRP][4][PT];  // swizzled 16-byte slot of this lane's operand: chunk of x taps, row of the pair's four-row window, position tile
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const int bpos = march_bpos(a, wave, pt, PT, j);
+#pragma unroll
+    for (int r = 0; r < NRP; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        sw[r][q][pt] = conv_a_unit<CI>(bpos + m.tap2d[r * TPC + sub] + q * a.TXI, c4);
+        asm volatile("" : "+v"(sw[r][q][pt]));
+      }
+  }
+  float4 scv[CT], biv[CT];
+  conv_load_affine<CT>(a, g, ct0, scv, biv);
+  const float4 *wp = wl + lane;
+  const int R = m.R, Dc = m.geo.Dc;
+  int cached = 0, L = 0;
+  for (int po = 0; po < m.NPO; ++po) {
+    const int raw = m.NPO == 1 ? 0 : (po == 0 ? 1 : 2);
+    for (int s = s0; s < s1;) {
+      const MarchSeg sg = march_segment(m.geo, s, s1);
+      int zc, py0, px0;
+      march_tile_origin(a, m, sg.col, zc, py0, px0);
+      MarchCursor cur;
+      cur.begin(m.geo, sg, L, R);
+      for (int z = sg.za; z < sg.zb; ++z) {
+        floatx4 acc[4][CT][PT];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) acc[p][ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
+        const int lo = z > 0 ? 0 : 1, hi = z < Dc - 1 ? 3 : 2, nsec = hi - lo;  // planes z - 1 + dz inside the volume
+        const int idx0 = L + cur.rel0;                                          // load index of section dz = 0 (whether it exists or not)
+        if (!march_wait_ready<NPW>(flags, idx0 + hi - 1, cached, m.err, lane)) return;  // loads are published in order
+        asm volatile("" ::: "memory");
+        const bool last = z == sg.zb - 1;
+        auto tile_of = [&](int i) {  // ring slot of the i-th existing section
+          int sl = cur.slot0 + lo + i;
+          sl = sl >= R ? sl - R : sl;
+          return (const float4 *)(lds4 + (size_t)sl * m.PS);
+        };
+        auto wsec_of = [&](int i) { return wp + (size_t)(lo + i) * m.wsec; };
+        MarchWSet<NRP, CT, PT> set[2];
+        march_w_load<NRP, CT, PT>(tile_of(0), wsec_of(0), sw, 0, set[0]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          if (i < nsec) {
+#pragma unroll
+            for (int r = 0; r < NRP; ++r) {
+              const int t = i * NRP + r;  // compile-time: the sets alternate
+              if (r + 1 < NRP) march_w_load<NRP, CT, PT>(tile_of(i), wsec_of(i), sw, r + 1, set[(t + 1) & 1]);
+              else if (i + 1 < nsec) march_w_load<NRP, CT, PT>(tile_of(i + 1), wsec_of(i + 1), sw, 0, set[(t + 1) & 1]);
+              __builtin_amdgcn_sched_barrier(0);
+              march_w_compute<NRP, CT, PT>(set[t & 1], acc);
+              __builtin_amdgcn_sched_barrier(0);
+              if (r + 1 < NRP || i + 1 < nsec) march_w_anchor<NRP, CT, PT>(set[(t + 1) & 1]);
+              // every read of section i has returned here (its last chunk's operands were anchored one chunk ago): release its slot if no later step reads it
+              if (r == NRP - 1 && (lo + i == 0 || last)) {
+                asm volatile("" ::: "memory");
+                if (lane == 0) flags[kMarchReleased + wave] = idx0 + lo + i + 1;
+              }
+            }
+          }
+        }
+        march_epilogue_w<CT, PT>(a, m, acc, scv, biv, raw, wave, j, g, ct0, zc, z, py0, px0);
+        cur.next_step(m.geo, R);
+      }
+      L += sg.nl;
+      s += sg.zb - sg.za;
+    }
+  }
+}
+
 // Producer wave pw of kMarchProducers: takes DMA pieces pw, pw + 2, ... of every plane and of the weights.
 // Up to m.depth loads of the wave are in flight: after issuing the pieces of load i it waits only until the pieces of load
 // i - depth + 1 have landed (s_waitcnt vmcnt(in flight behind it); a wave's loads return in order) and publishes THAT one.  Small planes
@@ -502,7 +679,7 @@ __device__ inline void march_producer_fz(const ConvArgs &a, const MarchArgs &m, 
 }
 
 // grid = (persistent workgroups (multiple of 8), 1, output-row groups); 8 consumer waves + 2 (DMA) or 4 (fused skip) producer waves.
-template <int CI, int NUP, int CT, int PT, int FZ = 0, int NCW = 8>
+template <int CI, int NUP, int CT, int PT, int FZ = 0, int NCW = 8, int W = 0>
 __global__ __launch_bounds__(64 * (NCW + (FZ ? kMarchFzProducers : kMarchProducers))) void k_conv_m(const ConvArgs a, const MarchArgs m) {
   extern __shared__ float4 lds4[];
   const int tid = threadIdx.x, lane = tid & 63, wave = march_uniform(tid >> 6);
@@ -516,7 +693,10 @@ __global__ __launch_bounds__(64 * (NCW + (FZ ? kMarchFzProducers : kMarchProduce
   int s0, s1;
   march_range(m.steps, id, nwg, s0, s1);
   if (s0 >= s1) return;
-  if (wave < NCW) march_consumer<CI, NUP, CT, PT, (FZ ? kMarchFzProducers : kMarchProducers)>(a, m, lds4, flags, wl, wave, lane, s0, s1);
+  if (wave < NCW) {
+    if constexpr (W) march_consumer_w<CI, NUP, CT, PT, kMarchProducers>(a, m, lds4, flags, wl, wave, lane, s0, s1);
+    else march_consumer<CI, NUP, CT, PT, (FZ ? kMarchFzProducers : kMarchProducers)>(a, m, lds4, flags, wl, wave, lane, s0, s1);
+  }
   else if constexpr (FZ > 0) march_producer_fz<FZ>(a, m, lds4, flags, wl, wave - NCW, lane, s0, s1, NUP, CT);
   else march_producer<CI>(a, m, lds4, flags, wl, wave - NCW, lane, s0, s1, NUP, CT);
 }

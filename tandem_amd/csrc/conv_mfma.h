@@ -644,8 +644,11 @@ __global__ __launch_bounds__(kConvAThreads) void k_conv_a(const ConvArgs a) {
 }
 
 }  // namespace dr
-#include "conv_march.h"  // k_conv_m: marching producer/consumer kernel for the stride-1 3x3 / 3x3x3 layers
 #include "conv_wino.h"   // k_conv_w: k_conv with the y axis of a 3-tap stride-1 layer in Winograd F(2,3) form (two thirds of the MFMAs)
+namespace dr {
+template <int CI> __host__ __device__ inline int conv_a_unit(int pos, int c4);
+}
+#include "conv_march.h"  // k_conv_m: marching producer/consumer kernel for the stride-1 3x3 / 3x3x3 layers (and their Winograd form)
 namespace dr {
 
 // ------------------------------------------------------------------------------------------------
@@ -796,8 +799,11 @@ inline bool conv_a_instance_exists(int ci, int ct, int pt) {  // PT = 1 (round 4
   X(16, 4, 1, 1, 8) X(16, 4, 1, 2, 8) X(16, 4, 1, 4, 8) X(16, 4, 1, 1, 10) X(16, 4, 1, 2, 10)                         \
   X(16, 3, 1, 1, 8) X(16, 3, 1, 2, 8) X(16, 3, 1, 4, 8) X(16, 3, 1, 1, 10) X(16, 3, 1, 2, 10)                         \
   X(16, 3, 2, 1, 8) X(16, 3, 2, 2, 8) X(16, 3, 2, 1, 10) X(16, 3, 2, 2, 10)
-inline bool conv_m_instance_exists(int ci, int nup, int ct, int pt, int ncw) {
+// the Winograd form of the 3-D instances (march_consumer_w): one position tile (16 x by a row pair) per wave
+#define DR_MARCH_W_INSTANCES(X) X(8, 6, 1, 1, 8) X(16, 12, 1, 1, 8) X(16, 9, 1, 1, 8)  // (twelve consumer waves leave 128 registers: the two operand sets spill)
+inline bool conv_m_instance_exists(int ci, int nup, int ct, int pt, int ncw, bool wino = false) {
 #define DR_X(CI_, NUP_, CT_, PT_, NCW_) if (ci == CI_ && nup == NUP_ && ct == CT_ && pt == PT_ && ncw == NCW_) return true;
+  if (wino) { DR_MARCH_W_INSTANCES(DR_X) return false; }
   DR_MARCH_INSTANCES(DR_X)
 #undef DR_X
   return false;
@@ -820,18 +826,19 @@ struct MarchShape {  // derived geometry of a k_conv_m candidate
   bool ok;
 };
 // rm (row march of a 2-D layer): KZ is the layer's kd (1), ntp the x taps of ONE row, nPD the images, nPH the rows; ty must be 1.
+// wino (march_consumer_w; KZ = 3 only): ty counts row PAIRS, nPH the pairs of the layer, ntp the taps of one plane as the DIRECT form has them (3 rows x the x taps)
 inline MarchShape march_shape(int KZ, int ntp, int Cin, int ci, int ct, int pt, int ty, int txt, int SX, int exy, int exx, int nPD, int nPH, int nPW, int CTtot,
-                              bool rm = false) {
+                              bool rm = false, bool wino = false) {
   MarchShape m{};
   const int tpc = 16 / ci;
-  if (Cin % ci || ntp % tpc || CTtot % ct || (ty * txt) % pt || (rm && (ty != 1 || KZ != 1))) return m;
+  if (Cin % ci || ntp % tpc || CTtot % ct || (ty * txt) % pt || (rm && (ty != 1 || KZ != 1)) || (wino && (KZ != 3 || rm || (ntp / 3) % tpc))) return m;
   m.ncw = ty * txt / pt;  // one wave per PT position tiles
-  m.nup = ntp / tpc;
-  if (!conv_m_instance_exists(ci, m.nup, ct, pt, m.ncw)) return m;
+  m.nup = ntp / tpc;      // (Winograd form: the same count -- three raw kernel rows per chunk of x taps)
+  if (!conv_m_instance_exists(ci, m.nup, ct, pt, m.ncw, wino)) return m;
   const int npass = Cin / ci, kz = rm ? 3 : KZ;
   if (npass > 2) return m;
   m.npi = KZ == 1 ? npass : 1; m.npo = KZ == 1 ? 1 : npass; m.ns = kz * m.npi;
-  m.tyi = rm ? 1 : ty - 1 + exy; m.txi = (txt * 16 - 1) * SX + exx; m.np = m.tyi * m.txi;
+  m.tyi = rm ? 1 : (wino ? 2 * ty + 2 : ty - 1 + exy); m.txi = (txt * 16 - 1) * SX + exx; m.np = m.tyi * m.txi;
   if (m.np >= 65536) return m;
   m.ps = cdiv(((m.np + 15) & ~15) * (ci / 4), 128) * 128;
   if (m.ps / 128 > kMarchMaxIt) return m;
@@ -1036,6 +1043,28 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
         }
     }
   }
+  // the Winograd form of the marching kernel (async = 5): 3-D layers, even output height; ty counts row pairs
+  const int wino_policy_m = (!fz && !bf3) ? conv_wino_policy() : 0;
+  if (march_ok && wino_policy_m >= 1 && L.kd == 3 && (R.outH & 1) == 0 && R.outH >= 2) {
+    const int nPHw = R.outH / 2;
+    for (int ci : {16, 8}) {
+      if (ci == 8 && L.Cin != 8) continue;
+      for (int ncw : {8})
+        for (int ty = 1; ty <= ncw; ++ty) {
+          if (ncw % ty) continue;
+          const int txt = ncw / ty;
+          if ((ty > 1 && ty / 2 >= nPHw) || (txt > 1 && (txt / 2) * 16 >= nPW)) continue;
+          const MarchShape ms = march_shape(L.kd, march_ntp, L.Cin, ci, 1, 1, ty, txt, SX, exy, exx, nPD, nPHw, nPW, CTtot, false, true);
+          if (!ms.ok) continue;
+          const double spw = std::ceil((double)ms.steps / ms.grid);
+          const double unit = ms.ns * (ms.nup / 3) * 16.0 * 32.0 * (ncw / 4) * (ncw == 12 ? 0.94 : 1.0);  // MFMA cycles of a step per SIMD: 16 per chunk of x taps and section
+          const double startup = (double)ms.lds_bytes / 16.0 + 3000.0;
+          double cost = ms.npo * (spw * unit * 1.1 + startup);
+          if (wino_policy_m >= 2) cost *= 1e-3 * 0.5;  // (preferred: ahead of k_conv_w's candidates as well)
+          cands.push_back({cost, ci, 1, 1, 1, ty, txt, L.kd, ms.tyi, ms.txi, 5});
+        }
+    }
+  }
   // the row march: 2-D 3x3 stride-1 layers on the same kernel, marching down the rows of each image (async = 3)
   const bool rowmarch_ok = !fz && !bf3 && conv_rowmarch_policy() >= 1 && ncls == 1 && !L.transposed && !L.up2 && mode != CONV_X8 && L.kd == 1 && L.kh == 3 && L.kw == 3 &&
                            SZ == 1 && SY == 1 && L.sw == 1 && !add;
@@ -1163,7 +1192,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   }
   if (!CI) fail(DR_ERR_ARG, "plan_conv: no kernel instance / tile shape for Cin=%d Cout=%d", L.Cin, L.Cout);
   const int npass = L.Cin / CI, TPC = (bf3 ? 32 : 16) / CI, CIS = CI + 4;
-  const bool wino = ASYNC == 4;
+  const bool wino = ASYNC == 4 || ASYNC == 5, wino_raw = ASYNC == 5;  // 5: the marching kernel derives the transformed weights itself (raw rows g0, g1 / 2, g2)
   if (wino) {  // the y axis as k_conv_w sees it: positions are row pairs, the tap table carries row 0 only (the kernel adds rows 1..3 itself)
     DimTaps &Y = cy[0];
     Y.t = {0}; Y.off = {0}; Y.s = 2; Y.p = 1; Y.om = 2; Y.oo = 0; Y.npos = R.outH / 2;
@@ -1191,7 +1220,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   for (int ic = 0; ic < ncls; ++ic) {
     const DimTaps &Z = *classes[ic].z, &Y = *classes[ic].y, &X = *classes[ic].x;
     const int ntz = (int)Z.t.size(), nty = (int)Y.t.size(), ntx = (int)X.t.size(), ntaps = classes[ic].ntaps;
-    const int NR = cdiv(ntaps, TPC), NU = wino ? 4 * NR : NR;  // k_conv_w: four weight chunks (one per Winograd point) per chunk of taps
+    const int NR = cdiv(ntaps, TPC), NU = wino_raw ? 3 * NR : (wino ? 4 * NR : NR);  // k_conv_w: four weight chunks (one per Winograd point) per chunk of taps; marching form: three (the raw kernel rows)
     cls[ic].NU = NU; cls[ic].tap_base = (int)tapoff.size(); cls[ic].w_base = (int)(pk.size() / 4);
     cls[ic].ooz = Z.oo; cls[ic].ooy = Y.oo; cls[ic].oox = X.oo;
     std::vector<int> tz(ntaps), ty(ntaps), tx(ntaps);
@@ -1248,6 +1277,12 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
           pb[((frag + 0) * 64 + l) * 8 + s] = hi;
           pb[((frag + 1) * 64 + l) * 8 + s] = lo;
         }
+    } else if (wino_raw) {  // [pass][chunk of taps][kernel row k][row tile][lane]: g0, g1 / 2, g2 (march_consumer_w forms u1, u2 from them)
+      for (int p = 0; p < npass; ++p) for (int u = 0; u < NR; ++u) for (int k = 0; k < 3; ++k) for (int ct = 0; ct < CTtot; ++ct)
+        for (int l = 0; l < 64; ++l) for (int s = 0; s < 4; ++s) {
+          const int g = l >> 4, i = l & 15, k16 = 4 * g + s;
+          pk[w0 + ((((size_t)p * NU + u * 3 + k) * CTtot + ct) * 64 + l) * 4 + s] = (k == 1 ? 0.5f : 1.f) * weight_of(u * TPC + k16 / CI, p * CI + k16 % CI, ct * 16 + i, k);
+        }
     } else if (wino) {  // [pass][chunk of taps][point][row tile][lane]: u_p = sum_ky G[p][ky] w[ky], formed in double, rounded once
       for (int p = 0; p < npass; ++p) for (int u = 0; u < NR; ++u) for (int pp = 0; pp < 4; ++pp) for (int ct = 0; ct < CTtot; ++ct)
         for (int l = 0; l < 64; ++l) for (int s = 0; s < 4; ++s) {
@@ -1303,7 +1338,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   cl.lds_bytes = (size_t)TZI * TYI * TXI * CIS * 4 + (size_t)nu_max * CT * (bf3 ? 2048 : 1024) + (size_t)nu_max * TPC * 4 + 64;
   cl.bf3 = bf3 ? 1 : 0;
   a.zero16 = nullptr; a.a_slots = 0; a.a_wbufs = 1;
-  if (wino) cl.async = 4;  // (k_conv's LDS layout and grid: the tile, nuMax weight chunks, the tap table)
+  if (ASYNC == 4) cl.async = 4;  // (k_conv's LDS layout and grid: the tile, nuMax weight chunks, the tap table)
   if (ASYNC == 1) {
     cl.async = 1;
     a.zero16 = arena.upload(std::vector<float>(4, 0.f));
@@ -1319,10 +1354,10 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
     const int want = std::max(1, std::min(ntiles, 256 * wpc / split));
     cl.grid = dim3(8 * cdiv(want, 8), 1, split);
   }
-  if (ASYNC == 2 || ASYNC == 3) {
+  if (ASYNC == 2 || ASYNC == 3 || ASYNC == 5) {
     const bool rm = ASYNC == 3;
     const MarchShape ms = rm ? march_shape(L.kd, row_ntp, L.Cin, CI, CT, PT, 1, TXT, SX, exy, exx, nPD, nPH, nPW, CTtot, true)
-                             : march_shape(L.kd, march_ntp, L.Cin, CI, CT, PT, TY, TXT, SX, exy, exx, nPD, nPH, nPW, CTtot);
+                             : march_shape(L.kd, march_ntp, L.Cin, CI, CT, PT, TY, TXT, SX, exy, exx, nPD, nPH, nPW, CTtot, false, wino_raw);
     if (!ms.ok) fail(DR_ERR_ARG, "plan_conv: inconsistent k_conv_m plan");
     cl.async = 2; cl.nup = ms.nup; cl.ncw = ms.ncw;
     a.zero16 = arena.upload(std::vector<float>(4, 0.f));
@@ -1346,6 +1381,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
     m.steps = (int)ms.steps;
     m.ncw = ms.ncw;
     m.rm = rm ? 1 : 0;
+    m.wino = wino_raw ? 1 : 0;
     const long long iplane = (long long)a.inH * a.inW * a.inC, oplane = (long long)a.outH * a.outW * a.outC;
     if (iplane * std::max(1, a.inD) >= (1ll << 31) || oplane * std::max(1, a.outD) >= (1ll << 31)) fail(DR_ERR_ARG, "plan_conv: tensor too large for k_conv_m's 32-bit strides");
     m.i_sv = L.kd == 3 ? 0 : (int)iplane; m.i_sz = rm ? a.inW * a.inC : (L.kd == 3 ? (int)iplane : 0); m.i_sy = rm ? 0 : a.inW * a.inC;
@@ -1396,11 +1432,11 @@ inline void launch_conv_w_inst(const ConvLaunch &c, hipStream_t st) {
   conv_allow_big_lds(reinterpret_cast<const void *>(&k_conv_w<CI, CT, PT>), done, c.lds_bytes);
   hipLaunchKernelGGL((k_conv_w<CI, CT, PT>), c.grid, dim3(kConvThreads), c.lds_bytes, st, c.args);
 }
-template <int CI, int NUP, int CT, int PT, int FZ = 0, int NCW = 8>
+template <int CI, int NUP, int CT, int PT, int FZ = 0, int NCW = 8, int W = 0>
 inline void launch_conv_m_inst(const ConvLaunch &c, hipStream_t st) {
   static std::atomic<unsigned long long> done{0};
-  conv_allow_big_lds(reinterpret_cast<const void *>(&k_conv_m<CI, NUP, CT, PT, FZ, NCW>), done, c.lds_bytes);
-  hipLaunchKernelGGL((k_conv_m<CI, NUP, CT, PT, FZ, NCW>), c.grid, dim3(64 * (NCW + (FZ ? kMarchFzProducers : kMarchProducers))), c.lds_bytes, st, c.args, c.march);
+  conv_allow_big_lds(reinterpret_cast<const void *>(&k_conv_m<CI, NUP, CT, PT, FZ, NCW, W>), done, c.lds_bytes);
+  hipLaunchKernelGGL((k_conv_m<CI, NUP, CT, PT, FZ, NCW, W>), c.grid, dim3(64 * (NCW + (FZ ? kMarchFzProducers : kMarchProducers))), c.lds_bytes, st, c.args, c.march);
 }
 inline void launch_conv(const ConvLaunch &c, hipStream_t st) {
   if (c.bf3) {
@@ -1429,6 +1465,13 @@ inline void launch_conv(const ConvLaunch &c, hipStream_t st) {
     return;
   }
 #endif
+  if (c.async == 2 && c.march.wino) {
+#define DR_X(CI_, NUP_, CT_, PT_, NCW_) \
+  if (c.ci == CI_ && c.nup == NUP_ && c.ct == CT_ && c.pt == PT_ && c.ncw == NCW_) { launch_conv_m_inst<CI_, NUP_, CT_, PT_, 0, NCW_, 1>(c, st); return; }
+    DR_MARCH_W_INSTANCES(DR_X)
+#undef DR_X
+    fail(DR_ERR_ARG, "launch_conv: no Winograd marching instance CI=%d NUP=%d CT=%d PT=%d waves=%d", c.ci, c.nup, c.ct, c.pt, c.ncw);
+  }
   if (c.async == 2) {
 #define DR_X(CI_, NUP_, CT_, PT_, NCW_) \
   if (c.ci == CI_ && c.nup == NUP_ && c.ct == CT_ && c.pt == PT_ && c.ncw == NCW_) { launch_conv_m_inst<CI_, NUP_, CT_, PT_, 0, NCW_>(c, st); return; }

@@ -85,7 +85,10 @@ static bool emulate(const ConvLaunch &c, const float *in, float *out, const floa
           MarchCursor cur;  // the kernel's division-free bookkeeping, checked against march_section_load
           cur.begin(m.geo, sg, L, m.R);
           for (int z = sg.za; z < sg.zb; cur.next_step(m.geo, m.R), ++z) {
-            std::vector<float> acc((size_t)m.ncw * CT * PT * 64 * 4, 0.f);
+            const bool W = m.wino != 0;  // march_consumer_w: four accumulator planes (one per Winograd point), chunks of x taps with three raw kernel rows each
+            const int NRP = NUP / 3;
+            std::vector<float> acc((size_t)(W ? 4 : 1) * m.ncw * CT * PT * 64 * 4, 0.f);
+            const size_t pstride = (size_t)m.ncw * CT * PT * 64 * 4;
             for (int sec = 0; sec < NS; ++sec) {
               const int rel = march_section_load(m.geo, sg, z, sec);
               if (rel < 0) continue;
@@ -94,6 +97,38 @@ static bool emulate(const ConvLaunch &c, const float *in, float *out, const floa
               if (idx - Lpass >= (int)loads.size()) { printf("emul: section reads load %d beyond the producer's list\n", idx); return false; }
               while (loaded <= idx) { if (!do_load(loaded)) return false; ++loaded; }
               if (idx < released) { printf("emul: section reads load %d after releasing it\n", idx); return false; }
+              if (W) {
+                for (int wave = 0; wave < m.ncw; ++wave)
+                  for (int r = 0; r < NRP; ++r)
+                    for (int ct = 0; ct < CT; ++ct)
+                      for (int pt = 0; pt < PT; ++pt) {
+                        F4 u[4][64], v[4][64];
+                        for (int lane = 0; lane < 64; ++lane) {
+                          const int j = lane & 15, g = lane >> 4, sub = (4 * g) / CI, c4 = ((4 * g) % CI) / 4;
+                          F4 gk[3], d[4];
+                          for (int k = 0; k < 3; ++k) gk[k] = wl[(size_t)sec * m.wsec + (size_t)((r * 3 + k) * CT + ct) * 64 + lane];
+                          for (int q = 0; q < 4; ++q) {
+                            const int slot = conv_a_unit<CI>(march_bpos(a, wave, pt, PT, j) + m.tap2d[r * TPC + sub] + q * a.TXI, c4);
+                            if (slot < 0 || slot >= m.PS) { printf("emul: operand slot %d outside the plane (%d slots)\n", slot, m.PS); return false; }
+                            d[q] = ring[(size_t)(idx % m.R) * m.PS + slot];
+                          }
+                          for (int e = 0; e < 4; ++e) {
+                            u[0][lane].v[e] = gk[0].v[e]; u[3][lane].v[e] = gk[2].v[e];
+                            u[1][lane].v[e] = march_w_u1(gk[0].v[e], gk[1].v[e], gk[2].v[e]);
+                            u[2][lane].v[e] = march_w_u2(gk[0].v[e], gk[1].v[e], gk[2].v[e]);
+                            v[0][lane].v[e] = d[0].v[e] - d[2].v[e]; v[1][lane].v[e] = d[1].v[e] + d[2].v[e];
+                            v[2][lane].v[e] = d[2].v[e] - d[1].v[e]; v[3][lane].v[e] = d[1].v[e] - d[3].v[e];
+                          }
+                        }
+                        for (int pp = 0; pp < 4; ++pp)
+                          for (int col = 0; col < 16; ++col)
+                            for (int row = 0; row < 16; ++row) {
+                              float &dd = acc[pp * pstride + ((((size_t)wave * CT + ct) * PT + pt) * 64 + ((row >> 2) * 16 + col)) * 4 + (row & 3)];
+                              for (int sidx = 0; sidx < 4; ++sidx)
+                                for (int g = 0; g < 4; ++g) dd = std::fmaf(u[pp][g * 16 + row].v[sidx], v[pp][g * 16 + col].v[sidx], dd);
+                            }
+                      }
+              } else
               for (int wave = 0; wave < m.ncw; ++wave)
                 for (int u = 0; u < NUP; ++u)
                   for (int ct = 0; ct < CT; ++ct)
@@ -129,9 +164,12 @@ static bool emulate(const ConvLaunch &c, const float *in, float *out, const floa
                   for (int ct = 0; ct < CT; ++ct) {
                     const int c0 = (ct0 + ct) * 16 + 4 * g;
                     if (c0 >= a.rows_valid) continue;
-                    const size_t ob = march_out_index(a, m, zc, z, qy, qx, c0);
+                    for (int ro = 0; ro < (W ? 2 : 1); ++ro) {
+                    const size_t ob = march_out_index(a, m, zc, z, W ? 2 * qy + ro : qy, qx, c0);
                     for (int r = 0; r < 4; ++r) {
-                      float v = acc[((((size_t)wave * CT + ct) * PT + pt) * 64 + lane) * 4 + r];
+                      const size_t ai = ((((size_t)wave * CT + ct) * PT + pt) * 64 + lane) * 4 + r;
+                      float v = acc[ai];
+                      if (W) v = ro == 0 ? (acc[ai] + acc[pstride + ai]) + acc[2 * pstride + ai] : (acc[pstride + ai] - acc[2 * pstride + ai]) - acc[3 * pstride + ai];
                       if (raw == 2) v += out[ob + r];
                       if (raw != 1) {
                         v = v * a.scale[c0 + r] + a.bias[c0 + r];
@@ -139,6 +177,7 @@ static bool emulate(const ConvLaunch &c, const float *in, float *out, const floa
                         if (a.add_mode == 1) v += add[ob + r];
                       }
                       out[ob + r] = v;
+                    }
                     }
                   }
                 }
@@ -198,7 +237,7 @@ static int run_case(const Case &cs, int max_plans) {
     double worst = 0;
     for (size_t i = 0; i < on; ++i) worst = std::max(worst, (double)std::fabs(out[i] - ref[i]) / (1.0 + std::fabs(ref[i])));
     const bool pass = ok && worst < 2e-5;
-    printf("%-22s plan %s w=%d ci=%d nup=%d ct=%d pt=%d tile %dx%d R=%d PS=%d NPI=%d NPO=%d grid %ux%u steps %d: %s (max rel err %.2e)\n", cs.name, c.march.rm ? "rows" : "tile", c.ncw, c.ci, c.nup, c.ct, c.pt,
+    printf("%-22s plan %s w=%d ci=%d nup=%d ct=%d pt=%d tile %dx%d R=%d PS=%d NPI=%d NPO=%d grid %ux%u steps %d: %s (max rel err %.2e)\n", cs.name, c.march.rm ? "rows" : (c.march.wino ? "wino" : "tile"), c.ncw, c.ci, c.nup, c.ct, c.pt,
            c.args.TY, c.args.TXT * 16, c.march.R, c.march.PS, c.march.geo.NPI, c.march.NPO, c.grid.x, c.grid.z, c.march.steps, pass ? "ok" : "FAIL", worst);
     ++done;
     if (!pass) ++fails;
@@ -210,6 +249,7 @@ static int run_case(const Case &cs, int max_plans) {
 int main(int argc, char **argv) {
   setenv("DR_CONV_MARCH", "2", 1);  // marching candidates first in the planner's ranking
   setenv("DR_CONV_ROWMARCH", "2", 1);
+  if (argc > 2 && !strcmp(argv[2], "wino")) setenv("DR_CONV_WINO", "2", 1);  // the Winograd form of the 3-D march first (march_consumer_w)
   const int max_plans = argc > 1 ? atoi(argv[1]) : 3;
   const Case cases[] = {
       {"xpair3d_c16", 5, 20, 40, 16, 8, 3, true, false},   // s2.conv0's type

@@ -198,7 +198,31 @@ def test_winograd_kernel_candidates(case, monkeypatch, capfd):
         monkeypatch.setenv("DR_CONV_RANK", str(rank))
         run_case(case)
         kinds += [l.split()[1].split("<")[0] for l in capfd.readouterr().err.splitlines() if l.startswith("debug_conv:")]
-    assert kinds and kinds[0] == "wino" and kinds.count("wino") >= 4, kinds
+    assert kinds and kinds[0] in ("wino", "winomarch") and kinds.count("wino") >= 4, kinds  # (3-D layers: the marching form's candidates lead)
+
+
+# ---- the same form on the marching kernel (conv_march.h march_consumer_w: raw kernel rows in LDS, u1 / u2 derived per lane): 3-D layers,
+# shapes with several steps per workgroup, two outer channel passes (raw partial sums), odd depth, ragged width
+WINO_MARCH = [
+    ("winomarch xpair 3x3x3 16->8", (20, 96, 160), 16, 8, (3, 3, 3), (1, 1, 1), False, True, "none"),
+    ("winomarch xpair 3x3x3 32->8 (two outer passes)", (12, 64, 128), 32, 8, (3, 3, 3), (1, 1, 1), False, True, "none"),
+    ("winomarch xpair 3x3x3 8->8", (8, 128, 256), 8, 8, (3, 3, 3), (1, 1, 1), False, True, "none"),
+    ("winomarch 3x3x3 16->16 +skip", (16, 64, 96), 16, 16, (3, 3, 3), (1, 1, 1), False, True, "same"),
+    ("winomarch ragged 3x3x3 16->8", (5, 36, 70), 16, 8, (3, 3, 3), (1, 1, 1), False, True, "none"),
+    ("winomarch two planes 3x3x3 8->8", (2, 60, 96), 8, 8, (3, 3, 3), (1, 1, 1), False, True, "none"),
+]
+
+
+@pytest.mark.parametrize("case", WINO_MARCH, ids=[c[0] for c in WINO_MARCH])
+def test_winograd_marching_candidates(case, monkeypatch, capfd):
+    monkeypatch.setenv("DR_CONV_WINO", "2")
+    monkeypatch.setenv("DR_CONV_PRINT", "1")
+    kinds = []
+    for rank in range(6):
+        monkeypatch.setenv("DR_CONV_RANK", str(rank))
+        run_case(case)
+        kinds += [l.split()[1].split("<")[0] for l in capfd.readouterr().err.splitlines() if l.startswith("debug_conv:")]
+    assert kinds and kinds[0] == "winomarch", kinds
 
 
 def test_winograd_form_is_not_planned_where_it_does_not_apply(monkeypatch, capfd):
