@@ -1175,7 +1175,8 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   }
   if (!cands.empty()) {
     std::stable_sort(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) { return a.cost < b.cost; });
-    if (rank == 0 && !getenv("DR_CONV_NO_TUNED")) {  // a measured plan for exactly this layer moves to the front
+    if (!getenv("DR_CONV_NO_TUNED")) {  // a measured plan for exactly this layer swaps places with the cost model's first choice -- for EVERY rank, so that the
+                                        // ranks stay a permutation of the candidates (the autotuner used to never time the model's own first choice of a tuned layer)
       for (const ConvTuned &t : kConvTuned) {
         if (t.Cin != L.Cin || t.Cout != L.Cout || t.kd != L.kd || t.kh != L.kh || t.kw != L.kw || t.sd != L.sd || t.sh != L.sh || t.sw != L.sw ||
             t.transposed != (L.transposed ? 1 : (L.up2 ? 1 + L.up2 : 0)) || t.mode != (int)mode || t.inD != inD || t.inH != inH || t.inW != inW) continue;
