@@ -1105,8 +1105,7 @@ class MvsEngine {
           break;
         }
         case Op::EDGE:
-          hipLaunchKernelGGL(k_filter_init, dim3(1), dim3(64), 0, stream_, d_state_, filter_rank_);
-          hipLaunchKernelGGL(k_edge, dim3(cdiv(H_ * W_, 256)), dim3(256), 0, stream_, T("depth3").d, T("edge").d, H_, W_);
+          hipLaunchKernelGGL(k_edge, dim3(cdiv(H_ * W_, 256)), dim3(256), 0, stream_, T("depth3").d, T("edge").d, H_, W_, d_state_, filter_rank_);
           break;
         case Op::HIST:
           hipLaunchKernelGGL(k_hist, dim3(std::min(cdiv(H_ * W_, 256), sw_.hist_blocks)), dim3(256), 0, stream_, T("edge").d, H_ * W_, o.shift, o.bits, d_state_, d_hist_);
