@@ -83,28 +83,46 @@ __device__ inline void conv_load_affine(const ConvArgs &a, int g, int ct0, float
     bi[ct] = *reinterpret_cast<const float4 *>(a.bias + (ct0 + ct) * 16 + 4 * g);
   }
 }
+// The residual / upsample-add operand is FETCHED FOR A GROUP OF UP TO FOUR (position tile, row tile) entries before the first store of the
+// group: `add` and `out` may alias (the folded stage-3 head adds in place), so hipcc keeps every load behind the store before it, and the
+// per-entry form paid one exposed memory round trip per entry (load, wait, store, load, wait, store ... in the ISA of every add layer).
 template <int CT, int PT>
 __device__ inline void conv_epilogue(const ConvArgs &a, const ConvClass &cls, floatx4 (&acc)[CT][PT], const float4 (&scv)[CT], const float4 (&biv)[CT],
                                      int wave, int j, int g, int ct0, int pz0, int py0, int px0) {
+#ifdef DR_EPILOGUE_PER_ENTRY  // A/B build: the per-entry form
+  constexpr int NE = CT * PT, GB = 1;
+#else
+  constexpr int NE = CT * PT, GB = NE < 4 ? NE : 4;
+#endif
 #pragma unroll
-  for (int pt = 0; pt < PT; ++pt) {
-    const int tau = wave * PT + pt;
-    const int xt = tau % a.TXT, yt = (tau / a.TXT) % a.TY, zt = tau / (a.TXT * a.TY);
-    const int qz = pz0 + zt, qy = py0 + yt, qx = px0 + xt * 16 + j;
-    if (qz >= a.nPD || qy >= a.nPH || qx >= a.nPW) continue;
+  for (int e0 = 0; e0 < NE; e0 += GB) {
+    size_t obase[GB];
+    float4 r[GB];
+    bool ok[GB];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
+    for (int k = 0; k < GB; ++k) {
+      const int e = e0 + k, pt = e / CT, ct = e - pt * CT;  // (compile-time after unrolling)
+      const int tau = wave * PT + pt;
+      const int xt = tau % a.TXT, yt = (tau / a.TXT) % a.TY, zt = tau / (a.TXT * a.TY);
+      const int qz = pz0 + zt, qy = py0 + yt, qx = px0 + xt * 16 + j;
       const int c0 = (ct0 + ct) * 16 + 4 * g;
-      if (c0 >= a.rows_valid) continue;
+      ok[k] = e < NE && qz < a.nPD && qy < a.nPH && qx < a.nPW && c0 < a.rows_valid;
       int oz = qz * a.omz + cls.ooz, oy = qy * a.omy + cls.ooy, ox = qx * a.omx + cls.oox, ch = c0;
       if (a.par_rows) {  // transposed layer: this lane's 4 rows are 4 channels of output parity q
         const int q = c0 / a.par_rows, bits = (a.par_map >> (3 * q)) & 7;
         ch = c0 - q * a.par_rows;
         oz += (bits >> 2) & 1; oy += (bits >> 1) & 1; ox += bits & 1;
       }
-      const size_t obase = (((size_t)oz * a.outH + oy) * a.outW + ox) * a.outC + ch;
-      size_t abase = obase;
+      obase[k] = (((size_t)oz * a.outH + oy) * a.outW + ox) * a.outC + ch;
+      size_t abase = obase[k];
       if (a.add_mode == 2) abase = (((size_t)oz * a.addH + (oy >> 1)) * a.addW + (ox >> 1)) * a.outC + ch;
+      r[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.add_mode && ok[k]) r[k] = *reinterpret_cast<const float4 *>(a.add + abase);
+    }
+#pragma unroll
+    for (int k = 0; k < GB; ++k) {
+      const int e = e0 + k, pt = e / CT, ct = e - pt * CT;
+      if (e >= NE || !ok[k]) continue;
       const float4 sc = scv[ct], bi = biv[ct];
       float4 v;
       v.x = acc[ct][pt][0] * sc.x + bi.x;
@@ -114,11 +132,8 @@ __device__ inline void conv_epilogue(const ConvArgs &a, const ConvClass &cls, fl
       if (a.relu) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       }
-      if (a.add_mode) {
-        const float4 r = *reinterpret_cast<const float4 *>(a.add + abase);
-        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-      }
-      *reinterpret_cast<float4 *>(a.out + obase) = v;
+      if (a.add_mode) { v.x += r[k].x; v.y += r[k].y; v.z += r[k].z; v.w += r[k].w; }
+      *reinterpret_cast<float4 *>(a.out + obase[k]) = v;
     }
   }
 }
