@@ -411,27 +411,32 @@ __device__ inline void march_epilogue_w(const ConvArgs &a, const MarchArgs &m, f
       if (c0 >= a.rows_valid) continue;
       const floatx4 m0 = acc[0][ct][pt], m1 = acc[1][ct][pt], m2 = acc[2][ct][pt], m3 = acc[3][ct][pt];
       const floatx4 o[2] = {(m0 + m1) + m2, (m1 - m2) - m3};
+      // both rows' partial sums / residual operands are fetched before the first store (they may alias `out`: hipcc would keep each load behind the store before it)
+      size_t obase[2];
+      float4 ps[2], ad[2];
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int oy = 2 * qy + r;
-        const size_t obase = march_out_index(a, m, zc, z, oy, qx, c0);
-        float4 v = make_float4(o[r][0], o[r][1], o[r][2], o[r][3]);
-        if (raw == 2) {
-          const float4 p = *reinterpret_cast<const float4 *>(a.out + obase);
-          v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        obase[r] = march_out_index(a, m, zc, z, oy, qx, c0);
+        ps[r] = ad[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (raw == 2) ps[r] = *reinterpret_cast<const float4 *>(a.out + obase[r]);
+        if (raw != 1 && a.add_mode) {
+          size_t abase = obase[r];
+          if (a.add_mode == 2) abase = (((size_t)(zc + z) * a.addH + (oy >> 1)) * a.addW + (qx >> 1)) * a.outC + c0;
+          ad[r] = *reinterpret_cast<const float4 *>(a.add + abase);
         }
+      }
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        float4 v = make_float4(o[r][0], o[r][1], o[r][2], o[r][3]);
+        if (raw == 2) { v.x += ps[r].x; v.y += ps[r].y; v.z += ps[r].z; v.w += ps[r].w; }
         if (raw != 1) {
           const float4 sc = scv[ct], bi = biv[ct];
           v.x = v.x * sc.x + bi.x; v.y = v.y * sc.y + bi.y; v.z = v.z * sc.z + bi.z; v.w = v.w * sc.w + bi.w;
           if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-          if (a.add_mode) {
-            size_t abase = obase;
-            if (a.add_mode == 2) abase = (((size_t)(zc + z) * a.addH + (oy >> 1)) * a.addW + (qx >> 1)) * a.outC + c0;
-            const float4 p = *reinterpret_cast<const float4 *>(a.add + abase);
-            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
-          }
+          if (a.add_mode) { v.x += ad[r].x; v.y += ad[r].y; v.z += ad[r].z; v.w += ad[r].w; }
         }
-        *reinterpret_cast<float4 *>(a.out + obase) = v;
+        *reinterpret_cast<float4 *>(a.out + obase[r]) = v;
       }
     }
   }

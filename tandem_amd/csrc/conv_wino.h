@@ -113,23 +113,27 @@ __device__ inline void conv_w_epilogue(const ConvArgs &a, const ConvClass &cls, 
       const floatx4 o[2] = {(m0 + m1) + m2, (m1 - m2) - m3};
       const float4 sc = scv[ct], bi = biv[ct];
       const int oz = qz * a.omz + cls.ooz, ox = qx * a.omx + cls.oox;
+      size_t obase[2];  // both rows' residual operands before the first store (`add` may alias `out`)
+      float4 ad[2];
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int oy = qy * 2 + r;
-        const size_t obase = (((size_t)oz * a.outH + oy) * a.outW + ox) * a.outC + c0;
-        size_t abase = obase;
+        obase[r] = (((size_t)oz * a.outH + oy) * a.outW + ox) * a.outC + c0;
+        size_t abase = obase[r];
         if (a.add_mode == 2) abase = (((size_t)oz * a.addH + (oy >> 1)) * a.addW + (ox >> 1)) * a.outC + c0;
+        ad[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.add_mode) ad[r] = *reinterpret_cast<const float4 *>(a.add + abase);
+      }
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
         float4 v;
         v.x = o[r][0] * sc.x + bi.x;
         v.y = o[r][1] * sc.y + bi.y;
         v.z = o[r][2] * sc.z + bi.z;
         v.w = o[r][3] * sc.w + bi.w;
         if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (a.add_mode) {
-          const float4 q = *reinterpret_cast<const float4 *>(a.add + abase);
-          v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-        }
-        *reinterpret_cast<float4 *>(a.out + obase) = v;
+        if (a.add_mode) { v.x += ad[r].x; v.y += ad[r].y; v.z += ad[r].z; v.w += ad[r].w; }
+        *reinterpret_cast<float4 *>(a.out + obase[r]) = v;
       }
     }
   }
