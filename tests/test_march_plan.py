@@ -12,11 +12,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
-@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="needs hipcc to compile the host emulation")
-def test_march_emulation_matches_direct_convolution(tmp_path):
-    exe = tmp_path / "march_emul"
+@pytest.fixture(scope="module")
+def march_emul(tmp_path_factory):
+    if not (os.path.exists(HIPCC) or shutil.which("hipcc")):
+        pytest.skip("needs hipcc to compile the host emulation")
+    exe = tmp_path_factory.mktemp("march_emul") / "march_emul"
     subprocess.check_call([HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-Wno-unused-function",
                            "-Wno-pass-failed", "-Wno-unused-result", os.path.join(ROOT, "tests", "cpp", "march_emul.hip"), "-o", str(exe)])
+    return str(exe)
+
+
+def test_march_emulation_matches_direct_convolution(march_emul):
+    exe = march_emul
     out = subprocess.run([str(exe), "80"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if " plan " in l]
@@ -27,14 +34,11 @@ def test_march_emulation_matches_direct_convolution(tmp_path):
         assert needle in text, needle
 
 
-@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="needs hipcc to compile the host emulation")
-def test_winograd_march_emulation_matches_direct_convolution(tmp_path):
+def test_winograd_march_emulation_matches_direct_convolution(march_emul):
     """march_consumer_w (the y axis of the 3-D layers in Winograd F(2,3) form on the marching kernel): the planner's row-pair geometry, the raw
     kernel rows [chunk of x taps][row k] it packs (g1 halved), u1 / u2 derived per lane with the kernel's own helper, the four rows of a
     pair's window through the swizzled ring image, the output transform, both outer-pass structures -- and the ring protocol unchanged."""
-    exe = tmp_path / "march_emul"
-    subprocess.check_call([HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-Wno-unused-function",
-                           "-Wno-pass-failed", "-Wno-unused-result", os.path.join(ROOT, "tests", "cpp", "march_emul.hip"), "-o", str(exe)])
+    exe = march_emul
     out = subprocess.run([str(exe), "5", "wino"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if " plan " in l]
