@@ -212,6 +212,56 @@ struct MvsSwitches {
 #endif
 };
 
+// One helper thread that takes half of the operator boundary's host copies (the window into the staging block, the result maps out of
+// the pinned block): a single core moves them at ~25 GB/s, i.e. 0.27 + 0.2 ms per 640 x 480 x 7 call on the critical path of TANDEM's
+// one-window-in-flight loop.  run() hands it a job, wait() returns when the job is done; the caller does its own half in between.
+class HostCopier {
+ public:
+  HostCopier() : th_(&HostCopier::loop, this) {}
+  ~HostCopier() {
+    { std::lock_guard<std::mutex> lk(mu_); quit_ = true; }
+    cv_.notify_all();
+    th_.join();
+  }
+  void run(std::function<void()> job) {
+    { std::lock_guard<std::mutex> lk(mu_); job_ = std::move(job); busy_ = true; }
+    cv_.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [&] { return !busy_; });
+    if (!error_.empty()) { std::string e = error_; error_.clear(); fail(DR_ERR_DEVICE, "%s", e.c_str()); }
+  }
+  void wait_quiet() {
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [&] { return !busy_; });
+    error_.clear();
+  }
+
+ private:
+  void loop() {
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      cv_.wait(lk, [&] { return busy_ || quit_; });
+      if (quit_) return;
+      std::function<void()> job = std::move(job_);
+      lk.unlock();
+      std::string err;
+      try { job(); } catch (const std::exception &e) { err = e.what(); }
+      lk.lock();
+      error_ = err;
+      busy_ = false;
+      done_.notify_all();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_, done_;
+  std::function<void()> job_;
+  std::string error_;
+  bool busy_ = false, quit_ = false;
+  std::thread th_;
+};
+
 static const char *conv_kind_name(const ConvLaunch &c) {
   return c.async == 2 ? (c.march.rm ? "rowmarch" : (c.march.wino ? "winomarch" : "march")) : (c.async == 4 ? "wino" : (c.async ? "async" : ""));
 }
@@ -278,8 +328,9 @@ class MvsEngine {
     if (!has_output_) fail(DR_ERR_PROTOCOL, "Output should be valid. Maybe you called GetResult more than once?");
     const size_t n = (size_t)H_ * W_;
     const float *src = h_out_[out_cur_];
+    copier_.run([=] { memcpy(depth_dense, src + 2 * n, n * 4); memcpy(conf_dense, src + 3 * n, n * 4); });  // two maps each
     memcpy(depth, src, n * 4); memcpy(conf, src + n, n * 4);
-    memcpy(depth_dense, src + 2 * n, n * 4); memcpy(conf_dense, src + 3 * n, n * 4);
+    copier_.wait();
     has_output_ = false;
   }
   // The same result WITHOUT the 4.9 MB host copy: pointers into the page-locked block the device wrote it to.  Two blocks alternate,
@@ -858,10 +909,21 @@ class MvsEngine {
       if (hipPointerGetAttributes(&at, bgrs[v]) != hipSuccess) { (void)hipGetLastError(); pinned = false; }
       else pinned = at.type == hipMemoryTypeHost;
     }
-    for (int v = 0; v < V; ++v) {
-      const uint8_t *src = bgrs[order[v]];
-      if (!pinned) { memcpy(h_in_ + v * img_bytes, src, img_bytes); src = h_in_ + v * img_bytes; }
-      DR_HIP(hipMemcpyAsync(d_bgr_ + v * img_bytes, src, img_bytes, hipMemcpyHostToDevice, stream_));
+    auto upload_views = [&, pinned](int v0) {  // views v0, v0 + 2, ...: gather into the staging block (unless page-locked already), then the copy engine
+      DR_HIP(hipSetDevice(device_));
+      for (int v = v0; v < V; v += 2) {
+        const uint8_t *src = bgrs[order[v]];
+        if (!pinned) { memcpy(h_in_ + v * img_bytes, src, img_bytes); src = h_in_ + v * img_bytes; }
+        DR_HIP(hipMemcpyAsync(d_bgr_ + v * img_bytes, src, img_bytes, hipMemcpyHostToDevice, stream_));
+      }
+    };
+    if (!pinned) {
+      copier_.run([&] { upload_views(1); });  // the helper thread takes every other view
+      try { upload_views(0); } catch (...) { copier_.wait_quiet(); throw; }  // (the job refers to this frame's locals)
+      copier_.wait();
+    } else {
+      upload_views(1);
+      upload_views(0);
     }
     if (pinned) {
       if (!ev_h2d_) DR_HIP(hipEventCreateWithFlags(&ev_h2d_, hipEventDisableTiming));
@@ -1179,6 +1241,7 @@ class MvsEngine {
   bool phase_mode_ = false;
 
   std::thread worker_;
+  HostCopier copier_;
   std::mutex mu_;
   std::condition_variable input_cv_, done_cv_;
   bool running_ = true;
