@@ -86,7 +86,9 @@ __device__ inline void conv_load_affine(const ConvArgs &a, int g, int ct0, float
 // The residual / upsample-add operand is FETCHED FOR A GROUP OF UP TO FOUR (position tile, row tile) entries before the first store of the
 // group: `add` and `out` may alias (the folded stage-3 head adds in place), so hipcc keeps every load behind the store before it, and the
 // per-entry form paid one exposed memory round trip per entry (load, wait, store, load, wait, store ... in the ISA of every add layer).
-template <int CT, int PT>
+// ADD = false: the instantiation for layers without a residual operand -- no load and therefore no s_waitcnt vmcnt in it (k_conv_a issues the next
+// unit's DMA before it: a counter wait here would wait for those older pieces as well).
+template <int CT, int PT, bool ADD = true>
 __device__ inline void conv_epilogue(const ConvArgs &a, const ConvClass &cls, floatx4 (&acc)[CT][PT], const float4 (&scv)[CT], const float4 (&biv)[CT],
                                      int wave, int j, int g, int ct0, int pz0, int py0, int px0) {
 #ifdef DR_EPILOGUE_PER_ENTRY  // A/B build: the per-entry form
@@ -117,7 +119,7 @@ __device__ inline void conv_epilogue(const ConvArgs &a, const ConvClass &cls, fl
       size_t abase = obase[k];
       if (a.add_mode == 2) abase = (((size_t)oz * a.addH + (oy >> 1)) * a.addW + (ox >> 1)) * a.outC + ch;
       r[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a.add_mode && ok[k]) r[k] = *reinterpret_cast<const float4 *>(a.add + abase);
+      if (ADD && a.add_mode && ok[k]) r[k] = *reinterpret_cast<const float4 *>(a.add + abase);
     }
 #pragma unroll
     for (int k = 0; k < GB; ++k) {
@@ -132,7 +134,7 @@ __device__ inline void conv_epilogue(const ConvArgs &a, const ConvClass &cls, fl
       if (a.relu) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       }
-      if (a.add_mode) { v.x += r[k].x; v.y += r[k].y; v.z += r[k].z; v.w += r[k].w; }
+      if (ADD && a.add_mode) { v.x += r[k].x; v.y += r[k].y; v.z += r[k].z; v.w += r[k].w; }
       *reinterpret_cast<float4 *>(a.out + obase[k]) = v;
     }
   }
@@ -622,6 +624,18 @@ __global__ __launch_bounds__(kConvAThreads) void k_conv_a(const ConvArgs a) {
   for (int i = 0; i < n_units; ++i) {
     conv_a_wait_dma();  // this wave's pieces of unit i have landed ...
     __syncthreads();    // ... and so have everybody else's; every wave is done reading the other buffer
+    // The next unit's DMA goes out BEFORE the previous tile's epilogue when that epilogue only stores (no residual operand): the round trip to L2 /
+    // HBM then runs beside the epilogue as well as the K loop (a stride-2 layer's K loop is 0.7 us against a 2-3 us round trip).  With a residual
+    // operand the order stays epilogue first: the DMA is invisible to hipcc's counters, and the vmcnt it puts behind the residual loads would then
+    // wait for the (older) DMA pieces too.
+#ifndef DR_ABL_NO_STAGE
+#ifndef DR_CONV_A_ISSUE_LATE  // (A/B build: always after the epilogue, round 3's order)
+    const bool early = a.add_mode == 0;
+#else
+    const bool early = false;
+#endif
+    if (early && i + 1 < n_units) issue(i + 1);
+#endif
 #ifdef DR_ABL_NO_EPI
     if (done_tile >= 0 && a.npass < 0) {
 #else
@@ -629,7 +643,8 @@ __global__ __launch_bounds__(kConvAThreads) void k_conv_a(const ConvArgs a) {
 #endif
       int pz0, py0, px0;
       tile_origin(done_tile, pz0, py0, px0);
-      conv_epilogue<CT, PT>(a, cls, acc, scv, biv, wave, j, g, ct0, pz0, py0, px0);
+      if (a.add_mode) conv_epilogue<CT, PT, true>(a, cls, acc, scv, biv, wave, j, g, ct0, pz0, py0, px0);
+      else conv_epilogue<CT, PT, false>(a, cls, acc, scv, biv, wave, j, g, ct0, pz0, py0, px0);
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -637,7 +652,7 @@ __global__ __launch_bounds__(kConvAThreads) void k_conv_a(const ConvArgs a) {
       done_tile = -1;
     }
 #ifndef DR_ABL_NO_STAGE
-    if (i + 1 < n_units) issue(i + 1);
+    if (!early && i + 1 < n_units) issue(i + 1);
 #endif
 #ifndef DR_ABL_NO_KLOOP
 #ifdef DR_NO_NARROW_KLOOP
