@@ -46,10 +46,6 @@ struct MarchArgs {
   int inHp;            // rows a plane has inside the tensor (inH, or 1 for the row march)
   int rm;              // row march
   int wino;            // 1: the y axis in Winograd F(2,3) form (march_consumer_w): a position is a row PAIR, a.sy = 2, the in-plane tap table lists the x taps only
-  int t3;              // 1: TILE RING -- every step is one (TZ x TY x TXT*16)-position tile of a layer of ANY kernel size and stride (KZ = 1, Dc = 1): the
-                       //    "plane" a load brings is the tile's whole 3-D halo (TZI x TYI x TXI positions), zc = the tile's index along z, the tap table holds
-                       //    3-D offsets.  What the strided layers get from it is the ring: two to four tiles' DMA in flight under the K loops (k_conv_a: one).
-  int i_szt;           // t3: input elements between two planes of a tile (inH * inW * inC)
   int *err;            // raised when a wait gave up (nullptr: not reported)
 };
 
@@ -67,9 +63,9 @@ __device__ inline int march_uniform(int v) { return __builtin_amdgcn_readfirstla
 
 // ---- index arithmetic shared with the host emulation (tests/cpp/march_emul.hip), which checks it against a direct convolution ----
 // staged position of output position j of position tile (wave, pt)
-DR_HD inline int march_bpos(const ConvArgs &a, int wave, int pt, int PT, int j, bool t3 = false) {
-  const int tau = wave * PT + pt, xt = tau % a.TXT, yz = tau / a.TXT, yt = t3 ? yz % a.TY : yz, zt = t3 ? yz / a.TY : 0;  // (tile ring: the tile has TZ planes of TY rows)
-  return ((zt * a.sz) * a.TYI + yt * a.sy) * a.TXI + (xt * 16 + j) * a.sx;  // (a.sy = 1, or 2 in the Winograd form: position tile yt starts at row 2 * yt of the staged plane)
+DR_HD inline int march_bpos(const ConvArgs &a, int wave, int pt, int PT, int j) {
+  const int tau = wave * PT + pt, xt = tau % a.TXT, yt = tau / a.TXT;
+  return yt * a.sy * a.TXI + (xt * 16 + j) * a.sx;  // (a.sy = 1, or 2 in the Winograd form: position tile yt starts at row 2 * yt of the staged plane)
 }
 // column -> tile origin (output positions) and, for 2-D layers, the image the column belongs to
 DR_HD inline void march_tile_origin(const ConvArgs &a, const MarchArgs &m, int col, int &zc, int &py0, int &px0) {
@@ -79,22 +75,17 @@ DR_HD inline void march_tile_origin(const ConvArgs &a, const MarchArgs &m, int c
 }
 // DMA piece (producer wave pw, iteration it), lane -> element offset inside the plane relative to the tile origin, packed (y, x)
 template <int CI>
-DR_HD inline void march_piece_entry(const ConvArgs &a, const MarchArgs &m, int pw, int it, int lane, int &rel, unsigned &yx, bool t3 = false) {  // t3: a compile-time constant in the kernel
+DR_HD inline void march_piece_entry(const ConvArgs &a, const MarchArgs &m, int pw, int it, int lane, int &rel, unsigned &yx) {
   int pos, c4;
   conv_a_slot<CI>((it * kMarchProducers + pw) * 64 + lane, pos, c4);
-  const unsigned t = (unsigned)pos / (unsigned)a.TXI, x = (unsigned)pos - t * a.TXI;
-  const unsigned z = t3 ? t / (unsigned)a.TYI : 0u, y = t - z * a.TYI;  // (tile ring: the staged "plane" is TZI planes of TYI rows)
+  const unsigned y = (unsigned)pos / (unsigned)a.TXI, x = (unsigned)pos - y * a.TXI;
   const bool ok = it < m.nit && pos < m.NP;
-  rel = ok ? (int)((t3 ? z * m.i_szt : 0u) + y * m.i_sy + x * a.inC + c4 * 4) : 0;
-  yx = ok ? ((z << 26) | (y << 16) | x) : 0x03ff7fffu;  // z (6 bits) | y (10 bits) | x (16 bits); the invalid mark is a position no tile origin can bring inside the tensor
+  rel = ok ? (int)(y * m.i_sy + x * a.inC + c4 * 4) : 0;
+  yx = ok ? ((y << 16) | x) : 0x7fff7fffu;  // a position no tile origin can bring inside the tensor
 }
-DR_HD inline bool march_piece_inside(const ConvArgs &a, const MarchArgs &m, unsigned yx, int iy0, int ix0, int iz0 = 0, bool t3 = false) {
-  if (!t3) {  // (z = 0 in the packed position: the two-field form the marching modes have always used)
-    const unsigned gy = (unsigned)(iy0 + (int)(yx >> 16)), gx = (unsigned)(ix0 + (int)(yx & 0xffffu));
-    return gy < (unsigned)m.inHp && gx < (unsigned)a.inW;
-  }
-  const unsigned gy = (unsigned)(iy0 + (int)((yx >> 16) & 0x3ffu)), gx = (unsigned)(ix0 + (int)(yx & 0xffffu)), gz = (unsigned)(iz0 + (int)(yx >> 26));
-  return gy < (unsigned)m.inHp && gx < (unsigned)a.inW && gz < (unsigned)a.inD;
+DR_HD inline bool march_piece_inside(const ConvArgs &a, const MarchArgs &m, unsigned yx, int iy0, int ix0) {
+  const unsigned gy = (unsigned)(iy0 + (int)(yx >> 16)), gx = (unsigned)(ix0 + (int)(yx & 0xffffu));
+  return gy < (unsigned)m.inHp && gx < (unsigned)a.inW;
 }
 // element offset of the tile origin of input plane `plane` of image zc, channel slice `pass` (may be negative: the halo starts outside the tensor)
 DR_HD inline long long march_plane_offset(const ConvArgs &a, const MarchArgs &m, int zc, int plane, int iy0, int ix0, int pass, int CI) {
@@ -232,20 +223,20 @@ __device__ inline void march_kloop3(const float4 *const (&tile)[3], const float4
 }
 
 // ---- epilogue of one step; raw: 0 = final, 1 = store raw partial sums, 2 = add the stored partial sums, then final ----
-template <int CT, int PT, bool T3 = false>
+template <int CT, int PT>
 __device__ inline void march_epilogue(const ConvArgs &a, const MarchArgs &m, floatx4 (&acc)[CT][PT], const float4 (&scv)[CT], const float4 (&biv)[CT], int raw,
                                       int wave, int j, int g, int ct0, int zc, int z, int py0, int px0) {
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
     const int tau = wave * PT + pt;
-    const int xt = tau % a.TXT, yz = tau / a.TXT, yt = T3 ? yz % a.TY : yz, zt = T3 ? yz / a.TY : 0;
+    const int xt = tau % a.TXT, yt = tau / a.TXT;
     const int qy = py0 + yt, qx = px0 + xt * 16 + j;
-    if (qy >= a.nPH || qx >= a.nPW || (T3 && zc * a.TZ + zt >= a.nPD)) continue;  // (tile ring: zc counts z tiles, o_sv = TZ output planes)
+    if (qy >= a.nPH || qx >= a.nPW) continue;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       const int c0 = (ct0 + ct) * 16 + 4 * g;
       if (c0 >= a.rows_valid) continue;
-      const size_t obase = march_out_index(a, m, zc, T3 ? zt : z, qy, qx, c0);
+      const size_t obase = march_out_index(a, m, zc, z, qy, qx, c0);
       float4 v = make_float4(acc[ct][pt][0], acc[ct][pt][1], acc[ct][pt][2], acc[ct][pt][3]);
       if (raw == 2) {
         const float4 r = *reinterpret_cast<const float4 *>(a.out + obase);
@@ -257,7 +248,7 @@ __device__ inline void march_epilogue(const ConvArgs &a, const MarchArgs &m, flo
         if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         if (a.add_mode) {
           size_t abase = obase;
-          if (a.add_mode == 2) abase = (((size_t)(T3 ? zc * a.TZ + zt : zc + z) * a.addH + (qy >> 1)) * a.addW + (qx >> 1)) * a.outC + c0;  // (never the row march: one of zc, z is 0)
+          if (a.add_mode == 2) abase = (((size_t)(zc + z) * a.addH + (qy >> 1)) * a.addW + (qx >> 1)) * a.outC + c0;  // (never the row march: one of zc, z is 0)
           const float4 r = *reinterpret_cast<const float4 *>(a.add + abase);
           v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
         }
@@ -267,7 +258,7 @@ __device__ inline void march_epilogue(const ConvArgs &a, const MarchArgs &m, flo
   }
 }
 
-template <int CI, int NUP, int CT, int PT, int NPW, bool T3 = false>
+template <int CI, int NUP, int CT, int PT, int NPW>
 __device__ inline void march_consumer(const ConvArgs &a, const MarchArgs &m, float4 *lds4, march_flag_t *flags, const float4 *wl, int wave, int lane,
                                       int s0, int s1) {
   constexpr int TPC = 16 / CI;
@@ -277,7 +268,7 @@ __device__ inline void march_consumer(const ConvArgs &a, const MarchArgs &m, flo
   int sw[NUP][PT];
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
-    const int bpos = march_bpos(a, wave, pt, PT, j, T3);
+    const int bpos = march_bpos(a, wave, pt, PT, j);
 #pragma unroll
     for (int u = 0; u < NUP; ++u) {
       sw[u][pt] = conv_a_unit<CI>(bpos + m.tap2d[u * TPC + sub], c4);
@@ -346,7 +337,7 @@ __device__ inline void march_consumer(const ConvArgs &a, const MarchArgs &m, flo
 #if defined(DR_MABL_NO_EPI) || defined(DR_MABL_FREE)
         if (m.NPO > 7)  // never true: keeps the accumulators live
 #endif
-        march_epilogue<CT, PT, T3>(a, m, acc, scv, biv, raw, wave, j, g, ct0, zc, z, py0, px0);
+        march_epilogue<CT, PT>(a, m, acc, scv, biv, raw, wave, j, g, ct0, zc, z, py0, px0);
         cur.next_step(m.geo, R);
       }
       L += sg.nl;
@@ -542,7 +533,7 @@ __device__ inline void march_consumer_w(const ConvArgs &a, const MarchArgs &m, f
 // (the row march: 10-20 KB per load, a step of 1-2 us) would otherwise be fetched one memory latency after the other.
 // When the ring has no free slot the wave first drains and publishes everything it has in flight -- the consumers may need
 // exactly those loads to release the slot it is waiting for.
-template <int CI, bool T3 = false>
+template <int CI>
 __device__ inline void march_producer(const ConvArgs &a, const MarchArgs &m, float4 *lds4, march_flag_t *flags, float4 *wl, int pw, int lane, int s0,
                                       int s1, int NUP, int CT) {
   const int ct0 = blockIdx.z * CT, NS = m.geo.KZ * m.geo.NPI;
@@ -551,7 +542,7 @@ __device__ inline void march_producer(const ConvArgs &a, const MarchArgs &m, flo
   int rel[kMarchMaxIt];
   unsigned yx[kMarchMaxIt];
 #pragma unroll
-  for (int it = 0; it < kMarchMaxIt; ++it) march_piece_entry<CI>(a, m, pw, it, lane, rel[it], yx[it], T3);
+  for (int it = 0; it < kMarchMaxIt; ++it) march_piece_entry<CI>(a, m, pw, it, lane, rel[it], yx[it]);
   const int depth = m.depth;
   int L = 0;
   for (int po = 0; po < m.NPO; ++po) {
@@ -565,12 +556,10 @@ __device__ inline void march_producer(const ConvArgs &a, const MarchArgs &m, flo
       int zc, py0, px0;
       march_tile_origin(a, m, sg.col, zc, py0, px0);
       const int iy0 = m.rm ? 0 : py0 * a.sy - a.py, ix0 = px0 * a.sx - a.px;  // (row march: the plane IS the row, no y padding inside it)
-      const int iz0 = T3 ? zc * a.TZ * a.sz - a.pz : 0;                       // (tile ring: first input plane of the tile's halo)
       for (int l = 0; l < sg.nl; ++l) {
         const int idx = L + l;
         int plane, pi;
         march_load_plane(m.geo, sg, l, plane, pi);
-        if (T3) plane = -a.pz;  // i_sv = the input planes a z tile advances by, i_sz = one plane: zc * i_sv + plane * i_sz = iz0 planes
 #ifndef DR_MABL_FREE
         if (idx >= m.R && march_released_now(flags, m.ncw) < idx - m.R + 1) {
           if (flight) {
@@ -591,7 +580,7 @@ __device__ inline void march_producer(const ConvArgs &a, const MarchArgs &m, flo
 #else
           if (it < m.nit) {
 #endif
-            const float *src = march_piece_inside(a, m, yx[it], iy0, ix0, iz0, T3) ? pbase + rel[it] : a.zero16;
+            const float *src = march_piece_inside(a, m, yx[it], iy0, ix0) ? pbase + rel[it] : a.zero16;
             conv_a_dma16(src, march_uniform(conv_a_lds_addr(dst + (it * kMarchProducers + pw) * 64)));
           }
         }
@@ -695,7 +684,6 @@ __device__ inline void march_producer_fz(const ConvArgs &a, const MarchArgs &m, 
 }
 
 // grid = (persistent workgroups (multiple of 8), 1, output-row groups); 8 consumer waves + 2 (DMA) or 4 (fused skip) producer waves.
-// W: 1 = the Winograd consumer (march_consumer_w), 2 = the tile ring (MarchArgs::t3: consumer, producer and epilogue with the tile's z axis)
 template <int CI, int NUP, int CT, int PT, int FZ = 0, int NCW = 8, int W = 0>
 __global__ __launch_bounds__(64 * (NCW + (FZ ? kMarchFzProducers : kMarchProducers))) void k_conv_m(const ConvArgs a, const MarchArgs m) {
   extern __shared__ float4 lds4[];
@@ -711,11 +699,11 @@ __global__ __launch_bounds__(64 * (NCW + (FZ ? kMarchFzProducers : kMarchProduce
   march_range(m.steps, id, nwg, s0, s1);
   if (s0 >= s1) return;
   if (wave < NCW) {
-    if constexpr (W == 1) march_consumer_w<CI, NUP, CT, PT, kMarchProducers>(a, m, lds4, flags, wl, wave, lane, s0, s1);
-    else march_consumer<CI, NUP, CT, PT, (FZ ? kMarchFzProducers : kMarchProducers), W == 2>(a, m, lds4, flags, wl, wave, lane, s0, s1);
+    if constexpr (W) march_consumer_w<CI, NUP, CT, PT, kMarchProducers>(a, m, lds4, flags, wl, wave, lane, s0, s1);
+    else march_consumer<CI, NUP, CT, PT, (FZ ? kMarchFzProducers : kMarchProducers)>(a, m, lds4, flags, wl, wave, lane, s0, s1);
   }
   else if constexpr (FZ > 0) march_producer_fz<FZ>(a, m, lds4, flags, wl, wave - NCW, lane, s0, s1, NUP, CT);
-  else march_producer<CI, W == 2>(a, m, lds4, flags, wl, wave - NCW, lane, s0, s1, NUP, CT);
+  else march_producer<CI>(a, m, lds4, flags, wl, wave - NCW, lane, s0, s1, NUP, CT);
 }
 
 }  // namespace dr

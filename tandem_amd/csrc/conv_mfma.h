@@ -831,14 +831,8 @@ inline bool conv_a_instance_exists(int ci, int ct, int pt) {  // PT = 1 (round 4
   X(16, 3, 2, 1, 8) X(16, 3, 2, 2, 8) X(16, 3, 2, 1, 10) X(16, 3, 2, 2, 10)
 // the Winograd form of the 3-D instances (march_consumer_w): one position tile (16 x by a row pair) per wave
 #define DR_MARCH_W_INSTANCES(X) X(8, 6, 1, 1, 8) X(16, 12, 1, 1, 8) X(16, 9, 1, 1, 8)  // (twelve consumer waves leave 128 registers: the two operand sets spill)
-// the TILE RING instances (MarchArgs::t3): strided and 5 x 5 layers.  NUP = K chunks of the whole tile: 3^3 taps of 8 channels = 14 (one padded tap);
-// 5 x 5 taps of 8 channels = 13 (one padded), of 16 channels = 25.  Four or eight consumer waves, one position tile each.  (3^3 stride-2 tiles of 16
-// channels -- 27 chunks -- are 53 KB and more: two ring slots at most, i.e. no deeper than k_conv_a; not instantiated.)
-#define DR_MARCH_T_INSTANCES(X) \
-  X(8, 14, 1, 1, 4) X(8, 14, 1, 1, 8) X(8, 13, 1, 1, 4) X(8, 13, 1, 1, 8) X(16, 25, 1, 1, 4) X(16, 25, 1, 1, 8) X(16, 25, 2, 1, 4) X(16, 25, 2, 1, 8)
-inline bool conv_m_instance_exists(int ci, int nup, int ct, int pt, int ncw, bool wino = false, bool t3 = false) {
+inline bool conv_m_instance_exists(int ci, int nup, int ct, int pt, int ncw, bool wino = false) {
 #define DR_X(CI_, NUP_, CT_, PT_, NCW_) if (ci == CI_ && nup == NUP_ && ct == CT_ && pt == PT_ && ncw == NCW_) return true;
-  if (t3) { DR_MARCH_T_INSTANCES(DR_X) return false; }
   if (wino) { DR_MARCH_W_INSTANCES(DR_X) return false; }
   DR_MARCH_INSTANCES(DR_X)
 #undef DR_X
@@ -905,36 +899,6 @@ inline int conv_wino_policy() {
 inline double conv_wino_g(int p, int k) {
   static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
   return G[p][k];
-}
-// Geometry of a TILE RING candidate (MarchArgs::t3): one step = one (tz x ty x txt*16)-position tile with its whole 3-D halo as the "plane"; ntaps = all taps.
-inline MarchShape march_shape_t3(int ntaps, int Cin, int ci, int ct, int tz, int ty, int txt, int SZ, int SY, int SX, int exz, int exy, int exx, int nPD, int nPH,
-                                 int nPW, int CTtot) {
-  MarchShape m{};
-  const int tpc = 16 / ci;
-  if (Cin % ci || CTtot % ct) return m;
-  m.ncw = tz * ty * txt;  // one position tile per consumer wave
-  m.nup = cdiv(ntaps, tpc);
-  if (!conv_m_instance_exists(ci, m.nup, ct, 1, m.ncw, false, true)) return m;
-  const int npass = Cin / ci;
-  if (npass > 2) return m;
-  m.npi = npass; m.npo = 1; m.ns = npass;  // channel passes run inside the step (KZ = 1)
-  const int tzi = (tz - 1) * SZ + exz;
-  m.tyi = (ty - 1) * SY + exy; m.txi = (txt * 16 - 1) * SX + exx; m.np = tzi * m.tyi * m.txi;
-  if (m.np >= 65536 || tzi >= 64 || m.tyi >= 1024) return m;
-  m.ps = cdiv(((m.np + 15) & ~15) * (ci / 4), 128) * 128;
-  if (m.ps / 128 > kMarchMaxIt) return m;
-  m.wbytes = (size_t)m.ns * m.nup * ct * 1024;
-  const size_t fixed = m.wbytes + kMarchFlagInts * 4;
-  if (fixed >= kConvMaxLds) return m;
-  const int rmin = m.npi + 1, rmax = 3 * m.npi + 1;  // the tile being read + up to three tiles' loads in flight
-  m.r = (int)std::min<size_t>(rmax, (kConvMaxLds - fixed) / ((size_t)m.ps * 16));
-  if (m.r < rmin) return m;
-  m.lds_bytes = (size_t)m.r * m.ps * 16 + fixed;
-  m.steps = (long long)cdiv(nPD, tz) * cdiv(nPH, ty) * cdiv(nPW, txt * 16);
-  const int split = CTtot / ct;
-  m.grid = 8 * cdiv((int)std::min<long long>(m.steps, std::max(8, 256 / split)), 8);
-  m.ok = true;
-  return m;
 }
 inline size_t conv_a_slots(int np, int ci) { return (size_t)cdiv(((np + 1) & ~1) * (ci / 4), 512) * 512; }
 // Form of a stride-2 transposed layer (see axis_classes): 0 = every strided axis dense (8 * Cout rows, 27 of 64 products useful),
@@ -1107,29 +1071,6 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
             cands.push_back({cost, ci, pt, ct, 1, ty, txt, L.kd, ms.tyi, ms.txi, 2});
           }
         }
-    }
-  }
-  // the TILE RING (async = 6): strided and 5 x 5 layers on k_conv_m's producer / consumer ring, one tile per step (conv_march.h MarchArgs::t3)
-  const bool ring_ok = !fz && !bf3 && conv_march_policy() >= 1 && !getenv("DR_CONV_NO_RING") && ncls == 1 && !L.transposed && !L.up2 && mode == CONV_NORMAL && (SZ > 1 || SY > 1 || SX > 1);
-  if (ring_ok) {
-    for (int ci : {16, 8}) {
-      if (L.Cin % ci || (ci == 8 && L.Cin != 8)) continue;
-      for (int ncw : {4, 8})
-        for (int tz = 1; tz <= ncw; tz *= 2)
-          for (int ty = 1; tz * ty <= ncw; ty *= 2) {
-            const int txt = ncw / (tz * ty);
-            if ((tz > 1 && tz / 2 >= nPD) || (ty > 1 && ty / 2 >= nPH) || (txt > 1 && (txt / 2) * 16 >= nPW)) continue;
-            for (int ct : {2, 1}) {
-              const MarchShape ms = march_shape_t3(classes[0].ntaps, L.Cin, ci, ct, tz, ty, txt, SZ, SY, SX, exz, exy, exx, nPD, nPH, nPW, CTtot);
-              if (!ms.ok) continue;
-              const double spw = std::ceil((double)ms.steps / ms.grid);
-              const double mfma = ms.ns * ms.nup * 4.0 * ct * 32.0 * std::max(1, ncw / 4);  // MFMA cycles of a step per SIMD
-              const double fill = (double)ms.ps * 16.0 * ms.npi / 24.0;                         // LDS fill of a step at ~24 B/clk/CU
-              double cost = spw * (std::max(mfma, fill) + 500.0) + (double)ms.lds_bytes / 16.0 + 3000.0;
-              if (conv_march_policy() >= 2) cost *= 1e-3;
-              cands.push_back({cost, ci, 1, ct, tz, ty, txt, (tz - 1) * SZ + exz, ms.tyi, ms.txi, 6});
-            }
-          }
     }
   }
   // the Winograd form of the marching kernel (async = 5): 3-D layers, even output height; ty counts row pairs
@@ -1444,37 +1385,6 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
     const int want = std::max(1, std::min(ntiles, 256 * wpc / split));
     cl.grid = dim3(8 * cdiv(want, 8), 1, split);
   }
-  if (ASYNC == 6) {  // tile ring: k_conv_m with one tile per step (MarchArgs::t3)
-    const MarchShape ms = march_shape_t3(classes[0].ntaps, L.Cin, CI, CT, TZ, TY, TXT, SZ, SY, SX, exz, exy, exx, nPD, nPH, nPW, CTtot);
-    if (!ms.ok) fail(DR_ERR_ARG, "plan_conv: inconsistent tile-ring plan");
-    cl.async = 2; cl.nup = ms.nup; cl.ncw = ms.ncw;
-    a.zero16 = arena.upload(std::vector<float>(4, 0.f));
-    a.a_slots = 0; a.a_wbufs = 0;
-    MarchArgs &m = cl.march;
-    std::vector<int> tap2d((size_t)ms.nup * TPC, 0);  // the tile's 3-D tap offsets, as k_conv's table (a padded tap points at offset 0 and carries weight 0)
-    for (size_t i = 0; i < tap2d.size() && i < (size_t)classes[0].ntaps; ++i) tap2d[i] = tapoff[cls[0].tap_base + i];
-    m.tap2d = arena.upload(tap2d);
-    m.geo.KZ = 1; m.geo.NPI = ms.npi; m.geo.Dc = 1;
-    m.NPO = 1;
-    m.colsH = cdiv(nPH, TY); m.colsW = cdiv(nPW, TXT * 16);
-    m.ncols = cdiv(nPD, TZ) * m.colsH * m.colsW;
-    m.R = ms.r; m.PS = ms.ps; m.NP = ms.np; m.nit = ms.ps / 128;
-    m.wsec = ms.nup * CT * 64; m.NU = ms.nup;
-    m.steps = (int)ms.steps;
-    m.ncw = ms.ncw;
-    m.rm = 0; m.wino = 0; m.t3 = 1;
-    const long long iplane = (long long)a.inH * a.inW * a.inC, oplane = (long long)a.outH * a.outW * a.outC;
-    if (iplane * std::max(1, a.inD) >= (1ll << 31) || oplane * std::max(1, a.outD) >= (1ll << 31)) fail(DR_ERR_ARG, "plan_conv: tensor too large for k_conv_m's 32-bit strides");
-    m.i_szt = (int)iplane;
-    m.i_sv = (int)(iplane * TZ * SZ); m.i_sz = (int)iplane; m.i_sy = a.inW * a.inC;   // zc = z-tile index; the producer passes plane = -pz
-    m.o_sv = (int)(oplane * TZ); m.o_sz = (int)oplane; m.o_sy = a.outW * a.outC;      // the epilogue passes z = the position tile's plane inside the tile
-    m.inHp = a.inH;
-    m.err = arena.err_flag;
-    m.depth = 3;
-    if (const char *e = getenv("DR_MARCH_PDEPTH")) m.depth = std::max(1, std::min(4, atoi(e)));
-    cl.lds_bytes = ms.lds_bytes;
-    cl.grid = dim3(ms.grid, 1, CTtot / CT);
-  }
   if (ASYNC == 2 || ASYNC == 3 || ASYNC == 5) {
     const bool rm = ASYNC == 3;
     const MarchShape ms = rm ? march_shape(L.kd, row_ntp, L.Cin, CI, CT, PT, 1, TXT, SX, exy, exx, nPD, nPH, nPW, CTtot, true)
@@ -1586,13 +1496,6 @@ inline void launch_conv(const ConvLaunch &c, hipStream_t st) {
     return;
   }
 #endif
-  if (c.async == 2 && c.march.t3) {
-#define DR_X(CI_, NUP_, CT_, PT_, NCW_) \
-  if (c.ci == CI_ && c.nup == NUP_ && c.ct == CT_ && c.pt == PT_ && c.ncw == NCW_) { launch_conv_m_inst<CI_, NUP_, CT_, PT_, 0, NCW_, 2>(c, st); return; }
-    DR_MARCH_T_INSTANCES(DR_X)
-#undef DR_X
-    fail(DR_ERR_ARG, "launch_conv: no tile-ring instance CI=%d NUP=%d CT=%d PT=%d waves=%d", c.ci, c.nup, c.ct, c.pt, c.ncw);
-  }
   if (c.async == 2 && c.march.wino) {
 #define DR_X(CI_, NUP_, CT_, PT_, NCW_) \
   if (c.ci == CI_ && c.nup == NUP_ && c.ct == CT_ && c.pt == PT_ && c.ncw == NCW_) { launch_conv_m_inst<CI_, NUP_, CT_, PT_, 0, NCW_, 1>(c, st); return; }

@@ -263,7 +263,7 @@ class HostCopier {
 };
 
 static const char *conv_kind_name(const ConvLaunch &c) {
-  return c.async == 2 ? (c.march.rm ? "rowmarch" : (c.march.wino ? "winomarch" : (c.march.t3 ? "ring" : "march"))) : (c.async == 4 ? "wino" : (c.async ? "async" : ""));
+  return c.async == 2 ? (c.march.rm ? "rowmarch" : (c.march.wino ? "winomarch" : "march")) : (c.async == 4 ? "wino" : (c.async ? "async" : ""));
 }
 
 class MvsEngine {
@@ -417,7 +417,7 @@ class MvsEngine {
                          conv_kind_name(best_c), best_c.ci, best_c.ct, best_c.pt, best_c.args.TZ, best_c.args.TY, best_c.args.TXT * 16);
       if (print && best_rank != 0)
         fprintf(stderr, "TUNED    {%s,   %d, %d, %d, %d, %d, %d, %d},  // %s %.4f -> %.4f ms\n", o.sig.c_str(), best_c.ci, best_c.ct, best_c.pt, best_c.args.TZ,
-                best_c.args.TY, best_c.args.TXT, best_c.async == 2 ? (best_c.march.rm ? 3 : (best_c.march.wino ? 5 : (best_c.march.t3 ? 6 : 2))) : best_c.async, o.name.c_str(), t0, best);
+                best_c.args.TY, best_c.args.TXT, best_c.async == 2 ? (best_c.march.rm ? 3 : (best_c.march.wino ? 5 : 2)) : best_c.async, o.name.c_str(), t0, best);
       o.conv = best_c;
       t_before += t0; t_after += best;
     }
@@ -532,7 +532,7 @@ class MvsEngine {
       ms.push_back(t);
       const Op &o = ops_[i];
       char kn[64] = "misc";
-      if (o.kind == Op::CONV && o.conv.async == 2) snprintf(kn, sizeof kn, "k_conv_m<%d,%d,%d,%d,%d,%d,%d>", o.conv.ci, o.conv.nup, o.conv.ct, o.conv.pt, o.conv.fz, o.conv.ncw, o.conv.march.t3 ? 2 : o.conv.march.wino);  // rocprofv3's spelling of the instance
+      if (o.kind == Op::CONV && o.conv.async == 2) snprintf(kn, sizeof kn, "k_conv_m<%d,%d,%d,%d,%d,%d,%d>", o.conv.ci, o.conv.nup, o.conv.ct, o.conv.pt, o.conv.fz, o.conv.ncw, o.conv.march.wino);  // rocprofv3's spelling of the instance
       else if (o.kind == Op::CONV && o.conv.async == 4) snprintf(kn, sizeof kn, "k_conv_w<%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt);
       else if (o.kind == Op::CONV && o.conv.async) snprintf(kn, sizeof kn, "k_conv_a<%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt);
       else if (o.kind == Op::CONV && o.conv.bf3) snprintf(kn, sizeof kn, "k_conv_b<%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt);
@@ -1392,7 +1392,7 @@ int drm_debug_conv(int device, const float *in, int D, int H, int W, int Cin, co
     if (march_err) fail(DR_ERR_DEVICE, "k_conv_m: a ring wait gave up (code %d)", march_err);
     if (getenv("DR_CONV_PRINT")) {
       const ConvLaunch &c = P.launches.at(0);
-      fprintf(stderr, "debug_conv: %s<%d,%d,%d> nup %d tile %dx%dx%d lds %zu grid %ux%u (%d candidates)\n", (c.async == 2 ? (c.march.rm ? "rowmarch" : (c.march.wino ? "winomarch" : (c.march.t3 ? "ring" : "march"))) : (c.async == 4 ? "wino" : (c.async ? "async" : (c.bf3 ? "bf16x3" : "sync")))), c.ci, c.ct, c.pt,
+      fprintf(stderr, "debug_conv: %s<%d,%d,%d> nup %d tile %dx%dx%d lds %zu grid %ux%u (%d candidates)\n", (c.async == 2 ? (c.march.rm ? "rowmarch" : (c.march.wino ? "winomarch" : "march")) : (c.async == 4 ? "wino" : (c.async ? "async" : (c.bf3 ? "bf16x3" : "sync")))), c.ci, c.ct, c.pt,
               c.nup, c.args.TZ, c.args.TY, c.args.TXT * 16, c.lds_bytes, c.grid.x, c.grid.z, P.ncand);
     }
     DR_HIP(hipMemcpy(out, d_out, on * 4, hipMemcpyDeviceToHost));

@@ -46,7 +46,7 @@ static bool emulate(const ConvLaunch &c, const float *in, float *out, const floa
             wl[(size_t)e * 64 + lane] = F4{{w.x, w.y, w.z, w.w}};
           }
         // the producer's load list of this pass, in issue order
-        struct Load { int zc, plane, pass, iy0, ix0, iz0; };
+        struct Load { int zc, plane, pass, iy0, ix0; };
         std::vector<Load> loads;
         for (int s = s0; s < s1;) {
           const MarchSeg sg = march_segment(m.geo, s, s1);
@@ -55,8 +55,7 @@ static bool emulate(const ConvLaunch &c, const float *in, float *out, const floa
           for (int l = 0; l < sg.nl; ++l) {
             int plane, pi;
             march_load_plane(m.geo, sg, l, plane, pi);
-            if (m.t3) plane = -a.pz;  // (tile ring: as the producer does)
-            loads.push_back({zc, plane, po * m.geo.NPI + pi, m.rm ? 0 : py0 * a.sy - a.py, px0 * a.sx - a.px, m.t3 ? zc * a.TZ * a.sz - a.pz : 0});
+            loads.push_back({zc, plane, po * m.geo.NPI + pi, m.rm ? 0 : py0 * a.sy - a.py, px0 * a.sx - a.px});
           }
           s += sg.zb - sg.za;
         }
@@ -69,9 +68,9 @@ static bool emulate(const ConvLaunch &c, const float *in, float *out, const floa
             for (int it = 0; it < m.nit; ++it)
               for (int lane = 0; lane < 64; ++lane) {
                 int rel; unsigned yx;
-                march_piece_entry<CI>(a, m, pw, it, lane, rel, yx, m.t3 != 0);
+                march_piece_entry<CI>(a, m, pw, it, lane, rel, yx);
                 F4 v{{0.f, 0.f, 0.f, 0.f}};
-                if (march_piece_inside(a, m, yx, ld.iy0, ld.ix0, ld.iz0, m.t3 != 0)) for (int k = 0; k < 4; ++k) v.v[k] = in[pofs + rel + k];
+                if (march_piece_inside(a, m, yx, ld.iy0, ld.ix0)) for (int k = 0; k < 4; ++k) v.v[k] = in[pofs + rel + k];
                 const size_t dst = (size_t)(i % m.R) * m.PS + (size_t)(it * kMarchProducers + pw) * 64 + lane;
                 if (dst >= ring.size() || (it * kMarchProducers + pw) * 64 + lane >= m.PS) { printf("emul: DMA piece outside its ring slot\n"); return false; }
                 ring[dst] = v;
@@ -109,7 +108,7 @@ static bool emulate(const ConvLaunch &c, const float *in, float *out, const floa
                           F4 gk[3], d[4];
                           for (int k = 0; k < 3; ++k) gk[k] = wl[(size_t)sec * m.wsec + (size_t)((r * 3 + k) * CT + ct) * 64 + lane];
                           for (int q = 0; q < 4; ++q) {
-                            const int slot = conv_a_unit<CI>(march_bpos(a, wave, pt, PT, j, m.t3 != 0) + m.tap2d[r * TPC + sub] + q * a.TXI, c4);
+                            const int slot = conv_a_unit<CI>(march_bpos(a, wave, pt, PT, j) + m.tap2d[r * TPC + sub] + q * a.TXI, c4);
                             if (slot < 0 || slot >= m.PS) { printf("emul: operand slot %d outside the plane (%d slots)\n", slot, m.PS); return false; }
                             d[q] = ring[(size_t)(idx % m.R) * m.PS + slot];
                           }
@@ -138,7 +137,7 @@ static bool emulate(const ConvLaunch &c, const float *in, float *out, const floa
                       for (int lane = 0; lane < 64; ++lane) {
                         const int j = lane & 15, g = lane >> 4, sub = (4 * g) / CI, c4 = ((4 * g) % CI) / 4;
                         av[lane] = wl[(size_t)sec * m.wsec + (size_t)(u * CT + ct) * 64 + lane];
-                        const int slot = conv_a_unit<CI>(march_bpos(a, wave, pt, PT, j, m.t3 != 0) + m.tap2d[u * TPC + sub], c4);
+                        const int slot = conv_a_unit<CI>(march_bpos(a, wave, pt, PT, j) + m.tap2d[u * TPC + sub], c4);
                         if (slot < 0 || slot >= m.PS) { printf("emul: operand slot %d outside the plane (%d slots)\n", slot, m.PS); return false; }
                         bv[lane] = ring[(size_t)(idx % m.R) * m.PS + slot];
                       }
@@ -159,14 +158,14 @@ static bool emulate(const ConvLaunch &c, const float *in, float *out, const floa
               for (int pt = 0; pt < PT; ++pt)
                 for (int lane = 0; lane < 64; ++lane) {
                   const int j = lane & 15, g = lane >> 4;
-                  const int tau = wave * PT + pt, xt = tau % a.TXT, yz = tau / a.TXT, yt = yz % a.TY, zt = yz / a.TY;
+                  const int tau = wave * PT + pt, xt = tau % a.TXT, yt = tau / a.TXT;
                   const int qy = py0 + yt, qx = px0 + xt * 16 + j;
-                  if (qy >= a.nPH || qx >= a.nPW || (m.t3 && zc * a.TZ + zt >= a.nPD)) continue;
+                  if (qy >= a.nPH || qx >= a.nPW) continue;
                   for (int ct = 0; ct < CT; ++ct) {
                     const int c0 = (ct0 + ct) * 16 + 4 * g;
                     if (c0 >= a.rows_valid) continue;
                     for (int ro = 0; ro < (W ? 2 : 1); ++ro) {
-                    const size_t ob = march_out_index(a, m, zc, m.t3 ? zt : z, W ? 2 * qy + ro : qy, qx, c0);
+                    const size_t ob = march_out_index(a, m, zc, z, W ? 2 * qy + ro : qy, qx, c0);
                     for (int r = 0; r < 4; ++r) {
                       const size_t ai = ((((size_t)wave * CT + ct) * PT + pt) * 64 + lane) * 4 + r;
                       float v = acc[ai];
@@ -193,39 +192,38 @@ static bool emulate(const ConvLaunch &c, const float *in, float *out, const floa
   return true;
 }
 
-struct Case { const char *name; int D, H, W, Cin, Cout, kd; bool relu, add; int k = 3, sd = 1, s = 1; };  // k: in-plane kernel size (3 or 5), sd / s: stride along z / in the plane
+struct Case { const char *name; int D, H, W, Cin, Cout, kd; bool relu, add; };
 
 static int run_case(const Case &cs, int max_plans) {
   std::mt19937 rng(1234);
   std::uniform_real_distribution<float> U(-1.f, 1.f);
-  const int K = cs.k, taps = cs.kd * K * K;
+  const int taps = cs.kd * 9;
   std::vector<float> in((size_t)cs.D * cs.H * cs.W * cs.Cin), w((size_t)cs.Cout * cs.Cin * taps), sc(cs.Cout), bi(cs.Cout);
   for (auto &v : in) v = U(rng);
   for (auto &v : w) v = U(rng) * 0.2f;
   for (auto &v : sc) v = 0.5f + 0.5f * std::fabs(U(rng));
   for (auto &v : bi) v = 0.3f * U(rng);
-  const int oD = (cs.D + 2 * (cs.kd / 2) - cs.kd) / cs.sd + 1, oH = (cs.H + 2 * (K / 2) - K) / cs.s + 1, oW = (cs.W + 2 * (K / 2) - K) / cs.s + 1;
-  const size_t on = (size_t)oD * oH * oW * cs.Cout;
+  const size_t on = (size_t)cs.D * cs.H * cs.W * cs.Cout;
   std::vector<float> add(on);
   for (auto &v : add) v = U(rng);
-  // direct convolution (torch Conv2d/Conv3d semantics, zero padding k / 2), channels-last
+  // direct convolution (torch Conv2d/Conv3d semantics, zero padding 1), channels-last
   std::vector<float> ref(on);
-  for (int z = 0; z < oD; ++z) for (int y = 0; y < oH; ++y) for (int x = 0; x < oW; ++x) for (int co = 0; co < cs.Cout; ++co) {
+  for (int z = 0; z < cs.D; ++z) for (int y = 0; y < cs.H; ++y) for (int x = 0; x < cs.W; ++x) for (int co = 0; co < cs.Cout; ++co) {
     double s = 0;
-    for (int tz = 0; tz < cs.kd; ++tz) for (int ty = 0; ty < K; ++ty) for (int tx = 0; tx < K; ++tx) {
-      const int iz = z * cs.sd + tz - cs.kd / 2, iy = y * cs.s + ty - K / 2, ix = x * cs.s + tx - K / 2;
+    for (int tz = 0; tz < cs.kd; ++tz) for (int ty = 0; ty < 3; ++ty) for (int tx = 0; tx < 3; ++tx) {
+      const int iz = z + tz - cs.kd / 2, iy = y + ty - 1, ix = x + tx - 1;
       if (iz < 0 || iz >= cs.D || iy < 0 || iy >= cs.H || ix < 0 || ix >= cs.W) continue;
       for (int ci = 0; ci < cs.Cin; ++ci)
-        s += (double)w[((((size_t)co * cs.Cin + ci) * cs.kd + tz) * K + ty) * K + tx] * in[(((size_t)iz * cs.H + iy) * cs.W + ix) * cs.Cin + ci];
+        s += (double)w[((((size_t)co * cs.Cin + ci) * cs.kd + tz) * 3 + ty) * 3 + tx] * in[(((size_t)iz * cs.H + iy) * cs.W + ix) * cs.Cin + ci];
     }
     double v = s * sc[co] + bi[co];
     if (cs.relu) v = std::max(v, 0.0);
-    if (cs.add) v += add[(((size_t)z * oH + y) * oW + x) * cs.Cout + co];
-    ref[(((size_t)z * oH + y) * oW + x) * cs.Cout + co] = (float)v;
+    if (cs.add) v += add[(((size_t)z * cs.H + y) * cs.W + x) * cs.Cout + co];
+    ref[(((size_t)z * cs.H + y) * cs.W + x) * cs.Cout + co] = (float)v;
   }
   ConvLayer L;
-  L.Cin = cs.Cin; L.Cout = cs.Cout; L.kd = cs.kd; L.kh = K; L.kw = K; L.sd = cs.sd; L.sh = cs.s; L.sw = cs.s; L.weight = w.data(); L.scale = sc; L.bias = bi; L.relu = cs.relu;
-  const ConvMode mode = (cs.Cout == 8 && cs.s == 1) ? CONV_XPAIR : CONV_NORMAL;
+  L.Cin = cs.Cin; L.Cout = cs.Cout; L.kd = cs.kd; L.kh = 3; L.kw = 3; L.weight = w.data(); L.scale = sc; L.bias = bi; L.relu = cs.relu;
+  const ConvMode mode = cs.Cout == 8 ? CONV_XPAIR : CONV_NORMAL;
   int done = 0, fails = 0;
   for (int rank = 0; rank < 400 && done < max_plans; ++rank) {
     DeviceArena arena;
@@ -239,7 +237,7 @@ static int run_case(const Case &cs, int max_plans) {
     double worst = 0;
     for (size_t i = 0; i < on; ++i) worst = std::max(worst, (double)std::fabs(out[i] - ref[i]) / (1.0 + std::fabs(ref[i])));
     const bool pass = ok && worst < 2e-5;
-    printf("%-22s plan %s w=%d ci=%d nup=%d ct=%d pt=%d tile %dx%d R=%d PS=%d NPI=%d NPO=%d grid %ux%u steps %d: %s (max rel err %.2e)\n", cs.name, c.march.rm ? "rows" : (c.march.wino ? "wino" : (c.march.t3 ? "ring" : "tile")), c.ncw, c.ci, c.nup, c.ct, c.pt,
+    printf("%-22s plan %s w=%d ci=%d nup=%d ct=%d pt=%d tile %dx%d R=%d PS=%d NPI=%d NPO=%d grid %ux%u steps %d: %s (max rel err %.2e)\n", cs.name, c.march.rm ? "rows" : (c.march.wino ? "wino" : "tile"), c.ncw, c.ci, c.nup, c.ct, c.pt,
            c.args.TY, c.args.TXT * 16, c.march.R, c.march.PS, c.march.geo.NPI, c.march.NPO, c.grid.x, c.grid.z, c.march.steps, pass ? "ok" : "FAIL", worst);
     ++done;
     if (!pass) ++fails;
@@ -268,11 +266,6 @@ int main(int argc, char **argv) {
       {"rows_32_32", 2, 6, 168, 32, 32, 1, true, false},   // fn.conv2.x: two channel slices per row, two row tiles
       {"rows_32_16", 3, 5, 330, 32, 16, 1, false, false},  // fn.out2
       {"rows_xpair_c32", 1, 11, 520, 32, 8, 1, true, false}, // fn.out3's shape without the fused skip
-      // the tile ring (MarchArgs::t3): strided and 5 x 5 layers, one 3-D halo tile per step
-      {"ring3d_s2_8_16", 6, 20, 40, 8, 16, 3, true, false, 3, 2, 2},      // conv1
-      {"ring3d_s2_8_16_odd", 7, 14, 36, 8, 16, 3, true, false, 3, 2, 2},  // conv1 shape with odd depth, ragged width
-      {"ring2d_5x5_s2_8_16", 3, 22, 50, 8, 16, 1, true, false, 5, 1, 2},  // fn.conv1.0
-      {"ring2d_5x5_s2_16_32", 2, 18, 36, 16, 32, 1, true, false, 5, 1, 2},// fn.conv2.0
   };
   int fails = 0;
   for (const Case &cs : cases) fails += run_case(cs, max_plans);

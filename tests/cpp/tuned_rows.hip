@@ -34,7 +34,7 @@ int main() {
     arena.host_only = true;
     ConvPlanOut P = plan_conv(L, (ConvMode)t.mode, &in, t.inD, t.inH, t.inW, t.Cin, &out, nullptr, 0, arena, 0);
     const ConvLaunch &c = P.launches.at(0);
-    const int async_ = c.async == 2 ? (c.march.rm ? 3 : (c.march.wino ? 5 : (c.march.t3 ? 6 : 2))) : c.async;
+    const int async_ = c.async == 2 ? (c.march.rm ? 3 : (c.march.wino ? 5 : 2)) : c.async;
     const bool live = c.ci == t.ci && c.ct == t.ct && c.pt == t.pt && c.args.TZ == t.tz && c.args.TY == t.ty && c.args.TXT == t.txt && async_ == t.async_;
     if (!live) {
       ++stale;

@@ -237,30 +237,6 @@ def test_winograd_form_is_not_planned_where_it_does_not_apply(monkeypatch, capfd
     assert len(kinds) == 5 and "wino" not in kinds, kinds
 
 
-# ---- the tile ring (conv_march.h MarchArgs::t3): strided and 5 x 5 layers on k_conv_m's producer / consumer ring, one 3-D halo tile per step.
-# DR_CONV_MARCH=2 ranks its candidates first.  Shapes with several steps per workgroup, ragged edges, odd depths.
-RING = [
-    ("ring 3x3x3 s2 8->16", (16, 64, 96), 8, 16, (3, 3, 3), (2, 2, 2), False, True, "none"),
-    ("ring 3x3x3 s2 8->16 odd", (7, 30, 70), 8, 16, (3, 3, 3), (2, 2, 2), False, True, "none"),
-    ("ring 3x3x3 s(1,2,2) 8->16", (3, 40, 64), 8, 16, (3, 3, 3), (1, 2, 2), False, True, "none"),
-    ("ring 5x5 s2 8->16, 7 views", (7, 64, 128), 8, 16, (1, 5, 5), (1, 2, 2), False, True, "none"),
-    ("ring 5x5 s2 16->32, 7 views", (7, 48, 96), 16, 32, (1, 5, 5), (1, 2, 2), False, True, "none"),
-    ("ring 5x5 s2 16->32 ragged", (2, 26, 52), 16, 32, (1, 5, 5), (1, 2, 2), False, True, "none"),
-]
-
-
-@pytest.mark.parametrize("case", RING, ids=[c[0] for c in RING])
-def test_tile_ring_candidates(case, monkeypatch, capfd):
-    monkeypatch.setenv("DR_CONV_MARCH", "2")
-    monkeypatch.setenv("DR_CONV_PRINT", "1")
-    kinds = []
-    for rank in range(10):
-        monkeypatch.setenv("DR_CONV_RANK", str(rank))
-        run_case(case)
-        kinds += [l.split()[1].split("<")[0] for l in capfd.readouterr().err.splitlines() if l.startswith("debug_conv:")]
-    assert kinds and kinds[0] == "ring" and kinds.count("ring") >= 3, kinds
-
-
 # ---- transposed stride-2 layers: the three parity forms (conv_mfma.h axis_classes: dense rows / x dense + (z, y) classes / one class per
 # parity) compute the same layer; every plan candidate of each form.
 DECONV = [c for c in CASES if c[6]] + [

@@ -30,8 +30,7 @@ def test_march_emulation_matches_direct_convolution(march_emul):
     assert len(lines) >= 30 and all(" ok " in l for l in lines), out.stdout[-4000:]
     # every instance family and both pass structures were exercised
     text = out.stdout
-    for needle in ("ci=8 nup=6", "ci=16 nup=12", "ci=16 nup=9", "ct=2", "pt=4", "pt=1", "w=12", "NPI=2", "NPO=2", "rows w=10", "rows w=8", "nup=2", "nup=3", "nup=4",
-                   "plan ring w=4 ci=8 nup=14", "plan ring w=8 ci=8 nup=14", "ring2d_5x5_s2_8_16", "ci=16 nup=25", "ring3d_s2_8_16_odd"):  # the tile ring: strided 3^3 and 5 x 5 layers
+    for needle in ("ci=8 nup=6", "ci=16 nup=12", "ci=16 nup=9", "ct=2", "pt=4", "pt=1", "w=12", "NPI=2", "NPO=2", "rows w=10", "rows w=8", "nup=2", "nup=3", "nup=4"):
         assert needle in text, needle
 
 
