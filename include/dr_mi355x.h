@@ -111,7 +111,8 @@ int drm_comm_init(drm_t *h, int rank, int world, const uint8_t id[128]);
 int drm_comm_destroy(drm_t *h);
 /* Device pointer and element count of a named internal tensor ("volume1".."volume3", "feat1", "depth2", ...) AS IT LIES IN
  * MEMORY: "feat1".."feat3" carry a one-pixel zero border in H and W (the cost-volume kernels read them that way), so for
- * those the pointer is the padded base and *nfloats = V * (H + 2) * (W + 2) * C; drm_get_tensor returns the logical block. */
+ * those the pointer is the padded base and *nfloats = V * (H + 2) * (W + 2) * C; "volume1" (32 channels) is stored as two consecutive
+ * (D, H, W, 16) halves (channels 0-15 | 16-31).  drm_get_tensor returns the logical (D, H, W, C) block in every case. */
 int drm_device_tensor(drm_t *h, const char *name, void **dptr, size_t *nfloats);
 /* Copy the last forward's stage-3 outputs to host (same four arrays as drm_get_result). */
 int drm_download(drm_t *h, float *depth, float *confidence, float *depth_dense, float *confidence_dense);

@@ -89,7 +89,8 @@ DR_HD inline bool march_piece_inside(const ConvArgs &a, const MarchArgs &m, unsi
 }
 // element offset of the tile origin of input plane `plane` of image zc, channel slice `pass` (may be negative: the halo starts outside the tensor)
 DR_HD inline long long march_plane_offset(const ConvArgs &a, const MarchArgs &m, int zc, int plane, int iy0, int ix0, int pass, int CI) {
-  return (long long)zc * m.i_sv + (long long)plane * m.i_sz + (long long)iy0 * m.i_sy + (long long)ix0 * a.inC + (long long)pass * CI;
+  (void)CI;
+  return (long long)zc * m.i_sv + (long long)plane * m.i_sz + (long long)iy0 * m.i_sy + (long long)ix0 * a.inC + (long long)pass * a.pass_stride;
 }
 // weight piece e = (sec * NUP + u) * CT + ct of outer pass po -> float4 index (lane 0) in the packed weight array
 DR_HD inline size_t march_weight_src(const ConvArgs &a, const MarchArgs &m, int po, int e, int NUP, int CT, int ct0) {

@@ -66,6 +66,8 @@ struct ConvArgs {
   // in[v][y][x][c] = (W1 . fz_x[v][y][x][0..FZ) + fz_b)[c] + fz_coarse[v][y/2][x/2][c]   (module.py:517-529)
   const float *fz_x, *fz_w, *fz_b, *fz_coarse;
   // k_conv_a (persistent, LDS-DMA staged) only:
+  int pass_stride;      // input elements between the channel slices of two passes: CI (the slices interleave inside a position's record) or, for an
+                        // input stored as consecutive (D,H,W,CI) sub-tensors (stage 1's cost volume), the size of one sub-tensor
   const float *zero16;  // 16 zero bytes: the source of every staged element outside the tensor
   int a_slots;          // 16-byte LDS slots per tile buffer (multiple of 512)
   int a_wbufs;          // weight buffers: npass when all passes fit (each fetched once per workgroup), else 2 (one per pass in flight)
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(kConvThreads, DR_KCONV_MIN_WAVES(CT, FZ)) void k_co
         v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         dst[k] = e < total ? (int)(pos * CIS + c4 * 4) : -1;
         if (e < total && gz >= 0 && gz < a.inD && gy >= 0 && gy < a.inH && gx >= 0 && gx < a.inW)
-          v[k] = *reinterpret_cast<const float4 *>(a.in + (((size_t)gz * a.inH + gy) * a.inW + gx) * a.inC + p * CI + c4 * 4);
+          v[k] = *reinterpret_cast<const float4 *>(a.in + (((size_t)gz * a.inH + gy) * a.inW + gx) * a.inC + (size_t)p * a.pass_stride + c4 * 4);
       }
 #pragma unroll
       for (int k = 0; k < kStageBatch; ++k)
@@ -519,7 +521,7 @@ __device__ inline void conv_a_issue(const ConvArgs &a, float4 *tile, float4 *wbu
     const int gz = iz0 + (int)z, gy = iy0 + (int)y, gx = ix0 + (int)x;
     const float *src = a.zero16;
     if (pos < NP && gz >= 0 && gz < a.inD && gy >= 0 && gy < a.inH && gx >= 0 && gx < a.inW)
-      src = a.in + (((size_t)gz * a.inH + gy) * a.inW + gx) * a.inC + p * CI + c4 * 4;
+      src = a.in + (((size_t)gz * a.inH + gy) * a.inW + gx) * a.inC + (size_t)p * a.pass_stride + c4 * 4;
     conv_a_dma16(src, __builtin_amdgcn_readfirstlane(conv_a_lds_addr(tile + s0)));
   }
   if (with_weights) {  // packed weights of this pass and row group: [u][CT][64] float4, lane-linear as they are in memory
@@ -935,8 +937,9 @@ inline int conv_async_policy() {
   return 2;
 }
 
+// in_split: 0 = the input is one (D,H,W,inC) tensor; 16 = it is stored as inC / 16 consecutive (D,H,W,16) sub-tensors (only 16-channel passes apply)
 inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in, int inD, int inH, int inW, int inC,
-                             float *out, const float *add, int add_mode, DeviceArena &arena, int rank = 0, const ConvFuse *fz = nullptr) {
+                             float *out, const float *add, int add_mode, DeviceArena &arena, int rank = 0, const ConvFuse *fz = nullptr, int in_split = 0) {
   // rank: which candidate of the cost model's ranking to build (0 = its choice); used by the engine's autotuner
   if (L.Cin % 4 != 0 || inC < L.Cin) fail(DR_ERR_ARG, "plan_conv: Cin=%d must be a multiple of 4 (tensor C=%d)", L.Cin, inC);
   const int form = L.transposed ? conv_deconv_form(L.Cout) : 0;
@@ -1203,6 +1206,10 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
       }
     }
   }
+  if (in_split) {
+    if (in_split != 16 || fz || bf3 || L.Cin % 16) fail(DR_ERR_ARG, "plan_conv: a split input has 16-channel sub-tensors and plain fp32 staging");
+    cands.erase(std::remove_if(cands.begin(), cands.end(), [](const Cand &c) { return c.ci != 16; }), cands.end());
+  }
   if (!cands.empty()) {
     std::stable_sort(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) { return a.cost < b.cost; });
     if (!getenv("DR_CONV_NO_TUNED")) {  // a measured plan for exactly this layer swaps places with the cost model's first choice -- for EVERY rank, so that the
@@ -1338,7 +1345,9 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   a.in = in; a.out = out; a.wpk = reinterpret_cast<const float4 *>(arena.upload(pk));
   a.scale = arena.upload(sc); a.bias = arena.upload(bi); a.add = add; a.tapoff = arena.upload(tapoff);
   a.cls = arena.upload(cls);
-  a.inD = inD; a.inH = inH; a.inW = inW; a.inC = inC;
+  a.inD = inD; a.inH = inH; a.inW = inW; a.inC = in_split ? in_split : inC;
+  a.pass_stride = in_split ? (int)((size_t)inD * inH * inW * in_split) : CI;
+  if (in_split && (size_t)inD * inH * inW * in_split >= (1ull << 31)) fail(DR_ERR_ARG, "plan_conv: split input too large");
   a.outD = R.outD; a.outH = R.outH + 2 * L.out_pad; a.outW = outWv; a.outC = outCv;
   if (L.out_pad) {  // bordered output: only the strides change (the x border is a whole number of XPAIR / X8 output groups or the mode is refused)
     if ((2 * L.out_pad) % shifts) fail(DR_ERR_ARG, "plan_conv: an output border of %d pixels does not fit the %d-wide output groups", L.out_pad, shifts);

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(kConvThreads, (CT * PT == 1 ? 4 : (CT * PT == 2 ? 3
         v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         dst[k] = e < total ? (int)(pos * CIS + c4 * 4) : -1;
         if (e < total && gz >= 0 && gz < a.inD && gy >= 0 && gy < a.inH && gx >= 0 && gx < a.inW)
-          v[k] = *reinterpret_cast<const float4 *>(a.in + (((size_t)gz * a.inH + gy) * a.inW + gx) * a.inC + p * CI + c4 * 4);
+          v[k] = *reinterpret_cast<const float4 *>(a.in + (((size_t)gz * a.inH + gy) * a.inW + gx) * a.inC + (size_t)p * a.pass_stride + c4 * 4);
       }
 #pragma unroll
       for (int k = 0; k < kStageBatch; ++k)

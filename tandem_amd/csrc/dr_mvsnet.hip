@@ -105,6 +105,7 @@ struct DevTensor {
   float *d = nullptr;
   int D = 0, H = 0, W = 0, C = 0;
   int pad = 0;  // zero border (pixels) around every H x W plane in memory; H and W stay the logical size
+  int split = 0;  // 16: stored as C / 16 consecutive (D,H,W,16) sub-tensors (stage 1's cost volume: each 16-channel pass of conv0 then reads whole records)
   size_t n() const { return (size_t)D * (H + 2 * pad) * (W + 2 * pad) * C; }         // floats in memory
   float *interior() const { return d + ((size_t)pad * (W + 2 * pad) + pad) * C; }    // first logical pixel
 };
@@ -192,6 +193,7 @@ struct MvsSwitches {
   bool costvol_v3 = on("DR_COSTVOL_V3");                 // k_costvol3 (global gathers; the fallback of the LDS-staged k_costvol4 for partial tiles / plain-variance models) everywhere
   bool regress_generic = on("DR_REGRESS_GENERIC");       // k_regress (the fallback for other plane counts) everywhere
   bool shard_allreduce = on("DR_SHARD_ALLREDUCE");       // view shard: round 2's all-reduce form instead of reduce + broadcast
+  bool vol_split = !on("DR_VOL_NO_SPLIT");               // stage 1's 32-channel cost volume as two 16-channel halves (DevTensor::split); off: one (D,h,w,32) tensor (A/B)
 #ifdef DR_PARITY_HOOKS
   bool costvol_v1 = on("DR_COSTVOL_V1");                 // round 2's k_costvol on unpadded feature maps
   int costvol_cpl = num("DR_COSTVOL_CPL", 4) == 8 ? 8 : 4;
@@ -507,7 +509,11 @@ class MvsEngine {
       if (logical > n_max) fail(DR_ERR_ARG, "get_tensor(%s): need %zu floats, have %zu", name, logical, n_max);
       DR_HIP(hipStreamSynchronize(stream_));
       check_march();
-      if (!t.pad) DR_HIP(hipMemcpy(out, t.d, logical * 4, hipMemcpyDeviceToHost));
+      if (t.split) {  // split tensor: sub-tensor k, strided into channels [k * split, (k + 1) * split) of the logical (D, H, W, C) block
+        const size_t npos = (size_t)t.D * t.H * t.W;
+        for (int k = 0; k < t.C / t.split; ++k)
+          DR_HIP(hipMemcpy2D(out + (size_t)k * t.split, (size_t)t.C * 4, t.d + (size_t)k * npos * t.split, (size_t)t.split * 4, (size_t)t.split * 4, npos, hipMemcpyDeviceToHost));
+      } else if (!t.pad) DR_HIP(hipMemcpy(out, t.d, logical * 4, hipMemcpyDeviceToHost));
       else  // bordered tensor: the caller gets the logical (D, H, W, C) block
         for (int z = 0; z < t.D; ++z)
           DR_HIP(hipMemcpy2D(out + (size_t)z * t.H * t.W * t.C, (size_t)t.W * t.C * 4, t.interior() + (size_t)z * (t.H + 2 * t.pad) * (t.W + 2 * t.pad) * t.C,
@@ -698,16 +704,16 @@ class MvsEngine {
     ConvFuse fzc{};
     if (fz) fzc = *fz;
     const bool fused = fz != nullptr;
-    ConvPlanOut P = plan_conv(L, mode, in.d, in.D, in.H, in.W, in.C, out.interior(), add_d, add_mode, *plan_arena_, 0, fz);
+    ConvPlanOut P = plan_conv(L, mode, in.d, in.D, in.H, in.W, in.C, out.interior(), add_d, add_mode, *plan_arena_, 0, fz, in.split);
     // the autotuner re-plans this layer with another candidate of the cost model's ranking (weights are kept alive)
     auto keep = std::make_shared<std::vector<float>>(L.weight, L.weight + (size_t)L.Cout * L.Cin * k3d * kh * kw);
     ConvLayer Lc = L;
     const float *in_d = in.d;
     float *out_d = out.interior();
-    const int iD = in.D, iH = in.H, iW = in.W, iC = in.C, ncand = P.ncand;
-    auto replan = [this, keep, Lc, mode, in_d, iD, iH, iW, iC, out_d, add_d, add_mode, fzc, fused](int rank) mutable {
+    const int iD = in.D, iH = in.H, iW = in.W, iC = in.C, iS = in.split, ncand = P.ncand;
+    auto replan = [this, keep, Lc, mode, in_d, iD, iH, iW, iC, iS, out_d, add_d, add_mode, fzc, fused](int rank) mutable {
       Lc.weight = keep->data();
-      return plan_conv(Lc, mode, in_d, iD, iH, iW, iC, out_d, add_d, add_mode, *plan_arena_, rank, fused ? &fzc : nullptr).launches.at(0);
+      return plan_conv(Lc, mode, in_d, iD, iH, iW, iC, out_d, add_d, add_mode, *plan_arena_, rank, fused ? &fzc : nullptr, iS).launches.at(0);
     };
     int idx = 0;
     for (auto &cl : P.launches) {
@@ -841,6 +847,7 @@ class MvsEngine {
       if (!(D == 4 || D % 8 == 0)) fail(DR_ERR_UNSUPPORTED, "depth_num[%d]=%d must be 4 or a multiple of 8", s - 1, D);
       const std::string S = std::to_string(s), cr = "cost_regularization_net.stage" + S + ".", pre = "s" + S + ".";
       DevTensor &vol = alloc("volume" + S, D, h, w, C);
+      if (C == 32 && sw_.vol_split && !conv_bf3_policy()) vol.split = 16;  // (the bf16 x 3 mode stages through its own kernel: one tensor)
       {
         Op o; o.kind = Op::COSTVOL; o.stage = s; o.name = pre + "costvol";
         o.bytes = 4.0 * ((double)V * h * w * C + vol.n());
@@ -949,6 +956,7 @@ class MvsEngine {
       a.feat = T("feat" + std::to_string(s)).d;
       a.fpad = T("feat" + std::to_string(s)).pad;
       a.vol = T("volume" + std::to_string(s)).d;
+      a.split = T("volume" + std::to_string(s)).split;
       a.V = V; a.h = h; a.w = w;
       a.dchunk = s == 1 ? 4 : (D >= 16 ? 8 : D);  // enough workgroups to fill 256 CUs at every stage
       if (sw_.cv_dchunk[s - 1] > 0) a.dchunk = std::min(D, sw_.cv_dchunk[s - 1]);  // tuning hook

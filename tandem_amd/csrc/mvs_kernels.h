@@ -136,7 +136,17 @@ struct CostVolArgs {
   int view_aggregation;
   int gx, gz, nwg;       // workgroup grid: x-blocks per row, depth chunks, total (rows = nwg / (gx * gz))
   int fpad;              // k_costvol2: the feature maps carry a zero border of this many pixels (1)
+  int split;             // 16: the 32-channel volume of stage 1 is stored as TWO (D,h,w,16) halves one after the other (channels 0-15 | 16-31), so
+                         // that each 16-channel pass of conv0 reads whole 64-byte records instead of half of every 128-byte one; 0: (D,h,w,C)
 };
+// float index of channel ch (a multiple of 4) of voxel `vox` = (d * h + y) * w + x in the volume
+template <int C>
+__device__ __forceinline__ size_t cv_vol_index(const CostVolArgs &a, size_t vox, int ch) {
+  if constexpr (C == 32) {
+    if (a.split) return (size_t)(ch >> 4) * ((size_t)a.planes.D * a.h * a.w * 16) + vox * 16 + (ch & 15);
+  }
+  return vox * C + ch;
+}
 
 __device__ inline float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
@@ -253,7 +263,7 @@ __global__ __launch_bounds__(256) void k_costvol(const CostVolArgs a) {
         const float4 mu = make_float4(s1[i].x / inv_n, s1[i].y / inv_n, s1[i].z / inv_n, s1[i].w / inv_n);
         o = make_float4(o.x - mu.x * mu.x, o.y - mu.y * mu.y, o.z - mu.z * mu.z, o.w - mu.w * mu.w);
       }
-      if (live) *reinterpret_cast<float4 *>(a.vol + ((size_t)d * h * w + (size_t)y * w + x) * C + q * CPL + 4 * i) = o;
+      if (live) *reinterpret_cast<float4 *>(a.vol + cv_vol_index<C>(a, (size_t)d * h * w + (size_t)y * w + x, q * CPL + 4 * i)) = o;
     }
   }
 }
@@ -370,7 +380,7 @@ __global__ __launch_bounds__(256) void k_costvol2(const CostVolArgs a) {
         const float4 mu = make_float4(s1.x * rcp_n, s1.y * rcp_n, s1.z * rcp_n, s1.w * rcp_n);
         o4 = make_float4(__builtin_fmaf(-mu.x, mu.x, o4.x), __builtin_fmaf(-mu.y, mu.y, o4.y), __builtin_fmaf(-mu.z, mu.z, o4.z), __builtin_fmaf(-mu.w, mu.w, o4.w));
       }
-      if (live) *reinterpret_cast<float4 *>(a.vol + ((size_t)d * h * w + (size_t)y * w + x) * C + q * 4) = o4;
+      if (live) *reinterpret_cast<float4 *>(a.vol + cv_vol_index<C>(a, (size_t)d * h * w + (size_t)y * w + x, q * 4)) = o4;
     }
   };
   const int n = (d1 - d0) * nsrc;
@@ -480,7 +490,7 @@ __global__ __launch_bounds__(256) void k_costvol3(const CostVolArgs a) {
         const float4 mu = make_float4(s1.x * rcp_n, s1.y * rcp_n, s1.z * rcp_n, s1.w * rcp_n);
         o4 = make_float4(__builtin_fmaf(-mu.x, mu.x, o4.x), __builtin_fmaf(-mu.y, mu.y, o4.y), __builtin_fmaf(-mu.z, mu.z, o4.z), __builtin_fmaf(-mu.w, mu.w, o4.w));
       }
-      if (live) *reinterpret_cast<float4 *>(a.vol + ((size_t)d * h * w + (size_t)y * w + x) * C + q * 4) = o4;
+      if (live) *reinterpret_cast<float4 *>(a.vol + cv_vol_index<C>(a, (size_t)d * h * w + (size_t)y * w + x, q * 4)) = o4;
     }
   };
   const int n = (d1 - d0) * nsrc;  // a multiple of LPB (host)
@@ -686,7 +696,7 @@ __global__ __launch_bounds__(256) void k_costvol4(const CostVolArgs a) {
 #pragma unroll
         for (int j = 0; j < SP; ++j) {
           const float4 o4 = make_float4(acc[j].x * rcp_n, acc[j].y * rcp_n, acc[j].z * rcp_n, acc[j].w * rcp_n);
-          *reinterpret_cast<float4 *>(a.vol + ((size_t)(d0 + g * SP + j) * h * w + (size_t)y * w + x) * C + q * 4) = o4;
+          *reinterpret_cast<float4 *>(a.vol + cv_vol_index<C>(a, (size_t)(d0 + g * SP + j) * h * w + (size_t)y * w + x, q * 4)) = o4;
           acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
@@ -697,7 +707,7 @@ __global__ __launch_bounds__(256) void k_costvol4(const CostVolArgs a) {
     }
   } else {  // (no source view on this rank: the host zeroes the volume instead of launching; kept for completeness)
     for (int i = 0; i < DCH; ++i)
-      *reinterpret_cast<float4 *>(a.vol + ((size_t)(d0 + i) * h * w + (size_t)y * w + x) * C + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4 *>(a.vol + cv_vol_index<C>(a, (size_t)(d0 + i) * h * w + (size_t)y * w + x, q * 4)) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 
