@@ -88,53 +88,6 @@ __device__ inline void conv_load_affine(const ConvArgs &a, int g, int ct0, float
 // The residual / upsample-add operand is FETCHED FOR A GROUP OF UP TO FOUR (position tile, row tile) entries before the first store of the
 // group: `add` and `out` may alias (the folded stage-3 head adds in place), so hipcc keeps every load behind the store before it, and the
 // per-entry form paid one exposed memory round trip per entry (load, wait, store, load, wait, store ... in the ISA of every add layer).
-// One entry's output index (and, through `ab`, the index of its residual operand); false: the entry lies outside the tensor / the valid rows.
-template <int CT, int PT>
-__device__ inline bool conv_entry_index(const ConvArgs &a, const ConvClass &cls, int e, int wave, int j, int g, int ct0, int pz0, int py0, int px0, size_t &ob, size_t &ab) {
-  const int pt = e / CT, ct = e - pt * CT;
-  const int tau = wave * PT + pt;
-  const int xt = tau % a.TXT, yt = (tau / a.TXT) % a.TY, zt = tau / (a.TXT * a.TY);
-  const int qz = pz0 + zt, qy = py0 + yt, qx = px0 + xt * 16 + j;
-  const int c0 = (ct0 + ct) * 16 + 4 * g;
-  int oz = qz * a.omz + cls.ooz, oy = qy * a.omy + cls.ooy, ox = qx * a.omx + cls.oox, ch = c0;
-  if (a.par_rows) {
-    const int q = c0 / a.par_rows, bits = (a.par_map >> (3 * q)) & 7;
-    ch = c0 - q * a.par_rows;
-    oz += (bits >> 2) & 1; oy += (bits >> 1) & 1; ox += bits & 1;
-  }
-  ob = (((size_t)oz * a.outH + oy) * a.outW + ox) * a.outC + ch;
-  ab = ob;
-  if (a.add_mode == 2) ab = (((size_t)oz * a.addH + (oy >> 1)) * a.addW + (ox >> 1)) * a.outC + ch;
-  return qz < a.nPD && qy < a.nPH && qx < a.nPW && c0 < a.rows_valid;
-}
-// k_conv_r: the residual operands of a workgroup's entries are requested BEFORE its tile is staged (their addresses depend on the tile's origin only):
-// the round trip runs beside the staging and the K loop instead of in front of the stores.  Four registers per entry, held through the K loop.
-template <int CT, int PT>
-__device__ inline void conv_prefetch_add(const ConvArgs &a, const ConvClass &cls, float4 (&r)[CT * PT], int wave, int j, int g, int ct0, int pz0, int py0, int px0) {
-#pragma unroll
-  for (int e = 0; e < CT * PT; ++e) {
-    size_t ob, ab;
-    const bool ok = conv_entry_index<CT, PT>(a, cls, e, wave, j, g, ct0, pz0, py0, px0, ob, ab);
-    r[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ok) r[e] = *reinterpret_cast<const float4 *>(a.add + ab);
-  }
-}
-template <int CT, int PT>
-__device__ inline void conv_epilogue_pre(const ConvArgs &a, const ConvClass &cls, floatx4 (&acc)[CT][PT], const float4 (&scv)[CT], const float4 (&biv)[CT],
-                                         const float4 (&r)[CT * PT], int wave, int j, int g, int ct0, int pz0, int py0, int px0) {
-#pragma unroll
-  for (int e = 0; e < CT * PT; ++e) {
-    const int pt = e / CT, ct = e - pt * CT;
-    size_t ob, ab;
-    if (!conv_entry_index<CT, PT>(a, cls, e, wave, j, g, ct0, pz0, py0, px0, ob, ab)) continue;
-    const float4 sc = scv[ct], bi = biv[ct];
-    float4 v;
-    v.x = acc[ct][pt][0] * sc.x + bi.x; v.y = acc[ct][pt][1] * sc.y + bi.y; v.z = acc[ct][pt][2] * sc.z + bi.z; v.w = acc[ct][pt][3] * sc.w + bi.w;
-    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    v.x += r[e].x; v.y += r[e].y; v.z += r[e].z; v.w += r[e].w;
-    *reinterpret_cast<float4 *>(a.out + ob) = v;
-  }
-}
 // ADD = false: the instantiation for layers without a residual operand -- no load and therefore no s_waitcnt vmcnt in it (k_conv_a issues the next
 // unit's DMA before it: a counter wait here would wait for those older pieces as well).
 template <int CT, int PT, bool ADD = true>
@@ -338,8 +291,8 @@ __device__ inline unsigned conv_a_lds_addr(const void *p) {
 #else
 #define DR_KCONV_MIN_WAVES(CT, FZ) ((CT) == 1 && (FZ) == 0 ? 4 : 1)
 #endif
-template <int CI, int CT, int PT, int FZ, bool PRE>
-__device__ __forceinline__ void conv_body(const ConvArgs &a) {
+template <int CI, int CT, int PT, int FZ = 0>
+__global__ __launch_bounds__(kConvThreads, DR_KCONV_MIN_WAVES(CT, FZ)) void k_conv(const ConvArgs a) {
   extern __shared__ float4 lds4[];
   float *lds = reinterpret_cast<float *>(lds4);
   constexpr int CIS = CI + 4;  // LDS floats per staged position (+4: spreads b128 reads over bank slots)
@@ -375,9 +328,6 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a) {
   for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-  float4 radd[PRE ? CT * PT : 1];
-  if constexpr (PRE) conv_prefetch_add<CT, PT>(a, cls, radd, wave, j, g, ct0, pz0, py0, px0);
 
   const int NP = a.TZI * a.TYI * a.TXI, NU = cls.NU;
   // tap table of this class -> LDS (pre-multiplied by the position stride) so the K loop has no dependent global load
@@ -529,15 +479,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a) {
 
   float4 scv[CT], biv[CT];
   conv_load_affine<CT>(a, g, ct0, scv, biv);
-  if constexpr (PRE) conv_epilogue_pre<CT, PT>(a, cls, acc, scv, biv, radd, wave, j, g, ct0, pz0, py0, px0);
-  else conv_epilogue<CT, PT>(a, cls, acc, scv, biv, wave, j, g, ct0, pz0, py0, px0);
+  conv_epilogue<CT, PT>(a, cls, acc, scv, biv, wave, j, g, ct0, pz0, py0, px0);
 }
-template <int CI, int CT, int PT, int FZ = 0>
-__global__ __launch_bounds__(kConvThreads, DR_KCONV_MIN_WAVES(CT, FZ)) void k_conv(const ConvArgs a) { conv_body<CI, CT, PT, FZ, false>(a); }
-// the same kernel for layers WITH a residual operand (a.add_mode != 0), one-row-tile instances: the operands are prefetched (conv_prefetch_add); three waves
-// per SIMD (168 registers) instead of four, which is what the 34-43 KB tiles of the transposed layers allow anyway
-template <int CI, int PT>
-__global__ __launch_bounds__(kConvThreads, 3) void k_conv_r(const ConvArgs a) { conv_body<CI, 1, PT, 0, true>(a); }
 
 #include "conv_bf3.h"  // k_conv_b: k_conv on the bf16 matrix cores with three-term split operands (opt-in)
 
@@ -773,7 +716,6 @@ struct ConvLaunch {
   int nup = 0;    // k_conv_m: K chunks per input plane
   int ncw = 8;    // k_conv_m: consumer waves (8 or 12)
   int bf3 = 0;    // 1: k_conv_b (bf16 x 3 operands; wpk holds hi / lo bf16 fragments, 32-wide K chunks)
-  int rpre = 0;   // 1: k_conv launches of this layer use k_conv_r (residual operands prefetched) when the layer has one
   dim3 grid;
   size_t lds_bytes;
   double flops;  // useful (algorithmic) flops of this launch
@@ -1435,7 +1377,6 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   a.nuMax = nu_max;
   cl.lds_bytes = (size_t)TZI * TYI * TXI * CIS * 4 + (size_t)nu_max * CT * (bf3 ? 2048 : 1024) + (size_t)nu_max * TPC * 4 + 64;
   cl.bf3 = bf3 ? 1 : 0;
-  cl.rpre = getenv("DR_CONV_NO_RPRE") ? 0 : 1;
   a.zero16 = nullptr; a.a_slots = 0; a.a_wbufs = 1;
   if (ASYNC == 4) cl.async = 4;  // (k_conv's LDS layout and grid: the tile, nuMax weight chunks, the tap table)
   if (ASYNC == 1) {
@@ -1512,12 +1453,6 @@ inline void launch_conv_inst(const ConvLaunch &c, hipStream_t st) {
   static std::atomic<unsigned long long> done{0};  // bit d: set on device d
   conv_allow_big_lds(reinterpret_cast<const void *>(&k_conv<CI, CT, PT, FZ>), done, c.lds_bytes);
   hipLaunchKernelGGL((k_conv<CI, CT, PT, FZ>), c.grid, dim3(kConvThreads), c.lds_bytes, st, c.args);
-}
-template <int CI, int PT>
-inline void launch_conv_r_inst(const ConvLaunch &c, hipStream_t st) {
-  static std::atomic<unsigned long long> done{0};
-  conv_allow_big_lds(reinterpret_cast<const void *>(&k_conv_r<CI, PT>), done, c.lds_bytes);
-  hipLaunchKernelGGL((k_conv_r<CI, PT>), c.grid, dim3(kConvThreads), c.lds_bytes, st, c.args);
 }
 template <int CI, int CT, int PT>
 inline void launch_conv_b_inst(const ConvLaunch &c, hipStream_t st) {
@@ -1616,12 +1551,6 @@ inline void launch_conv(const ConvLaunch &c, hipStream_t st) {
     return;
   }
 #endif
-  // layers with a residual operand on the one-row-tile instances: the prefetching twin (DR_CONV_NO_RPRE=1 at plan time keeps them on k_conv: A/B hook)
-  if (c.args.add_mode && c.ct == 1 && (c.ci == 8 || c.ci == 16) && c.rpre) {
-    if (c.ci == 16) { if (c.pt == 4) launch_conv_r_inst<16, 4>(c, st); else launch_conv_r_inst<16, 1>(c, st); }
-    else { if (c.pt == 4) launch_conv_r_inst<8, 4>(c, st); else launch_conv_r_inst<8, 1>(c, st); }
-    return;
-  }
 #define DR_CONV_CASE(CI_, CT_)                                                  \
   if (c.ci == CI_ && c.ct == CT_) {                                             \
     if (c.pt == 4) launch_conv_inst<CI_, CT_, 4>(c, st);                        \

@@ -542,7 +542,6 @@ class MvsEngine {
       else if (o.kind == Op::CONV && o.conv.async == 4) snprintf(kn, sizeof kn, "k_conv_w<%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt);
       else if (o.kind == Op::CONV && o.conv.async) snprintf(kn, sizeof kn, "k_conv_a<%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt);
       else if (o.kind == Op::CONV && o.conv.bf3) snprintf(kn, sizeof kn, "k_conv_b<%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt);
-      else if (o.kind == Op::CONV && o.conv.args.add_mode && o.conv.ct == 1 && o.conv.ci >= 8 && o.conv.rpre && !o.conv.fz) snprintf(kn, sizeof kn, "k_conv_r<%d,%d>", o.conv.ci, o.conv.pt);
       else if (o.kind == Op::CONV) snprintf(kn, sizeof kn, "k_conv<%d,%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt, o.conv.fz);
       else if (o.kind == Op::COSTVOL) {
         const CostVolArgs &ca = cv_[o.stage - 1];
