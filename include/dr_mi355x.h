@@ -220,6 +220,10 @@ int drf_bench_integrate(drf_t *h, const void *d_bgr, const void *d_depth, const 
  * render stream from the frame's pose with the D2H of its result.  ms[0] whole run (hipEvents), ms[1..4] sums of the
  * allocate / integrate / ray-cast / D2H intervals, ms[5] host wall clock. */
 int drf_bench_sequence(drf_t *h, const void *d_bgr, const void *d_depth, const float *poses16, int nframes, int render, float ms[6]);
+/* Test hook: host pointers (page-locked, library-owned) of the last (back = 0) / second-to-last (back = 1) render of `stream` written by
+ * drf_bench_sequence.  In that loop the allocation of scan k + 1 runs beside the ray-cast of scan k (a device-resident sequence is the only
+ * caller that reaches this overlap: through the operator API GetRenderResult(k) returns before IntegrateScanAsync(k + 1) is called). */
+int drf_bench_render_host(drf_t *h, int stream, int back, const uint8_t **bgr, const float **depth);
 
 /* ======================================================================================================
  * DrCoarseTracker -- the dense coarse tracker operator.  Replaces

@@ -937,7 +937,8 @@ inline int conv_async_policy() {
   return 2;
 }
 
-// in_split: 0 = the input is one (D,H,W,inC) tensor; 16 = it is stored as inC / 16 consecutive (D,H,W,16) sub-tensors (only 16-channel passes apply)
+// in_split: 0 = the input is one (D,H,W,inC) tensor; 16 = it is stored as inC / 16 consecutive (D,H,W,16) sub-tensors (only 16-channel passes apply;
+// a tuned row of such a layer carries mode + 16: plans measured in one layout are never applied to the other)
 inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in, int inD, int inH, int inW, int inC,
                              float *out, const float *add, int add_mode, DeviceArena &arena, int rank = 0, const ConvFuse *fz = nullptr, int in_split = 0) {
   // rank: which candidate of the cost model's ranking to build (0 = its choice); used by the engine's autotuner
@@ -1016,6 +1017,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   const int policy = (fz || bf3) ? 0 : conv_async_policy();
   if (policy >= 1 && ncls == 1) {  // k_conv_a: 8 waves, 8*pt position tiles per workgroup, two tile buffers
     for (int ci : {16, 8, 4}) {
+      if (in_split && ci != in_split) continue;  // a split input only has 16-channel passes
       if (L.Cin % ci || (ci == 4 && L.Cin != 4)) continue;
       const int npass = L.Cin / ci, tpc = 16 / ci, nu = cdiv(classes[0].ntaps, tpc);
       if (npass > 2 && (npass & 1)) continue;  // weight buffers alternate with the pass parity
@@ -1054,6 +1056,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   const int march_ntp = march_ok ? 3 * (int)cx[0].t.size() : 0;  // taps per input plane
   if (march_ok) {
     for (int ci : {16, 8}) {
+      if (in_split && ci != in_split) continue;  // a split input only has 16-channel passes
       if (ci == 8 && L.Cin != 8) continue;
       for (int ncw : {8, 12})
       for (int pt : {1, 2, 4})
@@ -1081,6 +1084,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   if (march_ok && wino_policy_m >= 1 && L.kd == 3 && (R.outH & 1) == 0 && R.outH >= 2) {
     const int nPHw = R.outH / 2;
     for (int ci : {16, 8}) {
+      if (in_split && ci != in_split) continue;  // a split input only has 16-channel passes
       if (ci == 8 && L.Cin != 8) continue;
       for (int ncw : {8})
         for (int ty = 1; ty <= ncw; ++ty) {
@@ -1104,6 +1108,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   const int row_ntp = rowmarch_ok ? (int)cx[0].t.size() : 0;  // x taps of one row
   if (rowmarch_ok) {
     for (int ci : {16, 8}) {
+      if (in_split && ci != in_split) continue;  // a split input only has 16-channel passes
       if (ci == 8 && L.Cin != 8) continue;
       for (int ncw : {8, 10})
         for (int pt : {1, 2, 4}) {
@@ -1132,6 +1137,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
     static const int cand8[][3] = {{1, 1, 8}, {1, 2, 4}, {1, 4, 2}, {1, 8, 1}, {2, 1, 4}, {2, 2, 2}, {2, 4, 1}, {4, 1, 2}, {4, 2, 1}, {8, 1, 1}};
     const int nPHw = R.outH / 2, ntw = (int)(cz[0].t.size() * cx[0].t.size());
     for (int ci : {16, 8}) {
+      if (in_split && ci != in_split) continue;  // a split input only has 16-channel passes
       if (L.Cin % ci || (ci == 8 && L.Cin != 8)) continue;
       const int npass = L.Cin / ci, tpc = 16 / ci, nr = cdiv(ntw, tpc);
       for (int pt : {2, 1}) {
@@ -1170,6 +1176,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   }
   const bool sync_too = policy != 1 || cands.empty();
   for (int ci : {16, 8, 4}) {
+    if (in_split && ci != in_split) continue;  // a split input only has 16-channel passes
     if (!sync_too) break;
     if (L.Cin % ci || (ci == 4 && L.Cin != 4)) continue;
     if (fz && ci != 16) continue;  // fused-skip instances exist for 16-channel passes, one row tile
@@ -1208,7 +1215,6 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   }
   if (in_split) {
     if (in_split != 16 || fz || bf3 || L.Cin % 16) fail(DR_ERR_ARG, "plan_conv: a split input has 16-channel sub-tensors and plain fp32 staging");
-    cands.erase(std::remove_if(cands.begin(), cands.end(), [](const Cand &c) { return c.ci != 16; }), cands.end());
   }
   if (!cands.empty()) {
     std::stable_sort(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) { return a.cost < b.cost; });
@@ -1216,7 +1222,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
                                         // ranks stay a permutation of the candidates (the autotuner used to never time the model's own first choice of a tuned layer)
       for (const ConvTuned &t : kConvTuned) {
         if (t.Cin != L.Cin || t.Cout != L.Cout || t.kd != L.kd || t.kh != L.kh || t.kw != L.kw || t.sd != L.sd || t.sh != L.sh || t.sw != L.sw ||
-            t.transposed != (L.transposed ? 1 : (L.up2 ? 1 + L.up2 : 0)) || t.mode != (int)mode || t.inD != inD || t.inH != inH || t.inW != inW) continue;
+            t.transposed != (L.transposed ? 1 : (L.up2 ? 1 + L.up2 : 0)) || t.mode != (int)mode + (in_split ? 16 : 0) || t.inD != inD || t.inH != inH || t.inW != inW) continue;
         for (size_t i = 0; i < cands.size(); ++i) {
           const Cand &k = cands[i];
           if (k.ci == t.ci && k.ct == t.ct && k.pt == t.pt && k.tz == t.tz && k.ty == t.ty && k.txt == t.txt && k.async == t.async_) { std::swap(cands[0], cands[i]); break; }

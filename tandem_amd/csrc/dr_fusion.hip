@@ -195,7 +195,7 @@ __device__ inline int find_block_table(const FusionDev &d, I3 p) {  // blocks ou
   unsigned s = hash_key(key) & d.cmask;
   for (unsigned probe = 0; probe <= d.cmask; ++probe) {
     const unsigned long long cur = d.keys[s];
-    if (cur == key) return d.vals[s];
+    if (cur == key) return __hip_atomic_load(&d.vals[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // -1 while the inserting lane has not stored the pool index yet (vals starts at -1)
     if (cur == kEmptyKey) return -1;
     s = (s + 1) & d.cmask;
   }
@@ -227,9 +227,9 @@ __device__ inline void allocate_block_table(const FusionDev &d, I3 p) {
       cur = atomicCAS(&d.keys[s], kEmptyKey, key);
       if (cur == kEmptyKey) {  // we own the slot: take a pool block
         const int idx = atomicAdd(d.n_alloc, 1);
-        if (idx >= d.o.num_blocks) { d.err[0] = 1; d.vals[s] = -1; return; }
-        d.vals[s] = idx;
+        if (idx >= d.o.num_blocks) { d.err[0] = 1; return; }  // (vals[s] stays -1: the key is there, the block is not)
         d.blk_key[idx] = key;
+        __hip_atomic_store(&d.vals[s], idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // readers in OTHER kernels see -1 or idx, never garbage
         atomicAdd(&d.n_alloc[3], 1);  // blocks living in the table (outside the dense grid)
         return;
       }
@@ -1126,6 +1126,10 @@ class FusionEngine {
     d_.o = o;
     d_.keys = dalloc<unsigned long long>(cap);
     d_.vals = dalloc<int>(cap);
+    // -1 everywhere: an insert publishes the key (CAS) BEFORE it stores the pool index, so a concurrent reader -- the ray-cast of scan k
+    // beside the allocation of scan k + 1 (enqueue_scan) -- may match a key whose value is not there yet; it then reads -1 = absent, which
+    // is the state the block was in a moment ago (its voxels are still all unobserved: the same ray-cast result either way)
+    DR_HIP(hipMemsetAsync(d_.vals, 0xFF, cap * sizeof(int), int_stream_));
     d_.cmask = (unsigned)(cap - 1);
     d_.blk_key = dalloc<unsigned long long>(o.num_blocks);
     d_.vox = dalloc<Voxel>((size_t)o.num_blocks * 512);
@@ -1291,6 +1295,17 @@ class FusionEngine {
     if (next_ != kIntegrate) fail(DR_ERR_PROTOCOL, "get_render_device: call after GetRenderResult");
     if (d_bgr) *d_bgr = renders_[i].d_bgr;
     if (d_depth) *d_depth = renders_[i].d_depth;
+  }
+  // Test hook: the page-locked host copies of the last (back = 0) and the second-to-last (back = 1) ray-cast of render stream i that
+  // bench_sequence wrote -- the second-to-last one ran BESIDE the allocation of the last scan (enqueue_scan), which is what a test of
+  // that overlap has to look at.
+  void bench_render_host(int i, int back, const uint8_t **bgr, const float **depth) {
+    if (i < 0 || i >= (int)renders_.size() || back < 0 || back > 1) fail(DR_ERR_ARG, "bench_render_host: stream %d of %zu, back %d", i, renders_.size(), back);
+    DR_HIP(hipSetDevice(device_));
+    DR_HIP(hipDeviceSynchronize());
+    const int slot = free_slot_ ^ back;
+    if (bgr) *bgr = renders_[i].h_bgr[slot];
+    if (depth) *depth = renders_[i].h_depth[slot];
   }
   void synchronize() {
     DR_HIP(hipSetDevice(device_));
@@ -1714,6 +1729,9 @@ int dr_memcpy_d2d(void *dst, const void *src, size_t bytes) {
 int dr_memcpy_d2h(void *dst, const void *dptr, size_t bytes) { return guarded([&] { DR_HIP(hipMemcpy(dst, dptr, bytes, hipMemcpyDeviceToHost)); }); }
 int drf_bench_sequence(drf_t *h, const void *d_bgr, const void *d_depth, const float *poses16, int nframes, int render, float ms[6]) {
   return guarded([&] { eng(h)->bench_sequence(d_bgr, d_depth, poses16, nframes, render, ms); });
+}
+int drf_bench_render_host(drf_t *h, int stream, int back, const uint8_t **bgr, const float **depth) {
+  return guarded([&] { eng(h)->bench_render_host(stream, back, bgr, depth); });
 }
 int drf_bench_integrate(drf_t *h, const void *d_bgr, const void *d_depth, const float *poses16, int nscans, float *ms, float *kernel_ms) {
   return guarded([&] { eng(h)->bench_integrate(d_bgr, d_depth, poses16, nscans, ms, kernel_ms); });

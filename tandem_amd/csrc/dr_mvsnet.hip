@@ -190,12 +190,12 @@ struct MvsSwitches {
   int prob_zchunk = num("DR_PROB_ZCHUNK", 0);            // tuning: z-march chunk of k_prob2 (0: default)
   int hist_blocks = std::max(1, num("DR_HIST_BLOCKS", 128));  // workgroups of a histogram level (each flushes its bins with atomics on a few hot addresses)
   bool costvol_v2 = on("DR_COSTVOL_V2");                 // k_costvol2 (the fallback for depth chunks that are not multiples of 4) everywhere
-  bool costvol_v3 = on("DR_COSTVOL_V3");                 // k_costvol3 (global gathers; the fallback of the LDS-staged k_costvol4 for partial tiles / plain-variance models) everywhere
   bool regress_generic = on("DR_REGRESS_GENERIC");       // k_regress (the fallback for other plane counts) everywhere
   bool shard_allreduce = on("DR_SHARD_ALLREDUCE");       // view shard: round 2's all-reduce form instead of reduce + broadcast
   bool vol_split = !on("DR_VOL_NO_SPLIT");               // stage 1's 32-channel cost volume as two 16-channel halves (DevTensor::split); off: one (D,h,w,32) tensor (A/B)
 #ifdef DR_PARITY_HOOKS
   bool costvol_v1 = on("DR_COSTVOL_V1");                 // round 2's k_costvol on unpadded feature maps
+  bool costvol_v3 = on("DR_COSTVOL_V3");                 // k_costvol3 everywhere, also where DR_CV4_STAGES selects the LDS-staged k_costvol4 (the only place the switch is read: cv4_applies)
   int costvol_cpl = num("DR_COSTVOL_CPL", 4) == 8 ? 8 : 4;
   bool prob_v1 = on("DR_PROB_V1");                       // round 2's k_prob (L1 gathers)
   int prob_block = std::max(64, std::min(256, num("DR_PROB_BLOCK", 256) / 64 * 64)), prob_xo = num("DR_PROB_XO", 1);
@@ -208,7 +208,7 @@ struct MvsSwitches {
   int cv4_stages = num("DR_CV4_STAGES", 0);              // bit s-1 set = stage s builds its cost volume with k_costvol4 where it applies
   int cv4_sp8 = num("DR_CV4_SP8", 0);                    // bit s-1 set = 8 planes per k_costvol4 step at stage s (else 4)
 #else
-  static constexpr bool costvol_v1 = false, prob_v1 = false, prob_launch_order = false, prob_on_conv = false, skip_on_conv = false,
+  static constexpr bool costvol_v1 = false, costvol_v3 = false, prob_v1 = false, prob_launch_order = false, prob_on_conv = false, skip_on_conv = false,
                         no_skip_fusion = false, out3_folded = true, d2h_copy = false;
   static constexpr int costvol_cpl = 4, prob_block = 256, prob_xo = 1, cv4_stages = 0, cv4_sp8 = 0;
 #endif
@@ -722,7 +722,7 @@ class MvsEngine {
         o.replan = replan; o.ncand = ncand;
         char sig[160];
         snprintf(sig, sizeof sig, "%d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d", L.Cin, L.Cout, k3d, kh, kw, L.sd, L.sh, L.sw, L.transposed ? 1 : (L.up2 ? 1 + L.up2 : 0),
-                 (int)mode + (fused ? 8 : 0), iD, iH, iW);
+                 (int)mode + (fused ? 8 : 0) + (iS ? 16 : 0), iD, iH, iW);
         o.sig = sig;
       }
       o.flops = cl.flops;
@@ -910,11 +910,21 @@ class MvsEngine {
     // Images that already live in page-locked memory (drm_host_alloc, hipHostMalloc, hipHostRegister) go to the device straight from
     // where they are -- no gather into the pinned block, which is the 0.3-0.4 ms memcpy on the operator boundary's critical path; the
     // call still returns only when the copies have completed ("inputs are copied before return": the caller may reuse its buffers).
+    // "Page-locked" is decided for the WHOLE image, not for its first byte: the allocation (or registered range) the first byte lies in has
+    // to contain all img_bytes of it -- an image that starts inside a hipHostRegister'ed range and runs past its end takes the staging path.
     bool pinned = true;
     for (int v = 0; v < V && pinned; ++v) {
       hipPointerAttribute_t at;
-      if (hipPointerGetAttributes(&at, bgrs[v]) != hipSuccess) { (void)hipGetLastError(); pinned = false; }
-      else pinned = at.type == hipMemoryTypeHost;
+      hipDeviceptr_t base = nullptr;
+      size_t span = 0;
+      if (hipPointerGetAttributes(&at, bgrs[v]) != hipSuccess || at.type != hipMemoryTypeHost || !at.devicePointer ||
+          hipMemGetAddressRange(&base, &span, (hipDeviceptr_t)at.devicePointer) != hipSuccess) {
+        (void)hipGetLastError();
+        pinned = false;
+      } else {
+        const char *lo = (const char *)base, *p = (const char *)at.devicePointer;
+        pinned = p >= lo && p + img_bytes <= lo + span;
+      }
     }
     auto upload_views = [&, pinned](int v0) {  // views v0, v0 + 2, ...: gather into the staging block (unless page-locked already), then the copy engine
       DR_HIP(hipSetDevice(device_));

@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256) void k_costvol3(const CostVolArgs a) {
 // MEASURED (MI355X, 640 x 480 x 7, profiles/r04_experiments.txt 5): 0.121 / 0.163 / 0.105 ms per stage against k_costvol3's 0.106 / 0.150 /
 // 0.099 (first version, before the per-sample instruction diet: 0.143 / 0.181 / 0.114) -- the staged form removes three quarters of the
 // line look-ups but pays 27 % more vector instructions per sample, two barriers per step and an LDS-DMA latency that four samples of
-// arithmetic do not cover.  Kept, with its test, in the parity build; the product runs k_costvol3 with neighbour-tap borrowing.  View-aggregation models only (the plain-
+// arithmetic do not cover.  Kept, with its test, in the parity build; the product runs k_costvol3 (whose neighbour-tap borrowing variant was slower too and is gone, see above).  View-aggregation models only (the plain-
 // variance form needs a second accumulator set per plane; it stays on k_costvol3).
 constexpr int kCv4Slots = 1024;  // float4 slots per LDS buffer (16 KiB; two buffers)
 template <int C> struct Cv4Shape {

@@ -137,6 +137,15 @@ class DrFusion:
         check(self._L.drf_bench_sequence(self._h, C.c_void_p(d_bgr), C.c_void_p(d_depth), fptr(ps), ps.shape[0], int(bool(render)), ms))
         return dict(total=ms[0], allocate=ms[1], integrate=ms[2], raycast=ms[3], d2h=ms[4], wall=ms[5])
 
+    def bench_last_render(self, back=0, stream=0):
+        """(bgr, depth) COPIES of the last (back=0) / second-to-last (back=1) ray-cast bench_sequence wrote for `stream` (test hook)."""
+        b, d = C.c_void_p(), C.c_void_p()
+        check(self._L.drf_bench_render_host(self._h, stream, back, C.byref(b), C.byref(d)))
+        H, W = self._hw
+        bgr = np.ctypeslib.as_array(C.cast(b, u8p), shape=(H, W, 3)).copy()
+        depth = np.ctypeslib.as_array(C.cast(d, C.POINTER(C.c_float)), shape=(H, W)).copy()
+        return bgr, depth
+
     def bench_integrate(self, bgrs, depths, poses):
         """Uploads the scans once, then times back-to-back allocate+integrate of all of them (HBM-resident)."""
         L = self._L

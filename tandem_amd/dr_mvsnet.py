@@ -41,21 +41,42 @@ def _marshal(bgrs, intrinsic_matrix, cam_to_worlds, height, width):
     return bgrs, c2ws, K, pb, pc
 
 
+class _Owned:
+    """Owner of something the C library must release exactly once (an engine handle, a drm_host_alloc block).  numpy views of
+    library-owned memory keep their owner alive (they are built on a ctypes buffer that carries a reference to it), so the
+    release happens when the last VIEW is gone, not when DrMvsnet.close() is called: a view can never dangle."""
+
+    def __init__(self, release, what):
+        self._release, self.what = release, what
+
+    def __del__(self):
+        rel, self._release = self._release, None
+        if rel is not None:
+            rel(self.what)
+
+
+def _view(ptr, nbytes, owner):
+    """ctypes byte buffer over library-owned memory that keeps `owner` alive; np.frombuffer(...) views inherit that."""
+    buf = (C.c_uint8 * nbytes).from_address(ptr if isinstance(ptr, int) else C.cast(ptr, C.c_void_p).value)
+    buf._owner = owner
+    return buf
+
+
 class DrMvsnet:
     def __init__(self, filename, device=0):
         """dr_mvsnet.h:38 `explicit DrMvsnet(char const* filename)`; filename = TDMW weight blob."""
         self._h = C.c_void_p()
         self._L = _lib.lib()  # the library this handle belongs to (tests may switch the process default, _lib.switch)
         check(self._L.drm_create(str(filename).encode(), int(device), C.byref(self._h)))
+        L = self._L
+        self._engine = _Owned(lambda h: L.drm_destroy(h), C.c_void_p(self._h.value))  # result views hold a reference to it
         self._hw = None
 
     def close(self):
-        if getattr(self, "_h", None) and self._h.value:
-            self._L.drm_destroy(self._h)
-            self._h = C.c_void_p()
-        for ptr in getattr(self, "_pinned", []):
-            self._L.drm_host_free(ptr)
-        self._pinned = []
+        """Drops the engine.  It is destroyed now unless result views (GetResultView) are still alive -- then when the last of them
+        goes; page-locked image blocks (alloc_images) likewise live as long as their arrays."""
+        self._h = C.c_void_p()
+        self._engine = None
 
     __del__ = close
 
@@ -92,18 +113,20 @@ class DrMvsnet:
         check(self._L.drm_get_result_view(self._h, *[C.byref(q) for q in p]))
         out = DrMvsnetOutput.__new__(DrMvsnetOutput)
         out.height, out.width = self._hw
-        out.depth, out.confidence, out.depth_dense, out.confidence_dense = [np.ctypeslib.as_array(q, shape=self._hw) for q in p]
+        n = self._hw[0] * self._hw[1] * 4
+        out.depth, out.confidence, out.depth_dense, out.confidence_dense = [
+            np.frombuffer(_view(q, n, self._engine), np.float32).reshape(self._hw) for q in p]
         return out
 
     def alloc_images(self, view_num, height, width):
         """`view_num` (H, W, 3) u8 arrays in page-locked memory (drm_host_alloc): CallAsync uploads such images in place, without the
-        gather into the engine's staging block.  Freed when the engine is closed."""
+        gather into the engine's staging block.  The block is freed when the last of the arrays is gone."""
         n = view_num * height * width * 3
         ptr = self._L.drm_host_alloc(n)
         if not ptr:
             raise MemoryError("drm_host_alloc(%d)" % n)
-        self._pinned = getattr(self, "_pinned", []) + [ptr]
-        flat = np.ctypeslib.as_array(C.cast(ptr, u8p), shape=(n,))
+        L = self._L
+        flat = np.frombuffer(_view(ptr, n, _Owned(lambda q: L.drm_host_free(q), ptr)), np.uint8)
         return [flat[v * height * width * 3:(v + 1) * height * width * 3].reshape(height, width, 3) for v in range(view_num)]
 
     # ---- device-resident / introspection hooks (no reference counterpart) ----

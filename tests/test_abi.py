@@ -99,3 +99,25 @@ def test_scene_generator_is_deterministic():
     a, b = scene.make_window(64, 96, 3, seed=5), scene.make_window(64, 96, 3, seed=5)
     assert all(np.array_equal(x, y) for x, y in zip(a["bgrs"], b["bgrs"]))
     assert a["ref_index"] == 1 and a["c2ws"].shape == (3, 4, 4)
+
+
+def test_views_keep_their_owner_alive():
+    """numpy views of library-owned memory (GetResultView, alloc_images) must not dangle after DrMvsnet.close().  The
+    views are built on a ctypes buffer that references an owner object; the release runs when the LAST view is gone."""
+    import ctypes as C
+    import gc
+    import numpy as np
+    from tandem_amd.dr_mvsnet import _Owned, _view
+    backing = (C.c_uint8 * 64)()
+    released = []
+    owner = _Owned(released.append, 1234)
+    a = np.frombuffer(_view(C.addressof(backing), 64, owner), np.uint8)
+    b = a[8:24].reshape(4, 4)
+    del owner, a
+    gc.collect()
+    assert released == []          # b still looks at the memory
+    b[0, 0] = 7
+    assert backing[8] == 7
+    del b
+    gc.collect()
+    assert released == [1234]      # released exactly once, after the last view

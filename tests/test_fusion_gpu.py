@@ -415,3 +415,43 @@ def test_blocks_outside_the_dense_grid():
     assert_same_volume(f, o)
     assert (od > 0).mean() > 0.3
     f.close()
+
+
+def test_far_blocks_through_the_device_resident_sequence():
+    """in drf_bench_sequence the allocation of scan k + 1 runs BESIDE the ray-cast of scan k.  For blocks outside the
+    dense grid the insert publishes its key before the pool index, so the concurrent ray-cast must never read an unpublished
+    value (vals starts at -1 = absent; find_block_table).  The far-block scene of test_blocks_outside_the_dense_grid goes
+    through the sequence hook: the ray-cast of the second-to-last scan (the one that overlapped an allocation), the last one
+    and the voxel state have to equal the oracle's bit for bit -- repeatedly, since a race is a matter of timing."""
+    import torch
+    from synth import scene
+    from oracle.tsdf_oracle import TsdfOracle
+    from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
+    H, W, vs, n = 96, 128, 0.02, 4
+    sc = scene.make_scans(n, H, W, seed=6)
+    opt = options(sc, H, W, vs)
+    S = np.eye(4, dtype=np.float32)
+    c, s = np.cos(1.45), np.sin(1.45)
+    S[:3, :3] = [[c, 0, s], [0, 1, 0], [-s, 0, c]]
+    S[:3, 3] = (40.2, 0.3, -0.2)
+    scans = [(bgr, depth, (S @ pose).astype(np.float32)) for bgr, depth, pose in sc["scans"]]
+    o = TsdfOracle(**opt)
+    renders = []
+    for bgr, depth, pose in scans:
+        assert o.integrate(bgr, depth, pose) == 0
+        renders.append(o.render(pose))
+    d_bgr = torch.from_numpy(np.stack([b for b, _, _ in scans])).cuda()
+    d_depth = torch.from_numpy(np.stack([d for _, d, _ in scans])).cuda()
+    poses = np.stack([p.reshape(16) for _, _, p in scans])
+    for rep in range(5):
+        f = DrFusion(DrFusionOptions(**opt))
+        f.bench_sequence(d_bgr.data_ptr(), d_depth.data_ptr(), poses, render=True)
+        for back in (0, 1):
+            rb, rd = f.bench_last_render(back)
+            ob, od = renders[n - 1 - back]
+            assert np.array_equal(rd.view(np.uint32), od.view(np.uint32)), f"rep {rep}, scan {n - 1 - back}: {(rd != od).sum()} px differ"
+            assert np.array_equal(rb, ob)
+        xs = [k[0] for k in f.export_blocks()]
+        assert min(xs) < 256 <= max(xs)
+        assert_same_volume(f, o)
+        f.close()
