@@ -14,7 +14,7 @@ HOBJS := $(CSRC)/dr_mvsnet_hooks.o $(CSRC)/dr_fusion_hooks.o $(CSRC)/dr_tracker.
 # -Bsymbolic: both libraries export the same C ABI and may be loaded into one process; each binds its internal calls to itself
 LDFLAGS := -shared -fPIC -Wl,-Bsymbolic
 
-all: $(LIB) $(HLIB) oracle/libtsdf_oracle.so oracle/libtsdf_oracle_omp.so oracle/libtracker_oracle.so
+all: $(LIB) $(HLIB) oracle/libtsdf_oracle.so oracle/libtsdf_oracle_omp.so oracle/libtracker_oracle.so oracle/libtracker_oracle_left.so
 
 MVS_DEPS := $(CSRC)/dr_mvsnet.hip $(CSRC)/conv_mfma.h $(CSRC)/conv_bf3.h $(CSRC)/conv_march.h $(CSRC)/conv_wino.h $(CSRC)/march_plan.h $(CSRC)/conv_tuned.h $(CSRC)/mvs_kernels.h $(CSRC)/dr_common.h include/dr_mi355x.h
 FUS_DEPS := $(CSRC)/dr_fusion.hip $(CSRC)/mesh_kernels.h $(CSRC)/mc_tables.h $(CSRC)/dr_common.h include/dr_mi355x.h
@@ -44,7 +44,10 @@ oracle/libtsdf_oracle_omp.so: oracle/tsdf_oracle.c tandem_amd/csrc/mc_tables.h
 
 oracle/libtracker_oracle.so: oracle/tracker_oracle.c
 	gcc -O2 -std=c99 -fPIC -shared -ffp-contract=off -fno-fast-math $< -o $@ -lm
+# the same restatement with the other order of the hand-off's 3-term products, (a0 + a1) + a2: tests/test_ref_handoff.py caps what the order moves
+oracle/libtracker_oracle_left.so: oracle/tracker_oracle.c
+	gcc -O2 -std=c99 -fPIC -shared -ffp-contract=off -fno-fast-math -DTRK_SUM_LEFT $< -o $@ -lm
 
 clean:
-	rm -f $(OBJS) $(HOBJS) $(LIB) $(HLIB) oracle/libtsdf_oracle.so oracle/libtsdf_oracle_omp.so oracle/libtracker_oracle.so
+	rm -f $(OBJS) $(HOBJS) $(LIB) $(HLIB) oracle/libtsdf_oracle.so oracle/libtsdf_oracle_omp.so oracle/libtracker_oracle.so oracle/libtracker_oracle_left.so
 .PHONY: all clean

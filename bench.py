@@ -45,7 +45,7 @@ def source_stamp():
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r*_pmc_traffic.json, written by
-    tools/gpu_r4_final.sh + tools/pmc_to_json.py on the same workload; counters cannot be read from inside this process).
+    tools/gpu_r5.sh pmc + tools/pmc_to_json.py on the same workload; counters cannot be read from inside this process).
     FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.  None when there is no profile, when the profile
     does not carry THIS tree's source stamp (a stale file is refused, not reported), or when it lacks the kernel."""
     import glob
@@ -98,6 +98,53 @@ DISCARD = 10.0                  # TANDEM's mvsnet_discard_percentage default (se
 DEPTH_MIN, DEPTH_MAX = 0.01, 10.0
 
 
+# DR_BENCH_DRY_RUN=1 (tests/test_bench_launch.py): the launcher, the rank plumbing, the replicas reduction, the view-shard leg's participant
+# logic and the JSON assembly run on a CPU box over gloo with a stand-in engine that does nothing (tests/stubs/dry_engine.py).  A dry run
+# prints "value": null and "dry_run": true -- it measures nothing and is never a result.
+DRY = os.environ.get("DR_BENCH_DRY_RUN") == "1"
+
+
+def engine_class():
+    if DRY:
+        sys.path.insert(0, os.path.join(ROOT, "tests", "stubs"))
+        from dry_engine import DryMvsnet
+        return DryMvsnet
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    return DrMvsnet
+
+
+def make_window(h, w, v, seed):
+    if DRY:
+        sys.path.insert(0, os.path.join(ROOT, "tests", "stubs"))
+        import dry_engine
+        return dry_engine.make_window(h, w, v, seed)
+    from synth import scene  # synthetic input generator (test infrastructure, not the measured path)
+    return scene.make_window(h, w, v, seed=seed)
+
+
+def gpu_sync():
+    if not DRY:
+        import torch
+        torch.cuda.synchronize()
+
+
+def gpu_state():
+    """sclk / mclk / power / temperature of GPU 0 as rocm-smi reports them right now (boxes of the pool differ by up to 20 %: the line says
+    what state the card was in around the timed region).  None where rocm-smi is missing."""
+    import subprocess
+    try:
+        r = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--showtemp", "--json"], capture_output=True, text=True, timeout=20)
+        card = next(iter(json.loads(r.stdout).values()))
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if "sclk" in kl or "mclk" in kl or "power" in kl or ("temperature" in kl and "edge" in kl) or "fclk" in kl:
+                keep[k] = v
+        return keep
+    except Exception as e:  # noqa: BLE001 -- reporting only
+        return dict(error=str(e)[:120])
+
+
 _BLOB = {}
 
 
@@ -116,11 +163,9 @@ def model_blob():
 
 
 def mvsnet_leg(args, rank, dev, world):
-    import torch
-    from synth import scene  # synthetic input generator (test infrastructure, not the measured path)
     from tandem_amd import replicas
-    from tandem_amd.dr_mvsnet import DrMvsnet
     import threading
+    DrMvsnet = engine_class()
     blob = model_blob()
     # E independent DrMvsnet engines per GPU (each its own stream, worker and keyframe window): the launches of
     # different windows overlap, which fills the CUs during the many small kernels of the coarse UNet levels
@@ -128,7 +173,7 @@ def mvsnet_leg(args, rank, dev, world):
     E = max(1, min(args.engines, args.steps))
     engines, wins = [], []
     for e in range(E):
-        win = scene.make_window(H, W, V, seed=rank * 16 + e)
+        win = make_window(H, W, V, rank * 16 + e)
         m = DrMvsnet(blob, device=dev)
         m.upload(H, W, V, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), DEPTH_MIN, DEPTH_MAX, DISCARD)
         if args.warmup > 0:
@@ -146,24 +191,28 @@ def mvsnet_leg(args, rank, dev, world):
     # interrupt); min / max of the repeats ride along.  9 repeats at the driver's K = 20, 3 at the default K = 300.
     repeats = max(3, min(9, -(-400 // max(1, args.steps))))
     spans = []
+    state_before = gpu_state() if rank == 0 and not DRY else None
     for _ in range(repeats):
         threads = [threading.Thread(target=run, args=(e,)) for e in range(E)]
         replicas.barrier(dev)
-        torch.cuda.synchronize()
+        gpu_sync()
         t0 = time.perf_counter()
         for t in threads:
             t.start()
         for t in threads:
             t.join()
-        torch.cuda.synchronize()
+        gpu_sync()
         t1 = time.perf_counter()
         replicas.barrier(dev)
         tmax, units = replicas.reduce_max_sum(t1 - t0, args.steps, dev)
         spans.append((tmax, units, max(ev)))
     tmax, units, evmax = sorted(spans)[len(spans) // 2]
-    res = dict(value=units / tmax, ms_per_step=1e3 * tmax / args.steps, event_ms_per_step=evmax / args.steps, engines_per_gpu=E,  # engines run concurrently: the slowest one's hipEvent span covers the job
+    state_after = gpu_state() if rank == 0 and not DRY else None
+    res = dict(value=units / tmax, units=units, ms_per_step=1e3 * tmax / args.steps, event_ms_per_step=evmax / args.steps, engines_per_gpu=E,  # engines run concurrently: the slowest one's hipEvent span covers the job
                repeats=dict(n=repeats, statistic="median", ms_per_step_min=1e3 * min(s[0] for s in spans) / args.steps,
                             ms_per_step_max=1e3 * max(s[0] for s in spans) / args.steps))
+    if state_before is not None:
+        res["gpu_state"] = dict(before_timed_region=state_before, after_timed_region=state_after, source="rocm-smi -d 0 --showclocks --showpower --showtemp")
     if rank == 0:  # the single-window latency (ONE DrMvsnet object = TANDEM's usage) next to the throughput figure
         nlat = max(10, min(100, args.steps))
         lat = m.forward(nlat) / nlat
@@ -231,13 +280,13 @@ def mvsnet_cpu_baseline(win, blob):
         from oracle import mvsnet_oracle as O
         w = O.Weights(meta, tens)
         run = lambda: O.forward(w, win["bgrs"], win["K"], win["c2ws"], win["ref_index"], DEPTH_MIN, DEPTH_MAX, DISCARD)
-    run()  # warm-up
+    run(); run()  # two warm-ups
     times = []
     while len(times) < 5 and sum(times) < 90.0:  # >= 5 timed forwards (about 11 s each on the GPU box's host)
         t0 = time.perf_counter(); run(); times.append(time.perf_counter() - t0)
     med = sorted(times)[len(times) // 2]
     return dict(value=1.0 / med, unit="depth-maps/s", cores=torch.get_num_threads(), physical_cores=phys, logical_cpus=logical, kind=kind,
-                sample="%d timed forwards of the same %dx%dx7-view (%d,%d,%d) window (depth range %g .. %g) after 1 warm-up, torch CPU fp32, %d threads; median %.2f s, best %.2f s"
+                sample="%d timed forwards of the same %dx%dx7-view (%d,%d,%d) window (depth range %g .. %g) after 2 warm-ups, torch CPU fp32, %d threads; median %.2f s, best %.2f s"
                        % ((len(times), W, H) + PLANES + (DEPTH_MIN, DEPTH_MAX, torch.get_num_threads(), med, min(times))))
 
 
@@ -402,7 +451,8 @@ def tsdf_leg(args, rank, dev, world):
                                         render_d2h=ms["d2h"] / n),  # hipEvents on the engine's streams; `integrate` brackets k_integrate alone
                integrate_only_voxels_per_s=vox / (ms["integrate"] * 1e-3),
                config=dict(workload="%d distinct synthetic 640x480 depth maps (camera loop through a 6x4x3 m room with a sphere, 2.5 %% invalid "
-                                    "pixels) fused into an initially empty 5 mm hashed voxel grid (truncation 20 mm, 2.5 M blocks = 10 GB): per frame "
+                                    "pixels) fused into an initially empty 5 mm hashed voxel grid (truncation 20 mm; num_blocks = 2.5 M = 10 GB of voxels, NOT the >= 16 M of SURVEY 8d: "
+                                    "the loop allocates 378 k blocks, and bump allocation makes the pool size irrelevant to every kernel -- a 16 M pool only adds 55 GB of hipMalloc): per frame "
                                     "allocate + integrate + one ray-cast from the frame's pose incl. D2H of the render; frames resident in HBM" % n))
     if rank == 0:
         ach = 16.0 * vox / (ms["integrate"] * 1e-3) / 1e9
@@ -497,8 +547,12 @@ def tracker_leg(args, dev):
     # warm-up covers everything the timed loops touch, the timing events included: the driver's fresh-lease runs of rounds 1
     # and 2 showed a one-off of ~55 ms inside whichever loop was timed first.  Every call is also timed on its own (it ends
     # with a stream synchronise), so a one-off shows up as `max_ms` instead of inflating the figure: the MEDIAN call is reported.
+    # ... and it lasts long enough (>= 0.25 s of back-to-back calls) to take the card out of the idle power state the preceding CPU-baseline
+    # legs leave it in: round 4's driver run showed ONE 60 ms call (calc_res_max_ms) beside a 0.037 ms median -- the first call after ~25 s
+    # without GPU work.  `slowest_call_index` below says where in the timed loop the slowest call sat, should one appear again.
     g.startTiming()
-    for _ in range(10):
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 0.25:
         g.calcRes(p["refToNew"], 1.0, [0.0, 0.0], 20.0); g.calcG(1.0, [0.0, 0.0])
     g.endTimingMilliseconds()
     reps = 50
@@ -509,8 +563,8 @@ def tracker_leg(args, dev):
         for _ in range(reps):
             t0 = time.perf_counter(); fn(); ts.append(1e3 * (time.perf_counter() - t0))
         span = g.endTimingMilliseconds() / reps
-        ts.sort()
-        return ts[len(ts) // 2], ts[-1], span
+        worst = max(range(reps), key=lambda i: ts[i])
+        return sorted(ts)[len(ts) // 2], (ts[worst], worst), span
     t_res, max_res, span_res = per_call(lambda: g.calcRes(p["refToNew"], 1.0, [0.0, 0.0], 20.0))
     t_g, max_g, span_g = per_call(lambda: g.calcG(1.0, [0.0, 0.0]))
     K = np.array([[p["fx"], 0, p["cx"]], [0, p["fy"], p["cy"]], [0, 0, 1]], np.float32)
@@ -524,7 +578,8 @@ def tracker_leg(args, dev):
     g.close()
     n = len(p["pc_u"])
     res = dict(points=n, calc_res_ms=t_res, calc_g_ms=t_g, gauss_newton_iterations_per_s=1e3 / (t_res + t_g),
-               per_call=dict(statistic="median of %d host-timed calls" % reps, calc_res_max_ms=max_res, calc_g_max_ms=max_g,
+               per_call=dict(statistic="median of %d host-timed calls after a 0.25 s spin-up" % reps, calc_res_max_ms=max_res[0], calc_g_max_ms=max_g[0],
+                             slowest_call_index=dict(calc_res=max_res[1], calc_g=max_g[1]),
                              calc_res_event_span_ms=span_res, calc_g_event_span_ms=span_g),
                hbm_gbps=dict(calc_res=n * 4.0 * (4 + 7) / (t_res * 1e-3) / 1e9, calc_g=n * 4.0 * 8 / (t_g * 1e-3) / 1e9),
                dense_handoff_ms_incl_uploads=1e3 * (t1 - t0), dense_points=n_dense,
@@ -547,12 +602,10 @@ def view_shard_leg(args, rank, dev, world):
     """BASELINE configs[2]: ONE 7-view window, its source views sharded over the ranks, one RCCL sum all-reduce of the
     fp32 cost volume per cascade stage (tandem_amd/view_shard.py).  Reported next to the replicas headline, never as it:
     by SURVEY 8e the reduce alone exceeds the single-GPU pipeline, so this configuration loses throughput by design."""
-    import torch
-    from synth import scene
     from tandem_amd import replicas, view_shard
-    from tandem_amd.dr_mvsnet import DrMvsnet
+    DrMvsnet = engine_class()
     steps, warmup = min(args.steps, 20), 2
-    win = scene.make_window(H, W, V, seed=0)  # the SAME window on every rank
+    win = make_window(H, W, V, 0)  # the SAME window on every rank
     window = dict(bgrs=win["bgrs"], K=win["K"], c2ws=list(win["c2ws"]), ref_index=win["ref_index"],
                   depth_min=DEPTH_MIN, depth_max=DEPTH_MAX, discard=DISCARD)
     m = DrMvsnet(model_blob(), device=dev)
@@ -581,10 +634,10 @@ def view_shard_leg(args, rank, dev, world):
         nbytes = sum(m.device_tensor("volume%d" % s)[1] for s in (1, 2, 3)) * 4
     step(warmup)
     replicas.barrier(dev)
-    torch.cuda.synchronize()
+    gpu_sync()
     t0 = time.perf_counter()
     step(steps)
-    torch.cuda.synchronize()
+    gpu_sync()
     t1 = time.perf_counter()
     replicas.barrier(dev)
     tmax, nsrc = replicas.reduce_max_sum(t1 - t0, len(mine) - 1, dev)
@@ -593,8 +646,13 @@ def view_shard_leg(args, rank, dev, world):
     chk = replicas.reduce_max_sum(mysum, 0, dev)[0]
     same = (not active) or abs(chk - mysum) == 0.0
     same = replicas.reduce_max_sum(0.0 if same else 1.0, 0, dev)[0] == 0.0
+    # how many ranks RCCL itself counts in the engine's communicator (ncclCommCount), the largest and the number of ranks holding one: a
+    # driver record then shows that the collective really spanned `participants` GPUs and that the idle ranks never joined it
+    cnt = m.comm_count() if hasattr(m, "comm_count") else -1
+    cmax, joined = replicas.reduce_max_sum(float(cnt), 1.0 if cnt > 0 else 0.0, dev)
     m.close()
-    return dict(depth_maps_per_s=steps / tmax, ms_per_depth_map=1e3 * tmax / steps, steps=steps, n_gpus=world,
+    return dict(depth_maps_per_s=steps / tmax, ms_per_depth_map=1e3 * tmax / steps, steps=steps, n_gpus=world, participants=P,
+                rccl_comm_ranks=int(cmax), ranks_in_communicator=int(joined),
                 source_views_total=int(nsrc), source_views_this_rank=len(mine) - 1,
                 allreduce_mb_per_depth_map=nbytes / 1e6, ranks_agree=bool(same), collective=mode,
                 note="one window sharded over the ranks; 3 fp32 volume reductions (RCCL) per depth map")
@@ -673,6 +731,19 @@ def main():
     rank, local_rank, world = replicas.env_world()
     if world != args.gpus and rank == 0:
         print("bench.py: --gpus %d but WORLD_SIZE=%d (running %d replica%s)" % (args.gpus, world, world, "" if world == 1 else "s"), file=sys.stderr)
+    if DRY:  # launcher / plumbing rehearsal on a CPU box: gloo, stand-in engines, only the legs every rank takes part in
+        replicas.init("gloo", None)
+        mv = mvsnet_leg(args, rank, None, world)
+        vs = view_shard_leg(args, rank, None, world) if world > 1 and not args.no_view_shard else None
+        if rank == 0:
+            print(json.dumps({"metric": "depth-maps/sec @ 640\u00d7480\u00d77-view\u00d73-stage; TSDF voxels integrated/sec", "value": None, "unit": "depth-maps/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+                              "vs_baseline": None, "dtype": "f32", "data": "DRY RUN: stand-in engine, no GPU work -- launcher and rank plumbing only", "dry_run": True,
+                              "config": {"workload": "none (dry run)"}, "engines_per_gpu": mv["engines_per_gpu"], "units_counted": mv["units"], "view_sharded": vs}), flush=True)
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
     # test scaffolding for 1-GPU boxes: DR_BENCH_ONE_DEVICE=1 runs every rank on cuda:0 over gloo (RCCL refuses two ranks

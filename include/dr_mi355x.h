@@ -109,6 +109,8 @@ int drm_comm_available(void);                /* DR_OK when RCCL (librccl.so.1, o
 int drm_comm_unique_id(uint8_t id[128]);
 int drm_comm_init(drm_t *h, int rank, int world, const uint8_t id[128]);
 int drm_comm_destroy(drm_t *h);
+/* Ranks of the engine's communicator as RCCL reports them (ncclCommCount): 0 = no communicator, -1 = the bound library lacks the call. */
+int drm_comm_count(drm_t *h, int *nranks);
 /* Device pointer and element count of a named internal tensor ("volume1".."volume3", "feat1", "depth2", ...) AS IT LIES IN
  * MEMORY: "feat1".."feat3" carry a one-pixel zero border in H and W (the cost-volume kernels read them that way), so for
  * those the pointer is the padded base and *nfloats = V * (H + 2) * (W + 2) * C; "volume1" (32 channels) is stored as two consecutive

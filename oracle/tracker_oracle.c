@@ -16,7 +16,10 @@
  *       the reference accumulates in float through cub::BlockReduce + atomicAdd (order arbitrary, ~1e-6 relative
  *       noise), so sums are compared with a relative tolerance stated in the tests;
  *   (3) Ki = K^-1 by cofactors * (1/det) in double (Eigen's 3x3 inverse), then cast to float as the host code does;
- *   (4) the 3-vector products of the reprojection follow Eigen's unrolled reduction a0 + (a1 + a2);
+ *   (4) the 3-vector products of the reprojection follow Eigen's unrolled reduction a0 + (a1 + a2) (redux_novec_unroller splits [0,3) into
+ *       [0,1) + [1,3)); -DTRK_SUM_LEFT builds (a0 + a1) + a2 instead (libtracker_oracle_left.so).  PINNED since round 5: the reference's own
+ *       lines (CoarseTracker.cpp:654-723) compiled for the host (oracle/_ref/libdense_handoff_ref.so, both orders) give the same appended
+ *       points bit for bit, and tests/test_ref_handoff.py caps what the order can move (a pixel index at a rounding tie, 1 ulp of idepth);
  *   (5) reprojected candidates with depth <= 0 in the target frame are dropped (in the reference they enter the
  *       z-buffer test `proj < 0 ? set : min`, making the result depend on visiting order; such pixels are discarded
  *       by the `mvs_depth <= 0` test afterwards unless overwritten);
@@ -234,7 +237,11 @@ int trk_append_dense(trk_t *t, const float *depth, const float *KRKi, const floa
       if (d <= 0.f) continue;
       const float o[3] = {x * d, y * d, d};
       float p[3];
+#ifdef TRK_SUM_LEFT
+      for (int r = 0; r < 3; ++r) p[r] = ((KRKi[3 * r] * o[0] + KRKi[3 * r + 1] * o[1]) + KRKi[3 * r + 2] * o[2]) + Kt[r];
+#else
       for (int r = 0; r < 3; ++r) p[r] = (KRKi[3 * r] * o[0] + (KRKi[3 * r + 1] * o[1] + KRKi[3 * r + 2] * o[2])) + Kt[r];
+#endif
       const float pd = p[2];
       if (!(pd > 0.f)) continue;
       const int pu = (int)(p[0] / p[2] + 0.5f), pv = (int)(p[1] / p[2] + 0.5f);

@@ -65,6 +65,7 @@ SIGNATURES = {
     "drm_comm_unique_id": (C.c_int, [u8p]),
     "drm_comm_init": (C.c_int, [vp, C.c_int, C.c_int, u8p]),
     "drm_comm_destroy": (C.c_int, [vp]),
+    "drm_comm_count": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "drm_device_tensor": (C.c_int, [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]),
     "drf_create": (C.c_int, [C.POINTER(FusionOptions), C.c_int, C.POINTER(vp)]),
     "drf_destroy": (None, [vp]),

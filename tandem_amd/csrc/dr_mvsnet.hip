@@ -135,6 +135,7 @@ struct Rccl {
   decltype(&ncclReduce) Reduce = nullptr;
   decltype(&ncclBroadcast) Broadcast = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;  // optional (reporting only)
   static Rccl &get() {
     static Rccl r;
     static std::mutex m;
@@ -154,6 +155,7 @@ struct Rccl {
       r.Reduce = reinterpret_cast<decltype(r.Reduce)>(dlsym(r.lib, "ncclReduce"));
       r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(dlsym(r.lib, "ncclBroadcast"));
       r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+      r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.lib, "ncclCommCount"));
       if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.Reduce || !r.Broadcast || !r.GetErrorString) {
         r.lib = nullptr;
         fail(DR_ERR_UNSUPPORTED, "RCCL: missing symbols in librccl");
@@ -454,6 +456,17 @@ class MvsEngine {
     r.check(r.CommInitRank(&comm_, world, id, rank), "ncclCommInitRank");
     comm_world_ = world;
     comm_rank_ = rank;
+  }
+  // ranks RCCL itself reports for the engine's communicator (ncclCommCount): what bench.py prints next to the sharded figure, so that a
+  // driver record shows how many GPUs the collective really spanned.  0: no communicator; -1: the bound library has no ncclCommCount.
+  int comm_count() {
+    std::unique_lock<std::mutex> lk(mu_);
+    if (!comm_) return 0;
+    Rccl &r = Rccl::get();
+    if (!r.CommCount) return -1;
+    int n = 0;
+    r.check(r.CommCount(comm_, &n), "ncclCommCount");
+    return n;
   }
   void comm_destroy() {
     std::unique_lock<std::mutex> lk(mu_);
@@ -1336,6 +1349,9 @@ int drm_comm_unique_id(uint8_t id[128]) {
 }
 int drm_comm_init(drm_t *h, int rank, int world, const uint8_t id[128]) { return guarded([&] { eng(h)->comm_init(rank, world, id); }); }
 int drm_comm_destroy(drm_t *h) { return guarded([&] { eng(h)->comm_destroy(); }); }
+int drm_comm_count(drm_t *h, int *nranks) {
+  return guarded([&] { if (!nranks) dr::fail(DR_ERR_ARG, "drm_comm_count: null pointer"); *nranks = eng(h)->comm_count(); });
+}
 int drm_device_tensor(drm_t *h, const char *name, void **dptr, size_t *nfloats) {
   return guarded([&] { if (!name) dr::fail(DR_ERR_ARG, "drm_device_tensor: null name"); eng(h)->device_tensor(name, dptr, nfloats); });
 }

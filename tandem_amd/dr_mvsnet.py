@@ -177,6 +177,12 @@ class DrMvsnet:
     def comm_destroy(self):
         check(self._L.drm_comm_destroy(self._h))
 
+    def comm_count(self):
+        """Ranks RCCL reports for the engine's communicator (0: none, -1: the bound library has no ncclCommCount)."""
+        n = C.c_int()
+        check(self._L.drm_comm_count(self._h, C.byref(n)))
+        return n.value
+
     def device_tensor(self, name):
         """(device pointer, float count) of a named internal tensor, e.g. "volume2"."""
         ptr, n = C.c_void_p(), C.c_size_t()

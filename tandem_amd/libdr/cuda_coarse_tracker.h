@@ -63,6 +63,7 @@ class CudaCoarseTracker {
     return n;
   }
   void synchronize() { check(drt_synchronize(impl)); }
+  drt_t *c_handle() { return impl; }  // extension: the C-ABI handle (introspection hooks such as drt_get_points take it)
   void startTiming() { check(drt_start_timing(impl)); }
   float endTimingMilliseconds() { float ms = -1.f; check(drt_end_timing_ms(impl, &ms)); return ms; }
 

@@ -83,6 +83,11 @@ ncclResult_t ncclCommDestroy(ncclComm_t c) {
   delete c;
   return ncclSuccess;
 }
+ncclResult_t ncclCommCount(const ncclComm_t c, int *count) {
+  if (!c || !count) return ncclInvalidArgument;
+  *count = c->nranks;
+  return ncclSuccess;
+}
 const char *ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no error" : "rccl_stub error"; }
 
 ncclResult_t ncclReduce(const void *send, void *recv, size_t count, ncclDataType_t type, ncclRedOp_t op, int root, ncclComm_t c, hipStream_t st) {

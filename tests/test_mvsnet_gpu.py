@@ -19,11 +19,14 @@ pytestmark = pytest.mark.gpu
 GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "mvsnet_*.npz")))
 
 
-def compare(out, ref, what=""):
+def compare(out, ref, what="", max_err=5e-3):
+    """The fp32 bounds every end-to-end case is held to.  max_err: no single pixel may be off by more than 5 mm (observed maximum over all
+    fixtures: 6e-4 m; until round 4 this bound was 5e-2 m, 80 x the observed error -- a plane jump at an isolated pixel would have passed)."""
     d_err = np.abs(out.depth_dense - ref["depth_dense"])
+    print("compare(%s): depth_dense mean %.2e max %.2e m" % (what, d_err.mean(), d_err.max()))
     assert d_err.mean() < 1e-4, f"{what} depth_dense mean err {d_err.mean()}"
     assert (d_err < 2e-3).mean() > 0.999, f"{what} depth_dense outliers {(d_err >= 2e-3).mean()}"
-    assert d_err.max() < 5e-2, f"{what} depth_dense max err {d_err.max()} m"  # no pixel is arbitrarily wrong (observed max: 6e-4 m)
+    assert d_err.max() < max_err, f"{what} depth_dense max err {d_err.max()} m"
     assert np.abs(out.confidence_dense - ref["confidence_dense"]).mean() < 1e-4
     flips = ((out.depth == 0) != (ref["depth"] == 0)).mean()
     assert flips < 2e-3, f"{what} mask flips {flips}"
@@ -491,7 +494,7 @@ def test_bf16x3_mode_stays_inside_the_fp32_bounds(path, trained_blob, tmp_path, 
         outs.append(m.GetResult())
         m.close()
     ref = {k: g[f"ref_s3_{k}"] for k in ("depth", "confidence", "depth_dense", "confidence_dense")}
-    compare(outs[0], ref, "bf16x3 " + os.path.basename(path))
+    compare(outs[0], ref, "bf16x3 " + os.path.basename(path), max_err=5e-2)  # 16-bit operands: the opt-in mode keeps round 4's single-pixel bound
     assert not np.array_equal(outs[0].depth_dense, outs[1].depth_dense)  # the mode really ran
     # (2e-3 m at the scene's 4.5 m depth range; the bound scales with the range, i.e. with the spacing of the hypothesis planes)
     assert np.abs(outs[0].depth_dense - outs[1].depth_dense).max() < 4.5e-4 * (float(g["depth_max"]) - float(g["depth_min"]))

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round 5's GPU script: ONE parameterised entry point for every gpurun call (the r4 per-call scripts were folded into this form).
 #   tools/gpu_r5.sh <tag> <step> [<step> ...]       results under gpurun_out/<tag>_*
-# steps: build_ubench fused_sweep batch_proxy tests tests_fast bench bench_quick prof pmc smoke autotune
+# steps: fused_sweep fused_prio corun batch_proxy ops tests tests_fast smoke bench bench_quick shipped pmc prof_seq prof_driver
+#   the round's closing evidence, in the order bench.py needs it:  tools/gpu_r5.sh final pmc tests smoke bench shipped prof_seq prof_driver
 set -u
 cd "$(dirname "$0")/.."
 TAG=$1; shift
@@ -31,10 +32,27 @@ print(json.dumps(d["pipeline"]["kernels"]))
 PY
       ;;
     ops) timeout 600 python tools/profile_ops.py > $OUT/${TAG}_ops.txt 2>&1; tail -4 $OUT/${TAG}_ops.txt ;;
-    prof)
-      rm -rf /tmp/prof_$TAG
-      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -- python $OLDPWD/bench.py --gpus 1 --steps 20 --warmup 5 --engines 1 --no-cpu --no-loop --no-boundary --no-tsdf-native > /dev/null 2> $OLDPWD/$OUT/${TAG}_prof.err)
-      python tools/rocprof_summary.py /tmp/prof_$TAG > $OUT/${TAG}_kernel_stats.txt 2>&1; head -40 $OUT/${TAG}_kernel_stats.txt ;;
+    pmc)  # counters in their own passes (--kernel-trace only), strictly sequential kernels (one engine, side stream off) -> profiles/r05_pmc_traffic.json, stamped with this tree's source hash
+      export DR_MVS_NO_SIDE_STREAM=1
+      S="--no-cpu --engines 1 --no-boundary --no-loop --no-tsdf-native"; A="--steps 3 --warmup 1 --tsdf-frames 60 $S"
+      rm -rf $OUT/pm1 $OUT/pm2 $OUT/pm3 $OUT/pm4
+      timeout 600 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pm1 -o pmc -- python bench.py $A > $OUT/pm1.log 2>&1
+      timeout 600 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pm2 -o pmc -- python bench.py $A > $OUT/pm2.log 2>&1
+      timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pm3 -o pmc -- python bench.py $A > $OUT/pm3.log 2>&1
+      timeout 600 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_WAIT_INST_LDS TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pm4 -o pmc -- python bench.py $A > $OUT/pm4.log 2>&1
+      for i in 1 2 3 4; do d=$(dirname $(find $OUT/pm$i -name "pmc_counter_collection.csv" | head -1)); echo "== pass $i"; python tools/pmc_summary.py $d 2>&1 | grep -v "^at::\|elementwise\|    .*at::\|rocclr\|^void at" ; done > $OUT/${TAG}_pmc_summary.txt
+      python tools/pmc_to_json.py profiles/r05_pmc_traffic.json $(for i in 1 2 3; do dirname $(find $OUT/pm$i -name "pmc_counter_collection.csv" | head -1); done)
+      cp profiles/r05_pmc_traffic.json $OUT/; rm -rf $OUT/pm1 $OUT/pm2 $OUT/pm3 $OUT/pm4
+      unset DR_MVS_NO_SIDE_STREAM ;;
+    shipped) timeout 600 python bench.py --config shipped --steps 240 --no-tsdf --no-loop --no-cpu > $OUT/${TAG}_bench_shipped.json 2> $OUT/${TAG}_bench_shipped.err; head -c 300 $OUT/${TAG}_bench_shipped.json; echo ;;
+    prof_seq)  # per-kernel durations without overlap: one engine, side stream off
+      rm -rf $OUT/prof
+      DR_MVS_NO_SIDE_STREAM=1 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python bench.py --steps 20 --warmup 3 --tsdf-frames 200 --no-cpu --engines 1 --no-boundary --no-loop --no-tsdf-native > $OUT/${TAG}_bench_prof.json 2> $OUT/prof.err
+      python tools/rocprof_summary.py $(find $OUT/prof -name "*_results.db" | head -1) > $OUT/${TAG}_bench_kernel_stats.txt 2>&1; head -14 $OUT/${TAG}_bench_kernel_stats.txt; rm -rf $OUT/prof ;;
+    prof_driver)  # the same under the driver's own command (three engines in flight)
+      rm -rf $OUT/prof
+      timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-boundary --no-loop --no-tsdf > $OUT/${TAG}_bench_prof_driver.json 2> $OUT/prof.err
+      python tools/rocprof_summary.py $(find $OUT/prof -name "*_results.db" | head -1) > $OUT/${TAG}_bench_kernel_stats_driver_cmd.txt 2>&1; head -14 $OUT/${TAG}_bench_kernel_stats_driver_cmd.txt; rm -rf $OUT/prof ;;
     *) echo "unknown step $step" ;;
   esac
 done
