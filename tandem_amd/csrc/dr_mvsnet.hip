@@ -21,6 +21,7 @@
 
 #include "conv_mfma.h"
 #include "mvs_kernels.h"
+#include "tail_kernels.h"
 
 namespace dr {
 
@@ -111,12 +112,13 @@ struct DevTensor {
 };
 
 struct Op {
-  enum Kind { PREPROCESS, CONV, SKIPUP, PROB, COSTVOL, REGRESS, EDGE, HIST, SCAN, APPLY, BORDERFIX } kind;
+  enum Kind { PREPROCESS, CONV, SKIPUP, PROB, COSTVOL, REGRESS, EDGE, HIST, SCAN, APPLY, BORDERFIX, TAIL } kind;
   const float *p0 = nullptr, *p1 = nullptr, *p3 = nullptr, *p4 = nullptr;
   float *p2 = nullptr;
   int d0 = 0, d1 = 0, d2 = 0;
   std::string name;
   ConvLaunch conv;
+  TailArgs tail{};                        // TAIL only: conv11 + prob in one launch (tail_kernels.h)
   std::function<ConvLaunch(int)> replan;  // CONV only: build candidate `rank` of the planner's ranking
   std::string sig;                        // CONV only: layer signature in conv_tuned.h's column order
   int ncand = 0;
@@ -194,6 +196,8 @@ struct MvsSwitches {
   bool costvol_v2 = on("DR_COSTVOL_V2");                 // k_costvol2 (the fallback for depth chunks that are not multiples of 4) everywhere
   bool regress_generic = on("DR_REGRESS_GENERIC");       // k_regress (the fallback for other plane counts) everywhere
   bool shard_allreduce = on("DR_SHARD_ALLREDUCE");       // view shard: round 2's all-reduce form instead of reduce + broadcast
+  bool tail_fused = !on("DR_NO_TAIL_FUSION");            // CostRegNet's conv11 + prob as ONE launch (k_tail); off: the transposed convolution on the MFMA kernel, then k_prob2 (A/B)
+  int tail_qy = num("DR_TAIL_QY", 0), tail_zchunk = num("DR_TAIL_ZCHUNK", 0);  // tuning: k_tail's tile (quad rows: 4, 8, 16, 32) and depth planes per workgroup (0: chosen by size)
   bool vol_split = !on("DR_VOL_NO_SPLIT");               // stage 1's 32-channel cost volume as two 16-channel halves (DevTensor::split); off: one (D,h,w,32) tensor (A/B)
 #ifdef DR_PARITY_HOOKS
   bool costvol_v1 = on("DR_COSTVOL_V1");                 // round 2's k_costvol on unpadded feature maps
@@ -564,6 +568,7 @@ class MvsEngine {
         else snprintf(kn, sizeof kn, sw_.costvol_v1 ? "k_costvol<%d>" : (sw_.costvol_v2 ? "k_costvol2<%d>" : "k_costvol3<%d>"), Cc);
       }
       else if (o.kind == Op::PROB) snprintf(kn, sizeof kn, sw_.prob_v1 ? "k_prob" : "k_prob2");
+      else if (o.kind == Op::TAIL) snprintf(kn, sizeof kn, "k_tail<%d>", std::max(3, tail_nout(o.tail.QY, o.tail.QX)));
       else if (o.kind == Op::REGRESS) snprintf(kn, sizeof kn, "k_regress");
       else if (o.kind == Op::PREPROCESS) snprintf(kn, sizeof kn, "k_preprocess");
       else if (o.kind == Op::SKIPUP) snprintf(kn, sizeof kn, "k_skip_up<%d>", o.stage);
@@ -877,6 +882,31 @@ class MvsEngine {
       DevTensor &k6 = cbr3(pre + "conv6", cr + "conv6", k5, 1, 1, CONV_NORMAL);
       DevTensor &x7 = dbr3(pre + "conv7", cr + "conv7", k6, four ? 1 : 2, k4);
       DevTensor &x9 = dbr3(pre + "conv9", cr + "conv9", x7, 2, k2);
+      const HostTensor &w11 = blob_.at(cr + "conv11.conv.weight");
+      const HostTensor &wpr = blob_.at(cr + "prob.weight");
+      const bool tail = sw_.tail_fused && !sw_.prob_on_conv && !conv_bf3_policy() && w11.dims.size() == 5 && w11.dims[0] == 16 && w11.dims[1] == 8 && w11.dims[2] == 3 &&
+                        w11.dims[3] == 3 && w11.dims[4] == 3 && x9.C == 16 && c0.C == 8 && x9.D * 2 == D && x9.H * 2 == h && x9.W * 2 == w && wpr.dims[0] == 1 && wpr.dims[1] == 8;
+      if (tail) {
+        // conv11 (ConvTranspose3d 16 -> 8 + BN + ReLU, + conv0) and prob (8 -> 1) in one z-marching launch: the 8-channel full-resolution tensor
+        // between them (78.6 MB at stages 2 and 3) is never written or read (tail_kernels.h)
+        std::vector<float> sc, bi;
+        fold_bn(cr + "conv11.bn", 8, sc, bi);
+        sc.insert(sc.end(), bi.begin(), bi.end());
+        DevTensor &lg = alloc("logits" + S, D, h, w, 1);
+        Op o; o.kind = Op::TAIL; o.stage = s; o.name = pre + "tail";
+        TailArgs &t = o.tail;
+        t.x = x9.d; t.skip = c0.d; t.out = lg.d; t.D = D; t.h = h; t.w = w;
+        t.wd = plan_arena_->upload(tail_pack_deconv(w11.data.data()));
+        t.sb = plan_arena_->upload(sc);
+        t.wp = plan_arena_->upload(tail_pack_prob(wpr.data.data()));
+        tail_pick_tile(h, w, t.QY, t.QX);
+        if (sw_.tail_qy == 4 || sw_.tail_qy == 8 || sw_.tail_qy == 16 || sw_.tail_qy == 32) { t.QY = sw_.tail_qy; t.QX = 256 / t.QY; }
+        t.zchunk = sw_.tail_zchunk > 0 ? std::min(D, sw_.tail_zchunk) : tail_pick_zchunk(D, h, w, t.QY, t.QX);
+        const double N = (double)D * h * w;
+        o.flops = 2.0 * 3.375 * 16 * 8 * N + 2.0 * 216 * N;  // the algorithmic MACs of both layers (halo recomputation not counted)
+        o.bytes = 4.0 * (x9.n() + c0.n() + lg.n());
+        ops_.push_back(o);
+      } else {
       DevTensor &x11 = dbr3(pre + "conv11", cr + "conv11", x9, 2, c0);
       if (sw_.prob_on_conv && w % 8 == 0) {
         // A/B hook: the Cout = 1 head as 8 x-shifts per column on the MFMA kernel (CONV_X8, 50 % of the rows carry work);
@@ -891,6 +921,7 @@ class MvsEngine {
         o.p0 = x11.d; o.p1 = plan_arena_->upload(wt); o.p2 = lg.d; o.d0 = D; o.d1 = h; o.d2 = w;
         o.flops = 2.0 * 216 * D * h * w; o.bytes = 4.0 * (x11.n() + lg.n());
         ops_.push_back(o);
+      }
       }
       alloc("depth" + S, 1, h, w, 1);
       alloc("conf" + S, 1, h, w, 1);
@@ -1110,6 +1141,9 @@ class MvsEngine {
           hipLaunchKernelGGL(k_prob2, dim3(8 * cdiv(nw, 8)), dim3(256), 0, stream_, o.p0, o.p1, o.p2, o.d0, o.d1, o.d2, zc, gxp, gyp, gzp, nw);
           break;
         }
+        case Op::TAIL:
+          launch_tail(o.tail, stream_);
+          break;
         case Op::COSTVOL: {
           const CostVolArgs &a = cv_[o.stage - 1];
           const int C = 32 >> (o.stage - 1);
@@ -1431,6 +1465,38 @@ int drm_debug_conv(int device, const float *in, int D, int H, int W, int Cin, co
     }
     DR_HIP(hipMemcpy(out, d_out, on * 4, hipMemcpyDeviceToHost));
     if (out_dims) { out_dims[0] = oD; out_dims[1] = oH; out_dims[2] = oW; }
+  });
+}
+
+/* Kernel unit-test hook for k_tail (tail_kernels.h): conv11 (ConvTranspose3d 16 -> 8, k 3, s 2, p 1, op 1; folded BN scale / bias; ReLU; + skip) followed by prob
+ * (Conv3d 8 -> 1, k 3, p 1).  x: (D/2, h/2, w/2, 16), skip: (D, h, w, 8) channels-last; w_deconv (16, 8, 3, 3, 3), w_prob (1, 8, 3, 3, 3) torch layouts;
+ * qy: quad rows of the tile (0: chosen by size), zchunk: depth planes per workgroup (0: chosen).  out: (D, h, w) logits. */
+int drm_debug_tail(int device, const float *x, const float *skip, const float *w_deconv, const float *scale8, const float *bias8, const float *w_prob, int D, int h,
+                   int w, int qy, int zchunk, float *out) {
+  return guarded([&] {
+    using namespace dr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= device) fail(DR_ERR_DEVICE, "no HIP device %d", device);
+    if (D <= 0 || h <= 0 || w <= 0 || (D | h | w) & 1) fail(DR_ERR_ARG, "drm_debug_tail: output dims must be positive and even");
+    DR_HIP(hipSetDevice(device));
+    DeviceArena arena;
+    TailArgs t{};
+    t.x = arena.upload(std::vector<float>(x, x + (size_t)(D / 2) * (h / 2) * (w / 2) * 16));
+    t.skip = arena.upload(std::vector<float>(skip, skip + (size_t)D * h * w * 8));
+    t.wd = arena.upload(tail_pack_deconv(w_deconv));
+    std::vector<float> sb(scale8, scale8 + 8);
+    sb.insert(sb.end(), bias8, bias8 + 8);
+    t.sb = arena.upload(sb);
+    t.wp = arena.upload(tail_pack_prob(w_prob));
+    float *d_out = arena.upload(std::vector<float>((size_t)D * h * w, -12345.f));
+    t.out = d_out; t.D = D; t.h = h; t.w = w;
+    tail_pick_tile(h, w, t.QY, t.QX);
+    if (qy == 4 || qy == 8 || qy == 16 || qy == 32) { t.QY = qy; t.QX = 256 / qy; }
+    t.zchunk = zchunk > 0 ? std::min(D, zchunk) : tail_pick_zchunk(D, h, w, t.QY, t.QX);
+    launch_tail(t, nullptr);
+    DR_HIP(hipDeviceSynchronize());
+    DR_HIP(hipGetLastError());
+    DR_HIP(hipMemcpy(out, d_out, (size_t)D * h * w * 4, hipMemcpyDeviceToHost));
   });
 }
 

@@ -250,3 +250,16 @@ def debug_conv(x, weight, stride=(1, 1, 1), transposed=False, scale=None, bias=N
                                     fptr(keep[2]) if keep[2] is not None else None, int(add_up2), fptr(out), dims))
     assert tuple(dims) == (oD, oH, oW)
     return out
+
+
+def debug_tail(x, skip, w_deconv, scale, bias, w_prob, qy=0, zchunk=0, device=0):
+    """Kernel unit-test hook for k_tail: x (D/2, h/2, w/2, 16), skip (D, h, w, 8) channels-last; torch-layout weights; returns (D, h, w) logits."""
+    x, skip = np.ascontiguousarray(x, np.float32), np.ascontiguousarray(skip, np.float32)
+    D, h, w, _ = skip.shape
+    assert x.shape == (D // 2, h // 2, w // 2, 16) and skip.shape[3] == 8
+    wd, wp = np.ascontiguousarray(w_deconv, np.float32), np.ascontiguousarray(w_prob, np.float32)
+    assert wd.shape == (16, 8, 3, 3, 3) and wp.shape == (1, 8, 3, 3, 3)
+    sc, bi = np.ascontiguousarray(scale, np.float32), np.ascontiguousarray(bias, np.float32)
+    out = np.empty((D, h, w), np.float32)
+    check(_lib.lib().drm_debug_tail(device, fptr(x), fptr(skip), fptr(wd), fptr(sc), fptr(bi), fptr(wp), D, h, w, int(qy), int(zchunk), fptr(out)))
+    return out
