@@ -43,7 +43,7 @@ def source_stamp():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, fetch="corrected"):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r*_pmc_traffic.json, written by
     tools/gpu_r5.sh pmc + tools/pmc_to_json.py on the same workload; counters cannot be read from inside this process).
     FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.  None when there is no profile, when the profile
@@ -58,7 +58,10 @@ def pmc_traffic(kernel):
     e = prof.get(kernel)
     if not e or "fetch_bytes_corrected" not in e or "write_bytes" not in e:
         return None
-    return e["fetch_bytes_corrected"] + e["write_bytes"]
+    # fetch="raw": kernels whose loads are 8 bytes per lane (k_integrate's voxel reads).  The x2 of MI355X_MICROARCH.md is calibrated on 16-byte-per-lane
+    # streams ("other access widths ... uncalibrated"); k_integrate's own calibration is exact -- it reads 4 KB per visited block, and its RAW FETCH_SIZE
+    # equals that count (tsdf.integrate_traffic_model)
+    return e["fetch_bytes_" + fetch] + e["write_bytes"]
 
 
 def pmc_profile_state():
@@ -455,9 +458,16 @@ def tsdf_leg(args, rank, dev, world):
                                     "the loop allocates 378 k blocks, and bump allocation makes the pool size irrelevant to every kernel -- a 16 M pool only adds 55 GB of hipMalloc): per frame "
                                     "allocate + integrate + one ray-cast from the frame's pose incl. D2H of the render; frames resident in HBM" % n))
     if rank == 0:
+        visited = f.visited_blocks()
+        # what k_integrate really moves: every visible block is READ whole (4 KB, updated or not), every updated voxel is written (8 B)
+        res["integrate_traffic_model"] = dict(visited_blocks_per_frame=visited / n, read_bytes_per_frame=4096.0 * visited / n, write_bytes_per_frame=8.0 * vox / n,
+                                              algorithmic_bytes_per_frame=16.0 * vox / n,
+                                              note="read = 4 KB x visible blocks (k_cull's list), written = 8 B x updated voxels; the PMC FETCH_SIZE of this kernel is compared with "
+                                                   "read_bytes_per_frame UNCORRECTED: its 8-byte-per-lane loads are not the 16-byte streaming reads the x2 rule of MI355X_MICROARCH.md was calibrated on")
         ach = 16.0 * vox / (ms["integrate"] * 1e-3) / 1e9
         res["roofline"] = dict(bound="hbm", kernel="k_integrate", avg_launch_ms=ms["integrate"] / n, bytes_per_launch=16.0 * vox / n,
-                               achieved=ach, peak=PEAK_HBM_GBPS, unit="GB/s", frac=ach / PEAK_HBM_GBPS, traffic=pmc_traffic("k_integrate"))
+                               achieved=ach, peak=PEAK_HBM_GBPS, unit="GB/s", frac=ach / PEAK_HBM_GBPS, traffic=pmc_traffic("k_integrate", fetch="raw"),
+                               traffic_if_fetch_doubled=pmc_traffic("k_integrate"))
         # marching cubes (DrFusion::ExtractMeshAsync + GetMeshSync) of the fused map over TANDEM's (-5..5 m)^3 box
         # (tandem_backend.cpp:80-81): device time = until the triangle count is known, total adds the D2H copy
         lo, hi = (-5.0, -5.0, -5.0), (5.0, 5.0, 5.0)

@@ -200,6 +200,9 @@ int drf_synchronize(drf_t *h);
 /* Counters: [0] allocated blocks, [1] voxels updated by the last scan (band + carve),
  * [2] voxels updated in total, [3] round-trip voxel mismatches (must stay 0). */
 int drf_stats(drf_t *h, uint64_t out[4]);
+/* Blocks the integration kernel has visited since creation (visible blocks of every scan; each is one 4 KB read whether or not a voxel of it was
+ * updated): with out[2] of drf_stats the kernel's exact HBM bytes are 4096 * visited + 8 * updated. */
+int drf_visited_blocks(drf_t *h, uint64_t *total);
 /* Canonical dump for bit-exact comparison: coords[3*i..] block coordinates, voxels[4096*i..] the
  * 512 8-byte voxels {f32 sdf, u8 b,g,r, u8 weight} of block i in index order x*64+y*8+z. */
 int drf_export_blocks(drf_t *h, int max_blocks, int32_t *coords, uint8_t *voxels, int *n);

@@ -105,6 +105,7 @@ SIGNATURES = {
     "dr_memcpy_h2d": (C.c_int, [vp, vp, C.c_size_t]),
     "dr_memcpy_d2h": (C.c_int, [vp, vp, C.c_size_t]),
     "drf_bench_sequence": (C.c_int, [vp, vp, vp, f32p, C.c_int, C.c_int, f32p]),
+    "drf_visited_blocks": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "drf_bench_render_host": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp)]),
     "drf_bench_integrate": (C.c_int, [vp, vp, vp, f32p, C.c_int, f32p, f32p]),
 }

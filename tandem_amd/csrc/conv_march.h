@@ -390,10 +390,16 @@ __device__ inline void march_w_compute(MarchWSet<NRP, CT, PT> &o, floatx4 (&acc)
   for (int ct = 0; ct < CT; ++ct) {
     const float4 g0 = o.g[0][ct], gh = o.g[1][ct], g2 = o.g[2][ct];
     u[0][ct] = g0; u[3][ct] = g2;
+#ifdef DR_WABL_NO_WT  // timing ablation (results wrong by design): what the per-lane weight transform costs
+    u[1][ct] = gh; u[2][ct] = gh;
+#else
     u[1][ct] = make_float4(march_w_u1(g0.x, gh.x, g2.x), march_w_u1(g0.y, gh.y, g2.y), march_w_u1(g0.z, gh.z, g2.z), march_w_u1(g0.w, gh.w, g2.w));
     u[2][ct] = make_float4(march_w_u2(g0.x, gh.x, g2.x), march_w_u2(g0.y, gh.y, g2.y), march_w_u2(g0.z, gh.z, g2.z), march_w_u2(g0.w, gh.w, g2.w));
+#endif
   }
+#ifndef DR_WABL_NO_IT  // timing ablation: what the input transform costs
   conv_w_transform<PT>(o.d);
+#endif
   conv_w_mfma<CT, PT>(u, o.d, acc);
 }
 

@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(256) void k_fold_counter(unsigned long long *cnt, i
   part[threadIdx.x] = a;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) { if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off]; __syncthreads(); }
-  if (threadIdx.x == 0) { const unsigned long long u = part[0] + cnt[0]; cnt[1] += u; cnt[3] = u; cnt[0] = 0; req_count[0] = 0; req_count[1] = 0; }
+  if (threadIdx.x == 0) { const unsigned long long u = part[0] + cnt[0]; cnt[1] += u; cnt[3] = u; cnt[0] = 0; cnt[4] += (unsigned long long)req_count[1]; req_count[0] = 0; req_count[1] = 0; }  // cnt[4]: blocks k_integrate visited (each one a 4 KB read), all scans
 }
 __global__ void k_fill_keys(unsigned long long *keys, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) keys[i] = kEmptyKey;
@@ -1135,7 +1135,7 @@ class FusionEngine {
     d_.vox = dalloc<Voxel>((size_t)o.num_blocks * 512);
     d_.n_alloc = dalloc<int>(4);
     d_.err = d_.n_alloc + 1;
-    d_.cnt = dalloc<unsigned long long>(4);
+    d_.cnt = dalloc<unsigned long long>(8);
     d_.sd = dalloc<float>(npix_);
     d_.pix = dalloc<PixRec>(npix_);
     for (int l = 0; l < kSuperLevels; ++l) d_.super[l] = dalloc<unsigned char>((size_t)1 << (3 * (kGridBits - kSuperShift[l])));
@@ -1154,7 +1154,7 @@ class FusionEngine {
     hipLaunchKernelGGL(k_fill_keys, dim3(1024), dim3(256), 0, int_stream_, d_.keys, cap);
     DR_HIP(hipMemsetAsync(d_.vox, 0, (size_t)o.num_blocks * 512 * sizeof(Voxel), int_stream_));  // hash_table.cu:28-32
     DR_HIP(hipMemsetAsync(d_.n_alloc, 0, 16, int_stream_));
-    DR_HIP(hipMemsetAsync(d_.cnt, 0, 32, int_stream_));
+    DR_HIP(hipMemsetAsync(d_.cnt, 0, 64, int_stream_));
     d_bgr_in_ = dalloc<unsigned char>(npix_ * 3);
     d_depth_in_ = dalloc<float>(npix_);
     DR_HIP(hipHostMalloc((void **)&h_bgr_in_, npix_ * 3, hipHostMallocDefault));
@@ -1319,6 +1319,15 @@ class FusionEngine {
     DR_HIP(hipMemcpy(c, d_.cnt, 32, hipMemcpyDeviceToHost));
     DR_HIP(hipMemcpy(na, d_.n_alloc, 8, hipMemcpyDeviceToHost));
     out[0] = (uint64_t)std::min(na[0], o_.num_blocks); out[1] = c[3]; out[2] = c[1]; out[3] = c[2];
+  }
+  // blocks k_integrate has read since the engine was created (one 4 KB read each, whether or not any voxel of the block was updated): with
+  // `updated_total` this gives the kernel's HBM bytes exactly -- 4096 x visited + 8 x updated -- for the counter calibration in DESIGN.md
+  uint64_t visited_blocks() {
+    DR_HIP(hipSetDevice(device_));
+    DR_HIP(hipDeviceSynchronize());
+    unsigned long long v = 0;
+    DR_HIP(hipMemcpy(&v, d_.cnt + 4, 8, hipMemcpyDeviceToHost));
+    return v;
   }
   void export_blocks(int max_blocks, int32_t *coords, uint8_t *voxels, int *n) {
     DR_HIP(hipSetDevice(device_));
@@ -1729,6 +1738,9 @@ int dr_memcpy_d2d(void *dst, const void *src, size_t bytes) {
 int dr_memcpy_d2h(void *dst, const void *dptr, size_t bytes) { return guarded([&] { DR_HIP(hipMemcpy(dst, dptr, bytes, hipMemcpyDeviceToHost)); }); }
 int drf_bench_sequence(drf_t *h, const void *d_bgr, const void *d_depth, const float *poses16, int nframes, int render, float ms[6]) {
   return guarded([&] { eng(h)->bench_sequence(d_bgr, d_depth, poses16, nframes, render, ms); });
+}
+int drf_visited_blocks(drf_t *h, uint64_t *total) {
+  return guarded([&] { if (!total) dr::fail(DR_ERR_ARG, "drf_visited_blocks: null pointer"); *total = eng(h)->visited_blocks(); });
 }
 int drf_bench_render_host(drf_t *h, int stream, int back, const uint8_t **bgr, const float **depth) {
   return guarded([&] { eng(h)->bench_render_host(stream, back, bgr, depth); });

@@ -196,7 +196,10 @@ struct MvsSwitches {
   bool costvol_v2 = on("DR_COSTVOL_V2");                 // k_costvol2 (the fallback for depth chunks that are not multiples of 4) everywhere
   bool regress_generic = on("DR_REGRESS_GENERIC");       // k_regress (the fallback for other plane counts) everywhere
   bool shard_allreduce = on("DR_SHARD_ALLREDUCE");       // view shard: round 2's all-reduce form instead of reduce + broadcast
-  bool tail_fused = !on("DR_NO_TAIL_FUSION");            // CostRegNet's conv11 + prob as ONE launch (k_tail); off: the transposed convolution on the MFMA kernel, then k_prob2 (A/B)
+  // CostRegNet's conv11 + prob as ONE launch (k_tail, tail_kernels.h).  OPT-IN: correct (tests/test_tail_gpu.py) and its memory side works (26 us floor at
+  // stage 2 against the two-kernel path's 100), but the transposed convolution on the vector pipe costs 65 us there (scalar weight loads the compiler does
+  // not pipeline, fp32 VALU rate = fp32 MFMA rate, 1.8 x halo recomputation): 0.117 / 0.108 ms at stages 2 / 3 against 0.100 / 0.097 (profiles/r05_tail.txt)
+  bool tail_fused = on("DR_TAIL_FUSED");
   int tail_qy = num("DR_TAIL_QY", 0), tail_zchunk = num("DR_TAIL_ZCHUNK", 0);  // tuning: k_tail's tile (quad rows: 4, 8, 16, 32) and depth planes per workgroup (0: chosen by size)
   bool vol_split = !on("DR_VOL_NO_SPLIT");               // stage 1's 32-channel cost volume as two 16-channel halves (DevTensor::split); off: one (D,h,w,32) tensor (A/B)
 #ifdef DR_PARITY_HOOKS

@@ -100,7 +100,11 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(const float *__restrict__
         rs[oa][ob][0] = ld4(p); rs[oa][ob][1] = ld4(p + 4);
       }
     // input planes of this output plane: even zz = 2k: plane k with kz = 1; odd zz = 2k + 1: plane k with kz = 2 and plane k + 1 with kz = 0
+#ifdef DR_TAIL_ABL_NOA  // timing ablation (results wrong by design): phase A without its MACs
+    const int np = 0;
+#else
     const int np = (zz & 1) ? 2 : 1;
+#endif
     for (int t = 0; t < np; ++t) {
       const int k = (zz & 1) ? (zz >> 1) + t : (zz >> 1), kz = (zz & 1) ? (t ? 0 : 2) : 1;
       if (k >= Dh) continue;  // (uniform; zz = D - 1 odd: plane D / 2 does not exist)
@@ -181,7 +185,11 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(const float *__restrict__
   for (int zz = z0 - 2; zz <= z1; ++zz, b ^= 1) {  // (the first trip only produces plane z0 - 1: ONE copy of phase A in the instruction stream)
     __syncthreads();  // plane zz is in buffer b; everybody is done with buffer b ^ 1
     if (zz + 1 <= z1) phase_a(zz + 1, v);
+#ifdef DR_TAIL_ABL_NOB  // timing ablation: no stencil
+    if (zz > 1 << 30) {
+#else
     if (zz >= z0 - 1 && zz >= 0 && zz < D) {
+#endif
       const float4 *lo = tail_lds + (size_t)b * 2 * SP, *hi = lo + SP;
 #pragma unroll
       for (int s = 0; s < NOUT; ++s) {

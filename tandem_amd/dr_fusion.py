@@ -104,6 +104,12 @@ class DrFusion:
         check(self._L.drf_stats(self._h, out))
         return dict(blocks=int(out[0]), updated_last=int(out[1]), updated_total=int(out[2]), mismatches=int(out[3]))
 
+    def visited_blocks(self):
+        """Blocks k_integrate has read so far (4 KB each): with stats()["updated_total"] the kernel's exact HBM bytes."""
+        v = C.c_uint64()
+        check(self._L.drf_visited_blocks(self._h, C.byref(v)))
+        return int(v.value)
+
     def export_blocks(self):
         """Canonical dump: dict {(bx,by,bz): uint8[4096]} (512 voxels x {f32 sdf, u8 b,g,r, u8 weight})."""
         n = self.stats()["blocks"]

@@ -41,15 +41,17 @@ def test_tail_matches_torch(D, h, w, qy, zchunk):
 
 
 def test_tail_fused_and_two_kernel_paths_agree(trained_blob, monkeypatch):
-    """The engine with k_tail against the same engine with DR_NO_TAIL_FUSION=1 (transposed convolution on the MFMA kernel, then k_prob2): every stage's
-    depth map within fp32 reassociation of each other, on a fixture-sized window."""
+    """The engine with k_tail (DR_TAIL_FUSED=1, opt-in) against the default two-kernel path (transposed convolution on the MFMA kernel, then k_prob2):
+    every stage's depth map within fp32 reassociation of each other, on a fixture-sized window."""
     from synth import scene
     from tandem_amd.dr_mvsnet import DrMvsnet
     win = scene.make_window(96, 160, 4, seed=11)
     outs = []
     for off in (False, True):
         if off:
-            monkeypatch.setenv("DR_NO_TAIL_FUSION", "1")
+            monkeypatch.delenv("DR_TAIL_FUSED", raising=False)
+        else:
+            monkeypatch.setenv("DR_TAIL_FUSED", "1")
         m = DrMvsnet(trained_blob)
         m.upload(96, 160, 4, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), win["depth_min"], win["depth_max"], 2.5)
         m.forward(1)

@@ -31,6 +31,10 @@ print("value %.1f /s  ms_per_step %.3f  single_window %.3f ms" % (d["value"], d[
 print(json.dumps(d["pipeline"]["kernels"]))
 PY
       ;;
+    ab_ops)  # per-op profile with every A/B library under build/ab (tools/build_ab.sh), the tree's own first
+      timeout 300 python tools/profile_ops.py "${DR_OPS_RE:-.}" > $OUT/${TAG}_ops_tree.txt 2>&1; tail -1 $OUT/${TAG}_ops_tree.txt
+      for so in build/ab/libdr_*.so; do n=$(basename $so .so); DR_MI355X_LIB=$PWD/$so timeout 300 python tools/profile_ops.py "${DR_OPS_RE:-.}" > $OUT/${TAG}_ops_$n.txt 2>&1; echo "--- $n"; tail -1 $OUT/${TAG}_ops_$n.txt; done ;;
+    loop_raycast) timeout 900 python tools/exp_loop_raycast.py 100 > $OUT/${TAG}_loop_raycast.txt 2>&1; cat $OUT/${TAG}_loop_raycast.txt ;;
     ops) timeout 600 python tools/profile_ops.py > $OUT/${TAG}_ops.txt 2>&1; tail -4 $OUT/${TAG}_ops.txt ;;
     pmc)  # counters in their own passes (--kernel-trace only), strictly sequential kernels (one engine, side stream off) -> profiles/r05_pmc_traffic.json, stamped with this tree's source hash
       export DR_MVS_NO_SIDE_STREAM=1
