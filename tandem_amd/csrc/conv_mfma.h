@@ -755,7 +755,33 @@ inline int up2_kernel_set(int parity, int off, int (&k)[2]) {
   if (off == 2) { k[0] = 2; return 1; }
   return 0;
 }
-inline std::vector<DimTaps> axis_classes(int k, int s, bool transposed, int in_size, bool split = false) {
+// Taps that can only ever read padding are dropped: on an axis of extent 1 a 3-tap stride-1 kernel touches the tensor through its centre tap
+// alone (stage 3's conv6 runs on a depth of 1: two thirds of its products were multiplications by staged zeros), a stride-2 kernel on an axis of
+// extent 2 through two of its three taps (conv5), a transposed stride-2 axis of extent 1 never reads x[m + 1] (conv7).  The remaining offsets are
+// shifted so that the smallest is 0 (the padding shrinks with them): the halo a tile stages shrinks too.
+inline void prune_taps(DimTaps &d, int in_size) {
+  std::vector<int> t, off;
+  for (size_t i = 0; i < d.t.size(); ++i) {
+    bool used = false;
+    for (int pos = 0; pos < d.npos && !used; ++pos) { const int x = pos * d.s - d.p + d.off[i]; used = x >= 0 && x < in_size; }
+    if (used) { t.push_back(d.t[i]); off.push_back(d.off[i]); }
+  }
+  if (t.empty() || t.size() == d.t.size()) return;
+  const int mo = *std::min_element(off.begin(), off.end());
+  for (int &o : off) o -= mo;
+  d.p -= mo;
+  d.t = t; d.off = off;
+}
+inline std::vector<DimTaps> axis_classes_unpruned(int k, int s, bool transposed, int in_size, bool split);
+// (prune: the planner asks for it on the DEPTH axis only -- the in-plane axes of every layer are far longer than their kernels, and the row march /
+// Winograd forms are written for exactly three y taps)
+inline std::vector<DimTaps> axis_classes(int k, int s, bool transposed, int in_size, bool split = false, bool prune = false) {
+  std::vector<DimTaps> r = axis_classes_unpruned(k, s, transposed, in_size, split);
+  if (prune && !getenv("DR_CONV_NO_TAP_PRUNE"))
+    for (DimTaps &d : r) prune_taps(d, in_size);
+  return r;
+}
+inline std::vector<DimTaps> axis_classes_unpruned(int k, int s, bool transposed, int in_size, bool split) {
   std::vector<DimTaps> r;
   if (!transposed) {
     DimTaps d;
@@ -946,7 +972,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   const int form = L.transposed ? conv_deconv_form(L.Cout) : 0;
   if (L.up2 && (L.up2 > 2 || L.transposed || L.kd != 1 || L.kh != 3 || L.kw != 3 || L.sd != 1 || L.sh != 1 || L.sw != 1 || mode != CONV_NORMAL))
     fail(DR_ERR_ARG, "plan_conv: up2 is a plain 3x3 stride-1 2-D layer over the upsampled input");
-  auto cz = axis_classes(L.kd, L.sd, L.transposed, inD, form >= 1);
+  auto cz = axis_classes(L.kd, L.sd, L.transposed, inD, form >= 1, true);
   auto cy = axis_classes(L.kh, L.sh, L.transposed, inH, form >= 1);
   auto cx = axis_classes(L.kw, L.sw, L.transposed, inW, form >= 2);
   if (L.up2) {  // one y parity per launch (a single class: the persistent kernels apply), both x parities as rows
@@ -1052,6 +1078,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   const bool march_fz_ok = !fz || (fz->cin == 8 && L.Cin == 32 && L.kd == 1 && mode == CONV_XPAIR && !getenv("DR_FZ_NO_MARCH"));
   const int march_policy = (march_fz_ok && !bf3) ? conv_march_policy() : 0;
   const bool march_ok = march_policy >= 1 && ncls == 1 && !L.transposed && !L.up2 && mode != CONV_X8 && L.kh == 3 && L.kw == 3 && (L.kd == 1 || L.kd == 3) &&
+                        (int)cz[0].t.size() == L.kd &&  // (a depth axis with pruned taps -- extent 1 or 2 -- stays on the tile kernels)
                         SZ == 1 && SY == 1 && L.sw == 1;
   const int march_ntp = march_ok ? 3 * (int)cx[0].t.size() : 0;  // taps per input plane
   if (march_ok) {

@@ -461,6 +461,11 @@ int main(int argc, char **argv) {
       {"conv2d_3x3_32_32_up2add", 0, 2, 8, 24, 32, 32, 1, 3, 3, 1, 1, 1, false, 2},    // fn.conv2.x shape with an upsample add
       {"conv3d_32_32", 0, 4, 6, 20, 32, 32, 3, 3, 3, 1, 1, 1, true, 0},                // conv4
       {"xpair3d_32_8", 0, 4, 8, 40, 32, 8, 3, 3, 3, 1, 1, 1, true, 0},                 // s1.conv0
+      // depth axes of extent 1 and 2 (stage 3's coarse levels): taps that only ever read padding are pruned (prune_taps)
+      {"conv3d_64_64_D1", 0, 1, 6, 10, 64, 64, 3, 3, 3, 1, 1, 1, true, 0},             // s3.conv6
+      {"conv3d_s2_32_64_D2", 0, 2, 8, 12, 32, 64, 3, 3, 3, 2, 2, 2, true, 0},          // s3.conv5
+      {"conv3d_32_32_D2", 0, 2, 6, 20, 32, 32, 3, 3, 3, 1, 1, 1, true, 0},             // s3.conv4 (nothing to prune, two-plane halo)
+      {"deconv_64_32_D1", 1, 1, 4, 6, 64, 32, 3, 3, 3, 2, 2, 2, true, 1},              // s3.conv7
   };
   int fails = 0;
   for (const Case &cs : cases) fails += run_case(cs, max_plans);
