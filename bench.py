@@ -806,7 +806,7 @@ def main():
                        "reference_published": "2.70 FPS (abl03, unstated GPU, incl. data loading) -- not the same clock, so vs_baseline is null"},
             "event_ms_per_step": mv["event_ms_per_step"],
         }
-        for k in ("repeats", "roofline", "cpu_baseline", "pipeline", "engines_per_gpu", "single_engine", "scene_depth_range"):
+        for k in ("repeats", "gpu_state", "roofline", "cpu_baseline", "pipeline", "engines_per_gpu", "single_engine", "scene_depth_range"):
             if k in mv:
                 out[k] = mv[k]
         # TANDEM's usage is ONE window in flight (tandem_backend.cpp:147): its latency and the operator boundary's rate as flat keys
