@@ -337,6 +337,63 @@ __global__ __launch_bounds__(kConvThreads, DR_KCONV_MIN_WAVES(CT, FZ)) void k_co
   [[maybe_unused]] const unsigned n_w = (unsigned)NU * CT * 64;
   const int *tp = tapl + sub;
   const unsigned total = (unsigned)NP * C4;
+  // PIPELINED PASSES (a.a_wbufs == 2; the planner sets it for the small multi-pass layers: PT = 1, the whole tile in kPipeBatch loads per lane).
+  // The coarse UNet levels run 2-4 channel passes of a few microseconds each, and every pass began with a bare round trip to L2 for its tile and
+  // its weights (one workgroup per CU or fewer: nobody else covers it).  Here the loads of pass p + 1 -- the tile into registers, the weights by
+  // LDS-DMA into the OTHER weight buffer -- are issued before the K loop of pass p and land under it: one exposed round trip per workgroup
+  // instead of one per pass.  Same products, same order: bit-identical to the plain loop (DR_CONV_NO_PIPE=1 keeps that one, A/B).
+  if constexpr (PT == 1 && CT <= 2 && FZ == 0) {
+    if (a.a_wbufs == 2) {
+      constexpr int kPipeBatch = 6;
+      float4 *wb1 = wl + (size_t)a.nuMax * CT * 64;
+      int *tapl2 = reinterpret_cast<int *>(wb1 + (size_t)a.nuMax * CT * 64);  // (the tap table sits behind BOTH weight buffers)
+      for (int i = tid; i < NU * TPC; i += kConvThreads) tapl2[i] = a.tapoff[cls.tap_base + i] * CIS;
+      const int *tp2 = tapl2 + sub;
+      int soff[kPipeBatch], dst[kPipeBatch];  // element offset of this lane's k-th staged float4 inside pass 0's slice (-1: outside the tensor), LDS float index (-1: none)
+#pragma unroll
+      for (int k = 0; k < kPipeBatch; ++k) {
+        const unsigned e = k * kConvThreads + tid;
+        const unsigned pos = e / C4, c4 = e - pos * C4;
+        const unsigned t = a.magicX ? __umulhi(pos, a.magicX) : pos, x = pos - t * a.TXI;
+        const unsigned z = a.magicY ? __umulhi(t, a.magicY) : t, y = t - z * a.TYI;
+        const int gz = iz0 + (int)z, gy = iy0 + (int)y, gx = ix0 + (int)x;
+        dst[k] = e < total ? (int)(pos * CIS + c4 * 4) : -1;
+        soff[k] = (e < total && gz >= 0 && gz < a.inD && gy >= 0 && gy < a.inH && gx >= 0 && gx < a.inW) ? (int)((((size_t)gz * a.inH + gy) * a.inW + gx) * a.inC + c4 * 4) : -1;
+      }
+      float4 v[kPipeBatch];
+      auto issue = [&](int p) {  // weights of pass p -> buffer p & 1 (LDS-DMA), its tile -> registers; nothing is waited for here
+        float4 *wb = (p & 1) ? wb1 : wl;
+        const float4 *wsrc = a.wpk + cls.w_base + ((size_t)p * NU * a.ctTot + ct0) * 64;
+        for (int e = wave; e < NU * CT; e += kConvThreads / 64) {
+          const int u = e / CT, ct = e - u * CT;
+          conv_a_dma16(wsrc + ((size_t)u * a.ctTot + ct) * 64 + lane, __builtin_amdgcn_readfirstlane(conv_a_lds_addr(wb + (size_t)e * 64)));
+        }
+#pragma unroll
+        for (int k = 0; k < kPipeBatch; ++k) {
+          v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (soff[k] >= 0) v[k] = *reinterpret_cast<const float4 *>(a.in + (size_t)soff[k] + (size_t)p * a.pass_stride);
+        }
+      };
+      __builtin_amdgcn_s_setprio(2);
+      issue(0);
+      for (int p = 0; p < a.npass; ++p) {
+#pragma unroll
+        for (int k = 0; k < kPipeBatch; ++k)
+          if (dst[k] >= 0) *reinterpret_cast<float4 *>(lds + dst[k]) = v[k];
+        conv_a_wait_dma();  // (everything in flight belongs to pass p: its tile, consumed just above, and its weights)
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
+        if (p + 1 < a.npass) issue(p + 1);  // in flight across the K loop, which touches neither those registers nor that weight buffer
+        const float4 *wp = ((p & 1) ? wb1 : wl) + lane;
+        conv_kloop_narrow<CT, PT>(tp2, TPC, NU, acc, [&](int toff, int u, float4 (&av)[CT], float4 (&bv)[PT]) { conv_chunk_load<CT, PT>(lds, wp, toff, u, base, av, bv); });
+        __syncthreads();  // everybody has left the tile before pass p + 1 overwrites it
+      }
+      float4 scv[CT], biv[CT];
+      conv_load_affine<CT>(a, g, ct0, scv, biv);
+      conv_epilogue<CT, PT>(a, cls, acc, scv, biv, wave, j, g, ct0, pz0, py0, px0);
+      return;
+    }
+  }
   for (int p = 0; p < a.npass; ++p) {
     // Staging waves get issue priority over co-resident workgroups' K loops: the sooner their loads are in flight the
     // sooner this workgroup can feed the MFMA pipe; the K loop of the neighbour fills the remaining issue slots.
@@ -1411,6 +1468,12 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   cl.lds_bytes = (size_t)TZI * TYI * TXI * CIS * 4 + (size_t)nu_max * CT * (bf3 ? 2048 : 1024) + (size_t)nu_max * TPC * 4 + 64;
   cl.bf3 = bf3 ? 1 : 0;
   a.zero16 = nullptr; a.a_slots = 0; a.a_wbufs = 1;
+  // k_conv with pipelined passes (see the kernel): small multi-pass layers on the one-position-tile instances whose tile is at most 6 loads per lane
+  if (ASYNC == 0 && !bf3 && !fz && PT == 1 && CT <= 2 && npass >= 2 && (size_t)TZI * TYI * TXI * (CI / 4) <= 6 * kConvThreads && !getenv("DR_CONV_NO_PIPE") &&
+      cl.lds_bytes + (size_t)nu_max * CT * 1024 <= kConvMaxLds) {
+    a.a_wbufs = 2;
+    cl.lds_bytes += (size_t)nu_max * CT * 1024;
+  }
   if (ASYNC == 4) cl.async = 4;  // (k_conv's LDS layout and grid: the tile, nuMax weight chunks, the tap table)
   if (ASYNC == 1) {
     cl.async = 1;
