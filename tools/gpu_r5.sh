@@ -35,6 +35,11 @@ PY
       timeout 300 python tools/profile_ops.py "${DR_OPS_RE:-.}" > $OUT/${TAG}_ops_tree.txt 2>&1; tail -1 $OUT/${TAG}_ops_tree.txt
       for so in build/ab/libdr_*.so; do n=$(basename $so .so); DR_MI355X_LIB=$PWD/$so timeout 300 python tools/profile_ops.py "${DR_OPS_RE:-.}" > $OUT/${TAG}_ops_$n.txt 2>&1; echo "--- $n"; tail -1 $OUT/${TAG}_ops_$n.txt; done ;;
     loop_raycast) timeout 900 python tools/exp_loop_raycast.py 100 > $OUT/${TAG}_loop_raycast.txt 2>&1; cat $OUT/${TAG}_loop_raycast.txt ;;
+    tune)  # three autotune runs per tuned shape WITH the committed table in place; merge at home: python tools/merge_tuned.py gpurun_out/<tag>_tune_*.txt
+      for r in 1 2 3; do
+        DR_CONV_PRINT=1 timeout 600 python tools/try_autotune.py 400 > $OUT/${TAG}_tune_head_$r.txt 2>&1; tail -3 $OUT/${TAG}_tune_head_$r.txt | cut -c1-150
+        DR_CONV_PRINT=1 timeout 600 python tools/try_autotune.py 400 320 512 48,4,4 > $OUT/${TAG}_tune_ship_$r.txt 2>&1; tail -3 $OUT/${TAG}_tune_ship_$r.txt | cut -c1-150
+      done ;;
     ops) timeout 600 python tools/profile_ops.py > $OUT/${TAG}_ops.txt 2>&1; tail -4 $OUT/${TAG}_ops.txt ;;
     pmc)  # counters in their own passes (--kernel-trace only), strictly sequential kernels (one engine, side stream off) -> profiles/r05_pmc_traffic.json, stamped with this tree's source hash
       export DR_MVS_NO_SIDE_STREAM=1
