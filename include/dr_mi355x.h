@@ -138,9 +138,10 @@ int drm_debug_conv(int device, const float *in, int D, int H, int W, int Cin, co
 
 /* Kernel unit-test hook for the fused tail of CostRegNet (conv11 + prob in one launch, csrc/tail_kernels.h; cva_mvsnet/models/module.py:571-575,598-599):
  * x (D/2, h/2, w/2, 16) and skip (D, h, w, 8) channels-last, host; w_deconv (16, 8, 3, 3, 3) and w_prob (1, 8, 3, 3, 3) in torch layout; scale8 / bias8 =
- * the folded BatchNorm of conv11; qy / zchunk: tile and depth-chunk overrides (0: chosen by size).  out: (D, h, w) logits. */
+ * the folded BatchNorm of conv11; qy / zchunk: tile and depth-chunk overrides (0: chosen by size); form: 1 = the transposed convolution on the matrix pipe
+ * (k_tail_m), 0 = on the vector pipe (k_tail).  out: (D, h, w) logits. */
 int drm_debug_tail(int device, const float *x, const float *skip, const float *w_deconv, const float *scale8, const float *bias8, const float *w_prob, int D,
-                   int h, int w, int qy, int zchunk, float *out);
+                   int h, int w, int qy, int zchunk, int form, float *out);
 
 /* ------------------------------------------------------------------ DrFusion */
 /* struct DrFusionOptions                                         dr_fusion.h:18-36 (same field order) */

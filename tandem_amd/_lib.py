@@ -58,7 +58,7 @@ SIGNATURES = {
     "drm_debug_conv": (C.c_int, [C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_int, f32p, C.c_int,
                                  f32p, C.POINTER(C.c_int)]),
-    "drm_debug_tail": (C.c_int, [C.c_int, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
+    "drm_debug_tail": (C.c_int, [C.c_int, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
     "drm_autotune": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "drm_set_view_shard": (C.c_int, [vp, C.c_int]),
     "drm_forward_phase": (C.c_int, [vp, C.c_int]),

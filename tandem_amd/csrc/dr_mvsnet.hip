@@ -196,10 +196,11 @@ struct MvsSwitches {
   bool costvol_v2 = on("DR_COSTVOL_V2");                 // k_costvol2 (the fallback for depth chunks that are not multiples of 4) everywhere
   bool regress_generic = on("DR_REGRESS_GENERIC");       // k_regress (the fallback for other plane counts) everywhere
   bool shard_allreduce = on("DR_SHARD_ALLREDUCE");       // view shard: round 2's all-reduce form instead of reduce + broadcast
-  // CostRegNet's conv11 + prob as ONE launch (k_tail, tail_kernels.h).  OPT-IN: correct (tests/test_tail_gpu.py) and its memory side works (26 us floor at
-  // stage 2 against the two-kernel path's 100), but the transposed convolution on the vector pipe costs 65 us there (scalar weight loads the compiler does
-  // not pipeline, fp32 VALU rate = fp32 MFMA rate, 1.8 x halo recomputation): 0.117 / 0.108 ms at stages 2 / 3 against 0.100 / 0.097 (profiles/r05_tail.txt)
-  bool tail_fused = on("DR_TAIL_FUSED");
+  // CostRegNet's conv11 + prob as ONE launch (tail_kernels.h).  OPT-IN: both forms are correct (tests/test_tail_gpu.py) and the memory side of the fusion works
+  // (the 78.6 MB tensor between the two layers is gone), but the transposed convolution x 1.8 (halo) and the prob stencil share the same issue slots -- fp32
+  // MFMAs and vector work serialise on a SIMD -- and nothing overlaps the kernel's memory side: 0.128 / 0.113 ms (matrix pipe) and 0.118 / 0.109 (vector pipe)
+  // at stages 2 / 3 against the two-kernel path's 0.100 / 0.096 (profiles/r05_tail.txt)
+  int tail_fused = num("DR_TAIL_FUSED", 0);              // 0: the two-kernel path; 1: k_tail_m (transposed convolution on the matrix pipe); 2: k_tail (on the vector pipe)
   int tail_qy = num("DR_TAIL_QY", 0), tail_zchunk = num("DR_TAIL_ZCHUNK", 0);  // tuning: k_tail's tile (quad rows: 4, 8, 16, 32) and depth planes per workgroup (0: chosen by size)
   bool vol_split = !on("DR_VOL_NO_SPLIT");               // stage 1's 32-channel cost volume as two 16-channel halves (DevTensor::split); off: one (D,h,w,32) tensor (A/B)
 #ifdef DR_PARITY_HOOKS
@@ -571,7 +572,7 @@ class MvsEngine {
         else snprintf(kn, sizeof kn, sw_.costvol_v1 ? "k_costvol<%d>" : (sw_.costvol_v2 ? "k_costvol2<%d>" : "k_costvol3<%d>"), Cc);
       }
       else if (o.kind == Op::PROB) snprintf(kn, sizeof kn, sw_.prob_v1 ? "k_prob" : "k_prob2");
-      else if (o.kind == Op::TAIL) snprintf(kn, sizeof kn, "k_tail<%d>", std::max(3, tail_nout(o.tail.QY, o.tail.QX)));
+      else if (o.kind == Op::TAIL) snprintf(kn, sizeof kn, o.tail.wmf ? "k_tail_m<%d>" : "k_tail<%d>", std::max(3, tail_nout(o.tail.QY, o.tail.QX)));
       else if (o.kind == Op::REGRESS) snprintf(kn, sizeof kn, "k_regress");
       else if (o.kind == Op::PREPROCESS) snprintf(kn, sizeof kn, "k_preprocess");
       else if (o.kind == Op::SKIPUP) snprintf(kn, sizeof kn, "k_skip_up<%d>", o.stage);
@@ -902,8 +903,10 @@ class MvsEngine {
         t.wd = plan_arena_->upload(tail_pack_deconv(w11.data.data()));
         t.sb = plan_arena_->upload(sc);
         t.wp = plan_arena_->upload(tail_pack_prob(wpr.data.data()));
-        tail_pick_tile(h, w, t.QY, t.QX);
-        if (sw_.tail_qy == 4 || sw_.tail_qy == 8 || sw_.tail_qy == 16 || sw_.tail_qy == 32) { t.QY = sw_.tail_qy; t.QX = 256 / t.QY; }
+        const bool mf = sw_.tail_fused == 1;
+        t.wmf = mf ? plan_arena_->upload(tail_pack_deconv_mfma(w11.data.data())) : nullptr;
+        tail_pick_tile(h, w, t.QY, t.QX, mf);
+        if (sw_.tail_qy == 4 || sw_.tail_qy == 8 || sw_.tail_qy == 16 || (sw_.tail_qy == 32 && !mf)) { t.QY = sw_.tail_qy; t.QX = 256 / t.QY; }
         t.zchunk = sw_.tail_zchunk > 0 ? std::min(D, sw_.tail_zchunk) : tail_pick_zchunk(D, h, w, t.QY, t.QX);
         const double N = (double)D * h * w;
         o.flops = 2.0 * 3.375 * 16 * 8 * N + 2.0 * 216 * N;  // the algorithmic MACs of both layers (halo recomputation not counted)
@@ -1473,9 +1476,9 @@ int drm_debug_conv(int device, const float *in, int D, int H, int W, int Cin, co
 
 /* Kernel unit-test hook for k_tail (tail_kernels.h): conv11 (ConvTranspose3d 16 -> 8, k 3, s 2, p 1, op 1; folded BN scale / bias; ReLU; + skip) followed by prob
  * (Conv3d 8 -> 1, k 3, p 1).  x: (D/2, h/2, w/2, 16), skip: (D, h, w, 8) channels-last; w_deconv (16, 8, 3, 3, 3), w_prob (1, 8, 3, 3, 3) torch layouts;
- * qy: quad rows of the tile (0: chosen by size), zchunk: depth planes per workgroup (0: chosen).  out: (D, h, w) logits. */
+ * qy: quad rows of the tile (0: chosen by size), zchunk: depth planes per workgroup (0: chosen), form: 1 = k_tail_m (matrix pipe), 0 = k_tail.  out: (D, h, w) logits. */
 int drm_debug_tail(int device, const float *x, const float *skip, const float *w_deconv, const float *scale8, const float *bias8, const float *w_prob, int D, int h,
-                   int w, int qy, int zchunk, float *out) {
+                   int w, int qy, int zchunk, int form, float *out) {
   return guarded([&] {
     using namespace dr;
     int n = 0;
@@ -1493,8 +1496,10 @@ int drm_debug_tail(int device, const float *x, const float *skip, const float *w
     t.wp = arena.upload(tail_pack_prob(w_prob));
     float *d_out = arena.upload(std::vector<float>((size_t)D * h * w, -12345.f));
     t.out = d_out; t.D = D; t.h = h; t.w = w;
-    tail_pick_tile(h, w, t.QY, t.QX);
-    if (qy == 4 || qy == 8 || qy == 16 || qy == 32) { t.QY = qy; t.QX = 256 / qy; }
+    const bool mf = form == 1;  // 1: k_tail_m (matrix pipe), else k_tail (vector pipe)
+    t.wmf = mf ? arena.upload(tail_pack_deconv_mfma(w_deconv)) : nullptr;
+    tail_pick_tile(h, w, t.QY, t.QX, mf);
+    if (qy == 4 || qy == 8 || qy == 16 || (qy == 32 && !mf)) { t.QY = qy; t.QX = 256 / qy; }
     t.zchunk = zchunk > 0 ? std::min(D, zchunk) : tail_pick_zchunk(D, h, w, t.QY, t.QX);
     launch_tail(t, nullptr);
     DR_HIP(hipDeviceSynchronize());

@@ -30,6 +30,7 @@ struct TailArgs {
   const float *wd;    // [27][16][8]: transposed-convolution weights, tap = (kz * 3 + ky) * 3 + kx, then input channel, then output channel
   const float *sb;    // [16]: folded BatchNorm scale[8], bias[8]
   const float *wp;    // [27][8]: prob weights, tap-major (as k_prob2)
+  const float *wmf;   // k_tail_m: the transposed-convolution weights as MFMA A fragments [kz][ky][jb][lane][4] (nullptr: k_tail, the vector-pipe form)
   float *out;         // logits (D, h, w)
   int D, h, w;        // OUTPUT dims (all even)
   int QY, QX;         // quads per workgroup and plane, QY * QX == 256
@@ -38,6 +39,7 @@ struct TailArgs {
 
 constexpr int kTailThreads = 256;
 typedef float tail_f2 __attribute__((ext_vector_type(2)));
+typedef float tail_fx4 __attribute__((ext_vector_type(4)));
 
 // (the pointers are separate __restrict__ parameters, not members of `a`: only then may hipcc keep the weight loads on the scalar unit INSIDE the
 // plane loop -- behind the kernel's own global stores a load through a plain pointer has to go through the vector memory path)
@@ -191,20 +193,22 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(const float *__restrict__
     if (zz >= z0 - 1 && zz >= 0 && zz < D) {
 #endif
       const float4 *lo = tail_lds + (size_t)b * 2 * SP, *hi = lo + SP;
+      // taps outermost: the 24 wave-uniform weights of a (kh, kw) tap are fetched (scalar loads) ONCE for all NOUT logits of the lane; lanes without a
+      // logit in a slot (go < 0) compute on a clamped position and never store
 #pragma unroll
-      for (int s = 0; s < NOUT; ++s) {
-        if (go[s] < 0) continue;
+      for (int kh = 0; kh < 3; ++kh) {
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
+        for (int kw = 0; kw < 3; ++kw) {
+          const tail_f2 *w2 = reinterpret_cast<const tail_f2 *>(gwp + ((2 * 3 + kh) * 3 + kw) * 8), *w1 = reinterpret_cast<const tail_f2 *>(gwp + ((1 * 3 + kh) * 3 + kw) * 8),
+                        *w0 = reinterpret_cast<const tail_f2 *>(gwp + ((0 * 3 + kh) * 3 + kw) * 8);
+          const tail_f2 a2[4] = {w2[0], w2[1], w2[2], w2[3]}, a1[4] = {w1[0], w1[1], w1[2], w1[3]}, a0[4] = {w0[0], w0[1], w0[2], w0[3]};
 #pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
+          for (int s = 0; s < NOUT; ++s) {
             const int p = sp[s] + kh * SW + kw;
             const float4 l4 = lo[p], h4 = hi[p];
             const tail_f2 x01 = {l4.x, l4.y}, x23 = {l4.z, l4.w}, x45 = {h4.x, h4.y}, x67 = {h4.z, h4.w};
-            const tail_f2 *w2 = reinterpret_cast<const tail_f2 *>(gwp + ((2 * 3 + kh) * 3 + kw) * 8), *w1 = reinterpret_cast<const tail_f2 *>(gwp + ((1 * 3 + kh) * 3 + kw) * 8),
-                          *w0 = reinterpret_cast<const tail_f2 *>(gwp + ((0 * 3 + kh) * 3 + kw) * 8);
 #define DR_TAIL_DOT8(A, WK) A = __builtin_elementwise_fma(x01, WK[0], A); A = __builtin_elementwise_fma(x23, WK[1], A); A = __builtin_elementwise_fma(x45, WK[2], A); A = __builtin_elementwise_fma(x67, WK[3], A)
-            DR_TAIL_DOT8(acc[s][0], w2); DR_TAIL_DOT8(acc[s][1], w1); DR_TAIL_DOT8(acc[s][2], w0);
+            DR_TAIL_DOT8(acc[s][0], a2); DR_TAIL_DOT8(acc[s][1], a1); DR_TAIL_DOT8(acc[s][2], a0);
 #undef DR_TAIL_DOT8
           }
         }
@@ -220,10 +224,229 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(const float *__restrict__
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// k_tail_m: the same fusion with phase A on the MATRIX pipe.  k_tail's vector-pipe transposed convolution is bound by operand delivery (one scalar
+// weight pair per packed FMA, profiles/r05_tail.txt); as an implicit GEMM the layer has the weights as the A operand, resident in REGISTERS for the
+// whole kernel: rows m = (x parity ob, output channel co) = 16, columns n = 16 consecutive input cells along x, K = (input position (ia, jb) of the
+// quad's 2 x 2 neighbourhood) x 16 input channels.  For output row parity a and depth-plane pair t that is 8 (1 + a) MFMAs of 16 x 16 x 4 per 16 cells,
+// 24 per input row and plane pair; x parity 0 uses only the jb = 0 half of K (zero weights in the other: 75 % of the products are useful).
+//   A fragment (kz, ky, jb), lane (m, g), component q:  W[kz][ky][kx = ob - 2 jb + 1][ci = 4 g + q][co]   (18 float4 per lane = 72 VGPRs)
+//   B fragment (ia, jb) of input plane t, lane (n, g):  x[t][i0 + ia][j0 + n + jb][4 g .. 4 g + 3]         (one ds_read_b128 per 4 MFMAs)
+// The input planes (conv9's output, (QY + 1) x (QX + 1) positions of the tile) live in a two-slot LDS ring: plane k serves the three output planes
+// 2k - 1, 2k, 2k + 1 and is fetched once per depth chunk; the slot of plane k + 1 is filled (global -> registers at the top of the iteration, registers
+// -> LDS at its end) during the iteration of output plane 2k, which reads plane k only.  Epilogue (BN, ReLU, + conv0, zero outside the image), staged
+// plane, phase B and the chunk march are k_tail's.  QX must be a multiple of 16.
+constexpr int kTailInStride = 20;  // floats per staged input position (16 channels + 4: consecutive positions start 5 bank groups apart)
+constexpr int kTailStage = 6;      // float4 per lane and input plane ((QY + 1)(QX + 1) * 4 <= 6 * 256 for the three tile forms)
+
+template <int KZ>
+__device__ __forceinline__ void tail_m_block(const float4 (&Wf)[3][3][2], const float *ib, int IW, tail_fx4 (&acc)[2]) {
+  float4 B[2][2];
+#pragma unroll
+  for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) B[ia][jb] = *reinterpret_cast<const float4 *>(ib + (ia * IW + jb) * kTailInStride);
+#define DR_TM(A, KY, IA)                                                                                                          \
+  _Pragma("unroll") for (int jb = 0; jb < 2; ++jb) {                                                                              \
+    acc[A] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wf[KZ][KY][jb].x, B[IA][jb].x, acc[A], 0, 0, 0);                                \
+    acc[A] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wf[KZ][KY][jb].y, B[IA][jb].y, acc[A], 0, 0, 0);                                \
+    acc[A] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wf[KZ][KY][jb].z, B[IA][jb].z, acc[A], 0, 0, 0);                                \
+    acc[A] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wf[KZ][KY][jb].w, B[IA][jb].w, acc[A], 0, 0, 0);                                \
+  }
+  // output row 2 i + a reads input row i + ia through tap ky = a - 2 ia + 1
+  DR_TM(0, 1, 0) DR_TM(1, 2, 0) DR_TM(1, 0, 1)
+#undef DR_TM
+}
+
+template <int NOUT>
+__global__ __launch_bounds__(kTailThreads) void k_tail_m(const float *__restrict__ gx, const float *__restrict__ gskip, const float *__restrict__ gwmf,
+                                                         const float *__restrict__ gsb, const float *__restrict__ gwp, float *__restrict__ gout, const TailArgs a) {
+  extern __shared__ float4 tail_lds[];  // [channel half 2][SH * SW] ONE staged conv11 plane (80 KB per workgroup in all: two of them per CU), then [slot 2][(QY + 1)(QX + 1)][kTailInStride] input planes
+  const int QX = a.QX, QY = a.QY, SW = 2 * QX, SH = 2 * QY, SP = SW * SH, TY = SH - 4, TX = SW - 4, IW = QX + 1, IP = IW * (QY + 1), CG = QX >> 4;
+  float *in_lds = reinterpret_cast<float *>(tail_lds + (size_t)2 * SP);
+  const int per = (a.nwg + 7) >> 3, nid = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+  if (nid >= a.nwg) return;
+  const int bz = nid % a.gz, bxy = nid / a.gz, bx = bxy % a.gx, by = bxy / a.gx;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n = lane & 15, g = lane >> 4, ob = g >> 1, ch0 = 4 * (g & 1);
+  const int D = a.D, h = a.h, w = a.w, Dh = D >> 1, hh = h >> 1, wh = w >> 1;
+  const int y0 = by * TY, x0 = bx * TX, z0 = bz * a.zchunk, z1 = min(D, z0 + a.zchunk);
+  const int I0 = (y0 >> 1) - 1, J0 = (x0 >> 1) - 1, Y0 = y0 - 2, X0 = x0 - 2;
+  const size_t in_plane = (size_t)hh * wh * 16, skip_plane = (size_t)h * w * 8;
+
+  float4 Wf[3][3][2];
+#pragma unroll
+  for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) Wf[kz][ky][jb] = reinterpret_cast<const float4 *>(gwmf)[((kz * 3 + ky) * 2 + jb) * 64 + lane];
+  const float4 sc4 = *reinterpret_cast<const float4 *>(gsb + ch0), bi4 = *reinterpret_cast<const float4 *>(gsb + 8 + ch0);
+
+  // ---- input planes: this lane's share of a plane's (QY + 1)(QX + 1) x 4 float4
+  int soff[kTailStage], doff[kTailStage];
+#pragma unroll
+  for (int k = 0; k < kTailStage; ++k) {
+    const int e = tid + k * kTailThreads, pos = e >> 2, c4 = e & 3, iy = pos / IW, ix = pos - iy * IW, gi = I0 + iy, gj = J0 + ix;
+    doff[k] = pos < IP ? pos * kTailInStride + c4 * 4 : -1;
+    soff[k] = (pos < IP && gi >= 0 && gi < hh && gj >= 0 && gj < wh) ? (gi * wh + gj) * 16 + c4 * 4 : -1;
+  }
+  float4 pv[kTailStage];
+  auto load_plane = [&](int k) {  // (planes outside the volume stage zeros: their products vanish)
+#pragma unroll
+    for (int i = 0; i < kTailStage; ++i) {
+      pv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (soff[i] >= 0 && k >= 0 && k < Dh) pv[i] = ld4(gx + (size_t)k * in_plane + soff[i]);
+    }
+  };
+  auto store_plane = [&](int k) {
+    float *dst = in_lds + (size_t)(k & 1) * IP * kTailInStride;
+#pragma unroll
+    for (int i = 0; i < kTailStage; ++i)
+      if (doff[i] >= 0) *reinterpret_cast<float4 *>(dst + doff[i]) = pv[i];
+  };
+
+  // ---- phase A: one output plane of conv11 for this wave's FOUR units (input row, group of 16 cells; QY * QX / 16 = 16 units per plane) -> staged buffer sb.
+  // One wave per SIMD and nobody else to hide a latency: the residual operands of all four units are requested first (they return under the MFMAs), the
+  // units' MFMAs run back to back, the epilogues come last.
+  constexpr int kUnits = 4;
+  float4 rs[kUnits][2];
+  bool ok[kUnits][2];
+  int spos[kUnits];
+  tail_fx4 cacc[kUnits][2];
+#pragma unroll
+  for (int k = 0; k < kUnits; ++k) {
+    const int uu = wave + k * (kTailThreads / 64), ui = uu / CG, cg = uu - ui * CG;
+    spos[k] = (2 * ui) * SW + 2 * (cg * 16 + n) + ob;
+  }
+  auto phase_a_mma = [&](int za) {  // residual loads and MFMAs of output plane za -> rs / ok / cacc (no LDS write: phase B may still be reading the staged plane)
+    const bool plane_ok = za >= 0 && za < D;
+    const int c = za & 1, k0 = za >> 1;
+#pragma unroll
+    for (int k = 0; k < kUnits; ++k) {
+      const int uu = wave + k * (kTailThreads / 64), ui = uu / CG, cg = uu - ui * CG;
+      const int xx = X0 + 2 * (cg * 16 + n) + ob;
+#pragma unroll
+      for (int oa = 0; oa < 2; ++oa) {
+        const int yy = Y0 + 2 * ui + oa;
+        ok[k][oa] = plane_ok && yy >= 0 && yy < h && xx >= 0 && xx < w;
+        rs[k][oa] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok[k][oa]) rs[k][oa] = ld4(gskip + (size_t)za * skip_plane + ((size_t)yy * w + xx) * 8 + ch0);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kUnits; ++k) {
+      cacc[k][0] = cacc[k][1] = tail_fx4{0.f, 0.f, 0.f, 0.f};
+#ifdef DR_TAIL_ABL_NOA  // timing ablation (results wrong by design)
+      if (plane_ok && za > (1 << 30)) {
+#else
+      if (plane_ok) {
+#endif
+        const int uu = wave + k * (kTailThreads / 64), ui = uu / CG, cg = uu - ui * CG;
+        const float *ib = in_lds + (size_t)(ui * IW + cg * 16 + n) * kTailInStride + g * 4;
+        const float *s0 = ib + (size_t)(k0 & 1) * IP * kTailInStride, *s1 = ib + (size_t)((k0 + 1) & 1) * IP * kTailInStride;
+        if (c == 0) tail_m_block<1>(Wf, s0, IW, cacc[k]);                                                // even plane 2k: input plane k, tap kz = 1
+        else { tail_m_block<2>(Wf, s0, IW, cacc[k]); tail_m_block<0>(Wf, s1, IW, cacc[k]); }             // odd plane 2k + 1: plane k (kz = 2), plane k + 1 (kz = 0)
+      }
+    }
+  };
+  auto phase_a_store = [&]() {  // BN, ReLU, + conv0, zero outside the image -> the staged plane
+    float4 *half = tail_lds + ((g & 1) ? SP : 0);
+#pragma unroll
+    for (int k = 0; k < kUnits; ++k)
+#pragma unroll
+      for (int oa = 0; oa < 2; ++oa) {
+        float4 v;
+        v.x = fmaxf(__builtin_fmaf(cacc[k][oa][0], sc4.x, bi4.x), 0.f) + rs[k][oa].x;
+        v.y = fmaxf(__builtin_fmaf(cacc[k][oa][1], sc4.y, bi4.y), 0.f) + rs[k][oa].y;
+        v.z = fmaxf(__builtin_fmaf(cacc[k][oa][2], sc4.z, bi4.z), 0.f) + rs[k][oa].z;
+        v.w = fmaxf(__builtin_fmaf(cacc[k][oa][3], sc4.w, bi4.w), 0.f) + rs[k][oa].w;
+        if (!ok[k][oa]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        half[spos[k] + oa * SW] = v;
+      }
+  };
+
+  // ---- phase B geometry (as k_tail)
+  int sp[NOUT], go[NOUT];
+#pragma unroll
+  for (int s = 0; s < NOUT; ++s) {
+    const int o = tid + s * kTailThreads, ty = o / TX, tx = o - ty * TX;
+    const int yo = y0 + ty, xo = x0 + tx;
+    const bool live = o < TY * TX && yo < h && xo < w;
+    sp[s] = (min(ty, TY - 1) + 1) * SW + tx + 1;
+    go[s] = live ? yo * w + xo : -1;
+  }
+  tail_f2 acc[NOUT][3];
+#pragma unroll
+  for (int s = 0; s < NOUT; ++s) acc[s][0] = acc[s][1] = acc[s][2] = tail_f2{0.f, 0.f};
+
+  // prologue: the two input planes the first output plane (z0 - 1) can need
+  const int zf = z0 - 1, P0 = zf >= 0 ? zf >> 1 : 0;
+  load_plane(P0); store_plane(P0);
+  load_plane(P0 + 1); store_plane(P0 + 1);
+  int loaded_hi = P0 + 1;
+  for (int zz = z0 - 2; zz <= z1; ++zz) {
+    __syncthreads();  // the staged plane is zz; the input ring is complete for output plane zz + 1
+    const int za = zz + 1;
+    const int kn = (za + 2) >> 1;  // highest input plane output plane za + 1 will read
+    const bool fetch = za + 1 <= z1 && kn > loaded_hi;  // (only in iterations that read ONE input plane: the other slot is free)
+    if (fetch) load_plane(kn);
+    if (za <= z1) phase_a_mma(za);
+#ifdef DR_TAIL_ABL_NOB
+    if (zz > (1 << 30)) {
+#else
+    if (zz >= z0 - 1 && zz >= 0 && zz < D) {
+#endif
+      const float4 *lo = tail_lds, *hi = lo + SP;
+      // taps outermost: the 24 wave-uniform weights of a (kh, kw) tap are fetched (scalar loads) ONCE for all NOUT logits of the lane; lanes without a
+      // logit in a slot (go < 0) compute on a clamped position and never store
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const tail_f2 *w2 = reinterpret_cast<const tail_f2 *>(gwp + ((2 * 3 + kh) * 3 + kw) * 8), *w1 = reinterpret_cast<const tail_f2 *>(gwp + ((1 * 3 + kh) * 3 + kw) * 8),
+                        *w0 = reinterpret_cast<const tail_f2 *>(gwp + ((0 * 3 + kh) * 3 + kw) * 8);
+          const tail_f2 a2[4] = {w2[0], w2[1], w2[2], w2[3]}, a1[4] = {w1[0], w1[1], w1[2], w1[3]}, a0[4] = {w0[0], w0[1], w0[2], w0[3]};
+#pragma unroll
+          for (int s = 0; s < NOUT; ++s) {
+            const int p = sp[s] + kh * SW + kw;
+            const float4 l4 = lo[p], h4 = hi[p];
+            const tail_f2 x01 = {l4.x, l4.y}, x23 = {l4.z, l4.w}, x45 = {h4.x, h4.y}, x67 = {h4.z, h4.w};
+#define DR_TAIL_DOT8(A, WK) A = __builtin_elementwise_fma(x01, WK[0], A); A = __builtin_elementwise_fma(x23, WK[1], A); A = __builtin_elementwise_fma(x45, WK[2], A); A = __builtin_elementwise_fma(x67, WK[3], A)
+            DR_TAIL_DOT8(acc[s][0], a2); DR_TAIL_DOT8(acc[s][1], a1); DR_TAIL_DOT8(acc[s][2], a0);
+#undef DR_TAIL_DOT8
+          }
+        }
+      }
+    }
+    const int zo = zz - 1;
+#pragma unroll
+    for (int s = 0; s < NOUT; ++s) {
+      if (zo >= z0 && zo < z1 && go[s] >= 0) gout[(size_t)zo * h * w + go[s]] = acc[s][0].x + acc[s][0].y;
+      acc[s][0] = acc[s][1]; acc[s][1] = acc[s][2]; acc[s][2] = tail_f2{0.f, 0.f};
+    }
+    __syncthreads();  // everybody has read staged plane zz
+    if (za <= z1) phase_a_store();
+    if (fetch) { store_plane(kn); loaded_hi = kn; }
+  }
+}
+
+// weights of the MFMA form: [kz][ky][jb][lane][q] (see k_tail_m)
+inline std::vector<float> tail_pack_deconv_mfma(const float *w /* (16, 8, 3, 3, 3) */) {
+  std::vector<float> o((size_t)18 * 64 * 4, 0.f);
+  for (int kz = 0; kz < 3; ++kz) for (int ky = 0; ky < 3; ++ky) for (int jb = 0; jb < 2; ++jb) for (int lane = 0; lane < 64; ++lane) {
+    const int m = lane & 15, obb = m >> 3, co = m & 7, gg = lane >> 4, kx = obb - 2 * jb + 1;
+    if (kx < 0 || kx > 2) continue;
+    for (int q = 0; q < 4; ++q) o[((size_t)((kz * 3 + ky) * 2 + jb) * 64 + lane) * 4 + q] = w[((size_t)(4 * gg + q) * 8 + co) * 27 + (kz * 3 + ky) * 3 + kx];
+  }
+  return o;
+}
+
 // Tile shape (quads per workgroup QY x QX, QY * QX = 256) that computes the fewest `conv11` positions for an h x w plane.
-inline void tail_pick_tile(int h, int w, int &QY, int &QX) {
+inline void tail_pick_tile(int h, int w, int &QY, int &QX, bool mfma = false) {
   long best = -1;
   for (int qy : {4, 8, 16, 32}) {
+    if (mfma && qy == 32) continue;  // (k_tail_m works on groups of 16 cells along x)
     const int qx = 256 / qy, TY = 2 * qy - 4, TX = 2 * qx - 4;
     const long cost = (long)cdiv(h, TY) * cdiv(w, TX);
     if (best < 0 || cost < best) { best = cost; QY = qy; QX = qx; }
@@ -231,6 +454,7 @@ inline void tail_pick_tile(int h, int w, int &QY, int &QX) {
 }
 inline int tail_nout(int QY, int QX) { return cdiv((2 * QY - 4) * (2 * QX - 4), kTailThreads); }
 inline size_t tail_lds_bytes(int QY, int QX) { return (size_t)2 * 2 * (2 * QY) * (2 * QX) * sizeof(float4); }
+inline size_t tail_m_lds_bytes(int QY, int QX) { return tail_lds_bytes(QY, QX) / 2 + (size_t)2 * (QY + 1) * (QX + 1) * kTailInStride * sizeof(float); }
 
 // torch layouts -> the kernel's: ConvTranspose3d weight (16, 8, 3, 3, 3) -> [tap][ci][co]; prob weight (1, 8, 3, 3, 3) -> [tap][ci]
 inline std::vector<float> tail_pack_deconv(const float *w) {
@@ -261,6 +485,14 @@ inline void launch_tail(TailArgs a, hipStream_t st) {
     if (!(allowed.load() & bit)) { DR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); allowed.fetch_or(bit); }
   };
   const int nout = tail_nout(a.QY, a.QX);
+  if (a.wmf) {
+    if (a.QX % 16) fail(DR_ERR_ARG, "launch_tail: the MFMA form needs QX %% 16 == 0 (QX = %d)", a.QX);
+    const size_t ldm = tail_m_lds_bytes(a.QY, a.QX);
+    if (nout <= 3) { allow(reinterpret_cast<const void *>(k_tail_m<3>), 4); hipLaunchKernelGGL(k_tail_m<3>, grid, dim3(kTailThreads), ldm, st, a.x, a.skip, a.wmf, a.sb, a.wp, a.out, a); }
+    else if (nout == 4) { allow(reinterpret_cast<const void *>(k_tail_m<4>), 8); hipLaunchKernelGGL(k_tail_m<4>, grid, dim3(kTailThreads), ldm, st, a.x, a.skip, a.wmf, a.sb, a.wp, a.out, a); }
+    else fail(DR_ERR_ARG, "launch_tail: tile %d x %d needs %d logits per lane", TY, TX, nout);
+    return;
+  }
   if (nout <= 3) { allow(reinterpret_cast<const void *>(k_tail<3>), 1); hipLaunchKernelGGL(k_tail<3>, grid, dim3(kTailThreads), lds, st, a.x, a.skip, a.wd, a.sb, a.wp, a.out, a); }
   else if (nout == 4) { allow(reinterpret_cast<const void *>(k_tail<4>), 2); hipLaunchKernelGGL(k_tail<4>, grid, dim3(kTailThreads), lds, st, a.x, a.skip, a.wd, a.sb, a.wp, a.out, a); }
   else fail(DR_ERR_ARG, "launch_tail: tile %d x %d needs %d logits per lane", TY, TX, nout);

@@ -252,8 +252,8 @@ def debug_conv(x, weight, stride=(1, 1, 1), transposed=False, scale=None, bias=N
     return out
 
 
-def debug_tail(x, skip, w_deconv, scale, bias, w_prob, qy=0, zchunk=0, device=0):
-    """Kernel unit-test hook for k_tail: x (D/2, h/2, w/2, 16), skip (D, h, w, 8) channels-last; torch-layout weights; returns (D, h, w) logits."""
+def debug_tail(x, skip, w_deconv, scale, bias, w_prob, qy=0, zchunk=0, form=1, device=0):
+    """Kernel unit-test hook for k_tail_m (form=1: matrix pipe) / k_tail (form=0: vector pipe): x (D/2, h/2, w/2, 16), skip (D, h, w, 8) channels-last; torch-layout weights; returns (D, h, w) logits."""
     x, skip = np.ascontiguousarray(x, np.float32), np.ascontiguousarray(skip, np.float32)
     D, h, w, _ = skip.shape
     assert x.shape == (D // 2, h // 2, w // 2, 16) and skip.shape[3] == 8
@@ -261,5 +261,5 @@ def debug_tail(x, skip, w_deconv, scale, bias, w_prob, qy=0, zchunk=0, device=0)
     assert wd.shape == (16, 8, 3, 3, 3) and wp.shape == (1, 8, 3, 3, 3)
     sc, bi = np.ascontiguousarray(scale, np.float32), np.ascontiguousarray(bias, np.float32)
     out = np.empty((D, h, w), np.float32)
-    check(_lib.lib().drm_debug_tail(device, fptr(x), fptr(skip), fptr(wd), fptr(sc), fptr(bi), fptr(wp), D, h, w, int(qy), int(zchunk), fptr(out)))
+    check(_lib.lib().drm_debug_tail(device, fptr(x), fptr(skip), fptr(wd), fptr(sc), fptr(bi), fptr(wp), D, h, w, int(qy), int(zchunk), int(form), fptr(out)))
     return out

@@ -25,7 +25,10 @@ def reference(x, skip, wd, scale, bias, wp):
     (16, 60, 124, 0, 0), (16, 60, 124, 4, 6), (16, 60, 124, 16, 16), (6, 120, 60, 32, 0),
     (2, 2, 2, 8, 0),                               # the smallest volume: one input position
 ])
-def test_tail_matches_torch(D, h, w, qy, zchunk):
+@pytest.mark.parametrize("form", [1, 0])
+def test_tail_matches_torch(D, h, w, qy, zchunk, form):
+    if form == 1 and qy == 32:
+        pytest.skip("k_tail_m works on groups of 16 cells along x: no 32 x 8 tile")
     from tandem_amd.dr_mvsnet import debug_tail
     rng = np.random.RandomState(D * 1000 + h * 10 + w + qy)
     x = rng.standard_normal((D // 2, h // 2, w // 2, 16)).astype(np.float32)
@@ -35,9 +38,9 @@ def test_tail_matches_torch(D, h, w, qy, zchunk):
     scale = (0.5 + rng.rand(8)).astype(np.float32)
     bias = (rng.standard_normal(8) * 0.3).astype(np.float32)
     ref = reference(x, skip, wd, scale, bias, wp)
-    out = debug_tail(x, skip, wd, scale, bias, wp, qy=qy, zchunk=zchunk)
+    out = debug_tail(x, skip, wd, scale, bias, wp, qy=qy, zchunk=zchunk, form=form)
     err = np.abs(out - ref).max()
-    assert err <= 2e-5 * np.abs(ref).max(), f"max err {err} of range {np.abs(ref).max()} (qy {qy}, zchunk {zchunk})"
+    assert err <= 2e-5 * np.abs(ref).max(), f"max err {err} of range {np.abs(ref).max()} (form {form}, qy {qy}, zchunk {zchunk})"
 
 
 def test_tail_fused_and_two_kernel_paths_agree(trained_blob, monkeypatch):
@@ -47,11 +50,11 @@ def test_tail_fused_and_two_kernel_paths_agree(trained_blob, monkeypatch):
     from tandem_amd.dr_mvsnet import DrMvsnet
     win = scene.make_window(96, 160, 4, seed=11)
     outs = []
-    for off in (False, True):
+    for off in (False, True, False):
         if off:
             monkeypatch.delenv("DR_TAIL_FUSED", raising=False)
         else:
-            monkeypatch.setenv("DR_TAIL_FUSED", "1")
+            monkeypatch.setenv("DR_TAIL_FUSED", "1" if not outs else "2")  # first k_tail_m, last k_tail
         m = DrMvsnet(trained_blob)
         m.upload(96, 160, 4, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), win["depth_min"], win["depth_max"], 2.5)
         m.forward(1)
@@ -59,6 +62,7 @@ def test_tail_fused_and_two_kernel_paths_agree(trained_blob, monkeypatch):
         assert any(o.endswith(".tail") for o in ops) != off and any(o.endswith(".conv11") for o in ops) == off, ops
         outs.append([m.stage_output(s) for s in (1, 2, 3)])
         m.close()
-    for s in range(3):
-        d = np.abs(outs[0][s][0] - outs[1][s][0])
-        assert d.mean() < 2e-5 and d.max() < 2e-3, (s + 1, d.mean(), d.max())
+    for fused in (0, 2):
+        for s in range(3):
+            d = np.abs(outs[fused][s][0] - outs[1][s][0])
+            assert d.mean() < 2e-5 and d.max() < 2e-3, (fused, s + 1, d.mean(), d.max())

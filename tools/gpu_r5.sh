@@ -40,6 +40,10 @@ PY
         DR_CONV_PRINT=1 timeout 600 python tools/try_autotune.py 400 > $OUT/${TAG}_tune_head_$r.txt 2>&1; tail -3 $OUT/${TAG}_tune_head_$r.txt | cut -c1-150
         DR_CONV_PRINT=1 timeout 600 python tools/try_autotune.py 400 320 512 48,4,4 > $OUT/${TAG}_tune_ship_$r.txt 2>&1; tail -3 $OUT/${TAG}_tune_ship_$r.txt | cut -c1-150
       done ;;
+    ab_tail)  # DR_TAIL_FUSED=1 per-op profile with every A/B library under build/ab
+      for so in build/ab/libdr_*.so; do nme=$(basename $so .so); echo "--- $nme: $(DR_TAIL_FUSED=1 DR_MI355X_LIB=$PWD/$so timeout 300 python tools/profile_ops.py "tail" 2>&1 | tail -1)"; done ;;
+    ops_tail)  # per-op profile with the fused tail forms beside the default
+      for f in 0 1 2; do DR_TAIL_FUSED=$f timeout 300 python tools/profile_ops.py "tail|conv11|prob" > $OUT/${TAG}_ops_tail$f.txt 2>&1; echo "DR_TAIL_FUSED=$f: $(tail -1 $OUT/${TAG}_ops_tail$f.txt)"; done ;;
     ops) timeout 600 python tools/profile_ops.py > $OUT/${TAG}_ops.txt 2>&1; tail -4 $OUT/${TAG}_ops.txt ;;
     pmc)  # counters in their own passes (--kernel-trace only), strictly sequential kernels (one engine, side stream off) -> profiles/r05_pmc_traffic.json, stamped with this tree's source hash
       export DR_MVS_NO_SIDE_STREAM=1
