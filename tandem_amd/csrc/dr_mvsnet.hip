@@ -192,6 +192,7 @@ struct MvsSwitches {
   std::string autotune_only = getenv("DR_AUTOTUNE_ONLY") ? getenv("DR_AUTOTUNE_ONLY") : "";  // tuning: restrict autotune to layers whose name contains this
   int cv_dchunk[3] = {num("DR_CV_DCHUNK1", 0), num("DR_CV_DCHUNK2", 0), num("DR_CV_DCHUNK3", 0)};  // tuning: depth planes per cost-volume workgroup (0: default)
   int prob_zchunk = num("DR_PROB_ZCHUNK", 0);            // tuning: z-march chunk of k_prob2 (0: default)
+  int prob_rows = num("DR_PROB_ROWS", 0);                // A-B: logits per lane of k_prob2 (2 or 4: measured slower; default 1)
   int hist_blocks = std::max(1, num("DR_HIST_BLOCKS", 128));  // workgroups of a histogram level (each flushes its bins with atomics on a few hot addresses)
   bool costvol_v2 = on("DR_COSTVOL_V2");                 // k_costvol2 (the fallback for depth chunks that are not multiples of 4) everywhere
   bool regress_generic = on("DR_REGRESS_GENERIC");       // k_regress (the fallback for other plane counts) everywhere
@@ -571,7 +572,10 @@ class MvsEngine {
         if (v4) snprintf(kn, sizeof kn, "k_costvol4<%d,%d>", Cc, dch);
         else snprintf(kn, sizeof kn, sw_.costvol_v1 ? "k_costvol<%d>" : (sw_.costvol_v2 ? "k_costvol2<%d>" : "k_costvol3<%d>"), Cc);
       }
-      else if (o.kind == Op::PROB) snprintf(kn, sizeof kn, sw_.prob_v1 ? "k_prob" : "k_prob2");
+      else if (o.kind == Op::PROB) {
+        if (sw_.prob_v1) snprintf(kn, sizeof kn, "k_prob");
+        else snprintf(kn, sizeof kn, "k_prob2<%d>", sw_.prob_rows == 2 || sw_.prob_rows == 4 ? sw_.prob_rows : 1);
+      }
       else if (o.kind == Op::TAIL) snprintf(kn, sizeof kn, o.tail.wmf ? "k_tail_m<%d>" : "k_tail<%d>", std::max(3, tail_nout(o.tail.QY, o.tail.QX)));
       else if (o.kind == Op::REGRESS) snprintf(kn, sizeof kn, "k_regress");
       else if (o.kind == Op::PREPROCESS) snprintf(kn, sizeof kn, "k_preprocess");
@@ -1140,11 +1144,20 @@ class MvsEngine {
             break;
           }
 #endif
-          int zc = std::min(o.d0, 8);  // LDS-staged plane tiles (k_prob2)
-          while (zc > 2 && cdiv(o.d1, kProbTY) * cdiv(o.d2, kProbTX) * cdiv(o.d0, zc) < 1024) zc /= 2;  // ~4 workgroups per CU
+          // LDS-staged plane tiles (k_prob2<NR>: NR rows per lane, tile 4 NR x 64)
+          const int NR = sw_.prob_rows == 2 || sw_.prob_rows == 4 ? sw_.prob_rows : 1;  // (measured: 0.028 / 0.044 / 0.084 ms at stage 2 for 1 / 2 / 4 rows per lane -- fewer, fatter workgroups lose more than the shared reads win)
+          const int tyr = kProbTY * NR;
+          int zc = std::min(o.d0, 8);
+          while (zc > 2 && cdiv(o.d1, tyr) * cdiv(o.d2, kProbTX) * cdiv(o.d0, zc) < (NR == 1 ? 1024 : 512)) zc /= 2;  // enough workgroups for every CU's LDS
           if (sw_.prob_zchunk > 0) zc = std::min(o.d0, sw_.prob_zchunk);
-          const int gxp = cdiv(o.d2, kProbTX), gyp = cdiv(o.d1, kProbTY), gzp = cdiv(o.d0, zc), nw = gxp * gyp * gzp;
-          hipLaunchKernelGGL(k_prob2, dim3(8 * cdiv(nw, 8)), dim3(256), 0, stream_, o.p0, o.p1, o.p2, o.d0, o.d1, o.d2, zc, gxp, gyp, gzp, nw);
+          const int gxp = cdiv(o.d2, kProbTX), gyp = cdiv(o.d1, tyr), gzp = cdiv(o.d0, zc), nw = gxp * gyp * gzp;
+          const size_t pl = prob2_lds_bytes(NR);
+          if (NR == 4) {
+            static std::atomic<int> big{0};
+            if (!big.load()) { DR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_prob2<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); big.store(1); }
+            hipLaunchKernelGGL(k_prob2<4>, dim3(8 * cdiv(nw, 8)), dim3(256), pl, stream_, o.p0, o.p1, o.p2, o.d0, o.d1, o.d2, zc, gxp, gyp, gzp, nw);
+          } else if (NR == 2) hipLaunchKernelGGL(k_prob2<2>, dim3(8 * cdiv(nw, 8)), dim3(256), pl, stream_, o.p0, o.p1, o.p2, o.d0, o.d1, o.d2, zc, gxp, gyp, gzp, nw);
+          else hipLaunchKernelGGL(k_prob2<1>, dim3(8 * cdiv(nw, 8)), dim3(256), pl, stream_, o.p0, o.p1, o.p2, o.d0, o.d1, o.d2, zc, gxp, gyp, gzp, nw);
           break;
         }
         case Op::TAIL:

@@ -789,47 +789,58 @@ __global__ __launch_bounds__(256) void k_prob(const float *__restrict__ x, const
 // plane is being consumed, registers -> the other LDS buffer afterwards, one barrier per plane -- and serves the nine
 // taps of all 256 lanes and the three output planes it contributes to.  The products are k_prob's; they are summed in two
 // interleaved chains (even and odd channels) instead of one.
-constexpr int kProbTY = 4, kProbTX = 64, kProbPos = (kProbTY + 2) * (kProbTX + 2);  // 396 staged positions per plane
+constexpr int kProbTY = 4, kProbTX = 64, kProbPos = (kProbTY + 2) * (kProbTX + 2);  // 396 staged positions per plane (NR = 1)
+// NR (round 5): rows per lane.  A lane that owns NR vertically adjacent logits reads the NR + 2 rows around them once (9 LDS reads per logit at NR = 4
+// against 18), the 24 wave-uniform weights of a tap are fetched once for all of them (the scalar loads and their s_waitcnt were what the NR = 1 kernel waited
+// for: 20 waits per 108 packed FMAs), and the tile's halo shrinks from 1.55 to 1.16 of its interior.  Per logit the products and their order are unchanged:
+// bit-identical for every NR.  MEASURED (MI355X, gpurun call c17 of round 5): 0.019 / 0.028 / 0.026 ms per stage at NR = 1, 0.029 / 0.044 / 0.038 at NR = 2,
+// 0.059 / 0.084 / 0.074 at NR = 4 -- half / a quarter of the workgroups, each with 1.7 / 3 x the LDS, lose more latency hiding than the shared reads save: the
+// product runs NR = 1 (DR_PROB_ROWS selects the others for A/B).
+template <int NR>
 __global__ __launch_bounds__(256) void k_prob2(const float *__restrict__ x, const float *__restrict__ wt /*[27][8]*/,
                                                float *__restrict__ out, int D, int h, int w, int zchunk, int gx, int gy, int gz, int nwg) {
-  __shared__ float4 lds[2][2][kProbPos];  // [buffer][channel half][position]
+  constexpr int TY = kProbTY * NR, POS = (TY + 2) * (kProbTX + 2), NS = (POS + 255) / 256;
+  extern __shared__ float4 prob_lds[];  // [buffer 2][channel half 2][POS]
   const int per = (nwg + 7) >> 3, nid = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);  // XCD k walks the k-th band of tile rows
   if (nid >= nwg) return;
   const int bz = nid % gz, bxy = nid / gz, bx = bxy % gx, by = bxy / gx;
-  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
-  const int x0 = bx * kProbTX, y0 = by * kProbTY, xo = x0 + tx, yo = y0 + ty;
+  const int tid = threadIdx.x, tx = tid & 63, ty = (tid >> 6) * NR;
+  const int x0 = bx * kProbTX, y0 = by * TY, xo = x0 + tx, yo = y0 + ty;
   const int z0 = bz * zchunk, z1 = min(D, z0 + zchunk);
-  // this thread's share of a plane: staged positions tid, tid + 256 (both halves each)
-  int spos[2];
-  const float *sptr[2];
-  bool sin[2];
+  // this thread's share of a plane: staged positions tid, tid + 256, ... (both halves each)
+  int spos[NS];
+  const float *sptr[NS];
+  bool sin[NS];
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < NS; ++k) {
     const int p = tid + k * 256, py = p / (kProbTX + 2), px = p - py * (kProbTX + 2);
     const int gyy = y0 - 1 + py, gxx = x0 - 1 + px;
-    spos[k] = p < kProbPos ? p : -1;
-    sin[k] = p < kProbPos && gyy >= 0 && gyy < h && gxx >= 0 && gxx < w;
+    spos[k] = p < POS ? p : -1;
+    sin[k] = p < POS && gyy >= 0 && gyy < h && gxx >= 0 && gxx < w;
     sptr[k] = x + ((size_t)(sin[k] ? gyy : 0) * w + (sin[k] ? gxx : 0)) * 8;
   }
   const size_t plane = (size_t)h * w * 8;
-  float4 r[2][2];
+  float4 r[NS][2];
   auto fetch = [&](int zz) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < NS; ++k) {
       r[k][0] = r[k][1] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (sin[k] && zz >= 0 && zz < D) { r[k][0] = ld4(sptr[k] + (size_t)zz * plane); r[k][1] = ld4(sptr[k] + (size_t)zz * plane + 4); }
     }
   };
   auto stash = [&](int b) {
+    float4 *lo = prob_lds + (size_t)b * 2 * POS, *hi = lo + POS;
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
-      if (spos[k] >= 0) { lds[b][0][spos[k]] = r[k][0]; lds[b][1][spos[k]] = r[k][1]; }
+    for (int k = 0; k < NS; ++k)
+      if (spos[k] >= 0) { lo[spos[k]] = r[k][0]; hi[spos[k]] = r[k][1]; }
   };
   // output planes zz-1, zz, zz+1 while input plane zz is being consumed.  Each accumulator is a PAIR (even / odd channels, added at
   // the end): the 8-channel dot product of a tap is then four packed fmas (v_pk_fma_f32: two fp32 fmas per lane and instruction)
-  // instead of eight scalar ones -- the kernel is bound by vector-ALU issue (216 MACs per voxel).
+  // instead of eight scalar ones.
   typedef float f2 __attribute__((ext_vector_type(2)));
-  f2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
+  f2 a0[NR], a1[NR], a2[NR];
+#pragma unroll
+  for (int q = 0; q < NR; ++q) a0[q] = a1[q] = a2[q] = f2{0.f, 0.f};
   fetch(z0 - 1);
   stash(0);
   int b = 0;
@@ -837,28 +848,36 @@ __global__ __launch_bounds__(256) void k_prob2(const float *__restrict__ x, cons
     __syncthreads();  // plane zz is in buffer b; everybody is done with buffer b ^ 1
     if (zz + 1 <= z1) fetch(zz + 1);
     if (zz >= 0 && zz < D) {
+      const float4 *lo = prob_lds + (size_t)b * 2 * POS, *hi = lo + POS;
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
-        if (yo + kh - 1 < 0 || yo + kh - 1 >= h) continue;  // as k_prob: rows outside the image are skipped (their staged zeros are never read)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
-          const int p = (ty + kh) * (kProbTX + 2) + tx + kw;
-          const float4 lo = lds[b][0][p], hi = lds[b][1][p];
-          const f2 x01 = {lo.x, lo.y}, x23 = {lo.z, lo.w}, x45 = {hi.x, hi.y}, x67 = {hi.z, hi.w};
           const f2 *w2 = reinterpret_cast<const f2 *>(wt + ((2 * 3 + kh) * 3 + kw) * 8), *w1 = reinterpret_cast<const f2 *>(wt + ((1 * 3 + kh) * 3 + kw) * 8),
                    *w0 = reinterpret_cast<const f2 *>(wt + ((0 * 3 + kh) * 3 + kw) * 8);
+#pragma unroll
+          for (int q = 0; q < NR; ++q) {
+            if (yo + q + kh - 1 < 0 || yo + q + kh - 1 >= h) continue;  // as k_prob: rows outside the image are skipped (their staged zeros are never read)
+            const int p = (ty + q + kh) * (kProbTX + 2) + tx + kw;
+            const float4 l4 = lo[p], h4 = hi[p];
+            const f2 x01 = {l4.x, l4.y}, x23 = {l4.z, l4.w}, x45 = {h4.x, h4.y}, x67 = {h4.z, h4.w};
 #define DR_DOT8(A, WK) A = __builtin_elementwise_fma(x01, WK[0], A); A = __builtin_elementwise_fma(x23, WK[1], A); A = __builtin_elementwise_fma(x45, WK[2], A); A = __builtin_elementwise_fma(x67, WK[3], A)
-          DR_DOT8(a0, w2); DR_DOT8(a1, w1); DR_DOT8(a2, w0);
+            DR_DOT8(a0[q], w2); DR_DOT8(a1[q], w1); DR_DOT8(a2[q], w0);
 #undef DR_DOT8
+          }
         }
       }
     }
     const int zo = zz - 1;
-    if (zo >= z0 && zo < z1 && xo < w && yo < h) out[((size_t)zo * h + yo) * w + xo] = a0.x + a0.y;
-    a0 = a1; a1 = a2; a2 = f2{0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      if (zo >= z0 && zo < z1 && xo < w && yo + q < h) out[((size_t)zo * h + yo + q) * w + xo] = a0[q].x + a0[q].y;
+      a0[q] = a1[q]; a1[q] = a2[q]; a2[q] = f2{0.f, 0.f};
+    }
     if (zz + 1 <= z1) stash(b ^ 1);
   }
 }
+inline size_t prob2_lds_bytes(int NR) { return (size_t)2 * 2 * (kProbTY * NR + 2) * (kProbTX + 2) * sizeof(float4); }
 
 // ------------------------------------------------------------------ folded out.stage3: border term
 // out.stage3(up(inter2) + skip3(c3)) is linear, so it is evaluated as conv3x3(c3; Wout . Wskip) + conv3x3(up(inter2); Wout) + B with

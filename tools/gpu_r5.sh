@@ -42,6 +42,8 @@ PY
       done ;;
     ab_tail)  # DR_TAIL_FUSED=1 per-op profile with every A/B library under build/ab
       for so in build/ab/libdr_*.so; do nme=$(basename $so .so); echo "--- $nme: $(DR_TAIL_FUSED=1 DR_MI355X_LIB=$PWD/$so timeout 300 python tools/profile_ops.py "tail" 2>&1 | tail -1)"; done ;;
+    ops_prob)  # k_prob2<NR>: rows per lane 1 / 2 / 4
+      for f in 1 2 4; do echo "DR_PROB_ROWS=$f: $(DR_PROB_ROWS=$f timeout 300 python tools/profile_ops.py "prob" 2>&1 | tail -1)"; done ;;
     ops_tail)  # per-op profile with the fused tail forms beside the default
       for f in 0 1 2; do DR_TAIL_FUSED=$f timeout 300 python tools/profile_ops.py "tail|conv11|prob" > $OUT/${TAG}_ops_tail$f.txt 2>&1; echo "DR_TAIL_FUSED=$f: $(tail -1 $OUT/${TAG}_ops_tail$f.txt)"; done ;;
     ops) timeout 600 python tools/profile_ops.py > $OUT/${TAG}_ops.txt 2>&1; tail -4 $OUT/${TAG}_ops.txt ;;
