@@ -426,8 +426,11 @@ __device__ __forceinline__ float cv_bcast_f(float x, int lpb, int j) { return __
 // Round 4 tried to take a pixel's right-hand taps from the NEIGHBOURING pixel's lanes (DPP) where they are the same addresses, sending
 // the now redundant loads to one shared line: 0.116 / 0.158 / 0.106 ms per stage against 0.105 / 0.149 / 0.100 -- slower, removed
 // (profiles/r04_experiments.txt, 6).
+#ifndef DR_CV3_MIN_WAVES  // A/B hook: minimum waves per SIMD hipcc must leave room for (register cap)
+#define DR_CV3_MIN_WAVES 1
+#endif
 template <int C>
-__global__ __launch_bounds__(256) void k_costvol3(const CostVolArgs a) {
+__global__ __launch_bounds__(256, DR_CV3_MIN_WAVES) void k_costvol3(const CostVolArgs a) {
   constexpr int LPV = C / 4;            // lanes per pixel, 4 channels each
   constexpr int PXB = 256 / LPV;        // pixels per block
   constexpr int LPB = LPV >= 4 ? 4 : 2; // iterations per batch = lanes of a pixel (within one quad) that share their set-up

@@ -55,7 +55,7 @@ public:
       exit(EXIT_FAILURE);
     }
   }
-  ~DrMvsnet() { drm_destroy(impl); }
+  ~DrMvsnet() { delete spare_; drm_destroy(impl); }
   DrMvsnet(const DrMvsnet &) = delete;
   DrMvsnet &operator=(const DrMvsnet &) = delete;
 
@@ -69,10 +69,20 @@ public:
     height_ = height; width_ = width;
     check(drm_call_async(impl, height, width, view_num, ref_index, (const uint8_t *const *) bgrs, intrinsic_matrix,
                          (const float *const *) cam_to_worlds, depth_min, depth_max, discard_percentage));
+    // The result object GetResult() will hand out is allocated and its pages TOUCHED here, while the device works on the window: TandemBackend
+    // never deletes its DrMvsnetOutputs, so every result lands in 4.9 MB of fresh memory, and the first-touch page faults of that memory
+    // (1200 of them at 640 x 480) were paid inside GetResult, on the caller's critical path -- more time than the copy itself.
+    if (spare_ && (spare_->height != height || spare_->width != width)) { delete spare_; spare_ = nullptr; }
+    if (!spare_) {
+      spare_ = new DrMvsnetOutput(height, width);
+      const size_t bytes = sizeof(float) * (size_t) width * height;
+      memset(spare_->depth, 0, bytes); memset(spare_->confidence, 0, bytes); memset(spare_->depth_dense, 0, bytes); memset(spare_->confidence_dense, 0, bytes);
+    }
   }
   // Blocking.  Ownership of the result passes to the caller (delete it), as in the reference.
   DrMvsnetOutput *GetResult() {
-    DrMvsnetOutput *out = new DrMvsnetOutput(height_, width_);
+    DrMvsnetOutput *out = spare_ ? spare_ : new DrMvsnetOutput(height_, width_);
+    spare_ = nullptr;
     if (drm_get_result(impl, out->depth, out->confidence, out->depth_dense, out->confidence_dense) != DR_OK) {
       delete out;
       check(DR_ERR_PROTOCOL);
@@ -103,6 +113,7 @@ private:
   }
   drm_t *impl;
   int height_, width_;
+  DrMvsnetOutput *spare_ = nullptr;  // the next GetResult()'s object, pages already touched (CallAsync)
 };
 
 // test_dr_mvsnet (dr_mvsnet.cpp:376-556): feeds a stored window through CallAsync/Ready/GetResult

@@ -42,6 +42,18 @@ PY
       done ;;
     ab_tail)  # DR_TAIL_FUSED=1 per-op profile with every A/B library under build/ab
       for so in build/ab/libdr_*.so; do nme=$(basename $so .so); echo "--- $nme: $(DR_TAIL_FUSED=1 DR_MI355X_LIB=$PWD/$so timeout 300 python tools/profile_ops.py "tail" 2>&1 | tail -1)"; done ;;
+    cv_sweep)  # cost-volume depth chunks and register caps (A/B libraries under build/ab)
+      for cfg in "" "DR_CV_DCHUNK1=8" "DR_CV_DCHUNK1=12" "DR_CV_DCHUNK1=16" "DR_CV_DCHUNK2=4" "DR_CV_DCHUNK2=16" "DR_CV_DCHUNK3=4"; do echo "[$cfg] $(env $cfg timeout 300 python tools/profile_ops.py "costvol" 2>&1 | tail -1)"; done
+      for so in build/ab/libdr_*.so; do nme=$(basename $so .so); echo "--- $nme: $(DR_MI355X_LIB=$PWD/$so timeout 300 python tools/profile_ops.py "costvol" 2>&1 | tail -1)"; done ;;
+    bench_host)  # the legs that cross the operator boundary: boundary, tandem_loop (no TSDF loop, no CPU baselines)
+      timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-tsdf > $OUT/${TAG}_bench_host.json 2> $OUT/${TAG}_bench_host.err
+      python - <<PY
+import json
+d=json.load(open("$OUT/${TAG}_bench_host.json"))
+print("value %.1f  single %.3f  boundary %.3f  pinned %.3f" % (d["value"], d["single_window_ms"], d["boundary_single_engine_ms"], d["boundary_pinned_single_engine_ms"]))
+print({k:(v.get("keyframes_per_s"),v.get("mean_ms")) for k,v in d["tandem_loop"].items() if isinstance(v,dict)})
+PY
+      ;;
     ops_prob)  # k_prob2<NR>: rows per lane 1 / 2 / 4
       for f in 1 2 4; do echo "DR_PROB_ROWS=$f: $(DR_PROB_ROWS=$f timeout 300 python tools/profile_ops.py "prob" 2>&1 | tail -1)"; done ;;
     ops_tail)  # per-op profile with the fused tail forms beside the default
