@@ -22,6 +22,7 @@
 #include "conv_mfma.h"
 #include "mvs_kernels.h"
 #include "tail_kernels.h"
+#include "fn_front.h"
 
 namespace dr {
 
@@ -112,13 +113,14 @@ struct DevTensor {
 };
 
 struct Op {
-  enum Kind { PREPROCESS, CONV, SKIPUP, PROB, COSTVOL, REGRESS, EDGE, HIST, SCAN, APPLY, BORDERFIX, TAIL } kind;
+  enum Kind { PREPROCESS, CONV, SKIPUP, PROB, COSTVOL, REGRESS, EDGE, HIST, SCAN, APPLY, BORDERFIX, TAIL, FRONT } kind;
   const float *p0 = nullptr, *p1 = nullptr, *p3 = nullptr, *p4 = nullptr;
   float *p2 = nullptr;
   int d0 = 0, d1 = 0, d2 = 0;
   std::string name;
   ConvLaunch conv;
   TailArgs tail{};                        // TAIL only: conv11 + prob in one launch (tail_kernels.h)
+  FrontArgs front{};                      // FRONT only: preprocess + conv0.0 + conv0.1 in one launch (fn_front.h)
   std::function<ConvLaunch(int)> replan;  // CONV only: build candidate `rank` of the planner's ranking
   std::string sig;                        // CONV only: layer signature in conv_tuned.h's column order
   int ncand = 0;
@@ -202,6 +204,7 @@ struct MvsSwitches {
   // MFMAs and vector work serialise on a SIMD -- and nothing overlaps the kernel's memory side: 0.128 / 0.113 ms (matrix pipe) and 0.118 / 0.109 (vector pipe)
   // at stages 2 / 3 against the two-kernel path's 0.100 / 0.096 (profiles/r05_tail.txt)
   int tail_fused = num("DR_TAIL_FUSED", 0);              // 0: the two-kernel path; 1: k_tail_m (transposed convolution on the matrix pipe); 2: k_tail (on the vector pipe)
+  bool fn_front = num("DR_FN_FRONT", 1) != 0;          // 1: FeatureNet's first block (u8 -> float, conv0.0, conv0.1) in one launch (k_fn_front); 0: the three launches
   int tail_qy = num("DR_TAIL_QY", 0), tail_zchunk = num("DR_TAIL_ZCHUNK", 0);  // tuning: k_tail's tile (quad rows: 4, 8, 16, 32) and depth planes per workgroup (0: chosen by size)
   bool vol_split = !on("DR_VOL_NO_SPLIT");               // stage 1's 32-channel cost volume as two 16-channel halves (DevTensor::split); off: one (D,h,w,32) tensor (A/B)
 #ifdef DR_PARITY_HOOKS
@@ -579,6 +582,7 @@ class MvsEngine {
       else if (o.kind == Op::TAIL) snprintf(kn, sizeof kn, o.tail.wmf ? "k_tail_m<%d>" : "k_tail<%d>", std::max(3, tail_nout(o.tail.QY, o.tail.QX)));
       else if (o.kind == Op::REGRESS) snprintf(kn, sizeof kn, "k_regress");
       else if (o.kind == Op::PREPROCESS) snprintf(kn, sizeof kn, "k_preprocess");
+      else if (o.kind == Op::FRONT) snprintf(kn, sizeof kn, "k_fn_front");
       else if (o.kind == Op::SKIPUP) snprintf(kn, sizeof kn, "k_skip_up<%d>", o.stage);
       else if (o.kind == Op::BORDERFIX) snprintf(kn, sizeof kn, "k_out3_border");
       else snprintf(kn, sizeof kn, "k_filter");
@@ -758,6 +762,38 @@ class MvsEngine {
       ++idx;
     }
   }
+  // FeatureNet's first block: u8 BGR -> RGB0 / 255, conv0.0 (3 -> 8), conv0.1 (8 -> 8), both 3x3 + BN + ReLU (module.py:461-470).  One launch
+  // (k_fn_front, fn_front.h) when the weights have that shape; DR_FN_FRONT=0, the bf16x3 mode and any other shape keep the three launches.
+  DevTensor &front_block(const std::string &fn, int V, int H, int W) {
+    const HostTensor &wa = blob_.at(fn + "conv0.0.conv.weight"), &wb = blob_.at(fn + "conv0.1.conv.weight");
+    const bool shape_ok = wa.dims.size() == 4 && wa.dims[0] == 8 && wa.dims[1] == 3 && wa.dims[2] == 3 && wa.dims[3] == 3 &&
+                          wb.dims.size() == 4 && wb.dims[0] == 8 && wb.dims[1] == 8 && wb.dims[2] == 3 && wb.dims[3] == 3;
+    if (!sw_.fn_front || conv_bf3_policy() || !shape_ok) {
+      DevTensor &img = alloc("image", V, H, W, 4);
+      { Op o; o.kind = Op::PREPROCESS; o.name = "preprocess"; o.bytes = (double)V * H * W * (3 + 16); ops_.push_back(o); }
+      DevTensor &c3a = cbr2("fn.conv0.0", fn + "conv0.0", img, 3, 1, CONV_XPAIR);
+      return cbr2("fn.conv0.1", fn + "conv0.1", c3a, 3, 1, CONV_XPAIR);
+    }
+    DevTensor &c3 = alloc("fn.conv0.1", V, H, W, 8);
+    Op o; o.kind = Op::FRONT; o.name = "fn.front";
+    FrontArgs &a = o.front;
+    a.bgr = d_bgr_; a.lut = lut_; a.out = c3.d;
+    a.w1 = reinterpret_cast<const float4 *>(plan_arena_->upload(front_pack(wa.data.data(), 3, 4)));
+    a.w2 = reinterpret_cast<const float4 *>(plan_arena_->upload(front_pack(wb.data.data(), 8, 8)));
+    auto affine = [&](const std::string &bn) {  // 16 scales, 16 biases: XPAIR row r = 8 * (x of the pair) + channel
+      std::vector<float> sc, bi, sb(32);
+      fold_bn(bn, 8, sc, bi);
+      for (int r = 0; r < 16; ++r) { sb[r] = sc[r & 7]; sb[16 + r] = bi[r & 7]; }
+      return plan_arena_->upload(sb);
+    };
+    a.sb1 = affine(fn + "conv0.0.bn"); a.sb2 = affine(fn + "conv0.1.bn");
+    a.V = V; a.H = H; a.W = W;
+    a.tilesY = cdiv(H, kFrontTY); a.tilesX = cdiv(W, kFrontTXP); a.ntiles = V * a.tilesY * a.tilesX;
+    o.flops = 2.0 * V * H * W * 9.0 * (4 * 8 + 8 * 8);  // (as the planner counts the two layers: RGB0 has four channels)
+    o.bytes = (double)V * H * W * (3 + 32);
+    ops_.push_back(o);
+    return c3;
+  }
   DevTensor &cbr2(const std::string &name, const std::string &p, const DevTensor &in, int k, int s, ConvMode m) {
     return add_conv(name, p + ".conv", p + ".bn", false, true, in, name, 1, k, k, 1, s, s, false, m, nullptr, 0);
   }
@@ -797,16 +833,13 @@ class MvsEngine {
     }
     has_output_ = false;
     DR_HIP(hipHostMalloc((void **)&h_in_, (size_t)V * H * W * 3, hipHostMallocDefault));
-    d_bgr_ = dalloc<uint8_t>((size_t)V * H * W * 3); misc_.push_back(d_bgr_);
+    d_bgr_ = dalloc<uint8_t>((size_t)V * H * W * 3 + 16); misc_.push_back(d_bgr_);  // (+16: k_fn_front fetches a pixel as the two aligned words around it)
     d_state_ = dalloc<unsigned>(8); misc_.push_back(d_state_);
     d_hist_ = dalloc<unsigned>(2048); misc_.push_back(d_hist_);
     DR_HIP(hipMemset(d_hist_, 0, 2048 * 4));
 
     const std::string fn = "feature_net.";
-    DevTensor &img = alloc("image", V, H, W, 4);
-    { Op o; o.kind = Op::PREPROCESS; o.name = "preprocess"; o.bytes = (double)V * H * W * (3 + 16); ops_.push_back(o); }
-    DevTensor &c3a = cbr2("fn.conv0.0", fn + "conv0.0", img, 3, 1, CONV_XPAIR);
-    DevTensor &c3 = cbr2("fn.conv0.1", fn + "conv0.1", c3a, 3, 1, CONV_XPAIR);
+    DevTensor &c3 = front_block(fn, V, H, W);
     DevTensor &c2a = cbr2("fn.conv1.0", fn + "conv1.0", c3, 5, 2, CONV_NORMAL);
     DevTensor &c2b = cbr2("fn.conv1.1", fn + "conv1.1", c2a, 3, 1, CONV_NORMAL);
     DevTensor &c2 = cbr2("fn.conv1.2", fn + "conv1.2", c2b, 3, 1, CONV_NORMAL);
@@ -1162,6 +1195,9 @@ class MvsEngine {
         }
         case Op::TAIL:
           launch_tail(o.tail, stream_);
+          break;
+        case Op::FRONT:
+          launch_fn_front(o.front, stream_);
           break;
         case Op::COSTVOL: {
           const CostVolArgs &a = cv_[o.stage - 1];

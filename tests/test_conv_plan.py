@@ -109,3 +109,18 @@ def test_every_tuned_row_names_a_plan_the_planner_can_build(tmp_path):
     env = {k: v for k, v in os.environ.items() if not k.startswith("DR_")}
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0 and " 0 stale" in out.stdout, out.stdout[-3000:] + out.stderr[-1000:]
+
+
+def test_fused_front_kernel_emulation_matches_the_two_layers(tmp_path):
+    """k_fn_front (csrc/fn_front.h: u8 -> float, conv0.0 and conv0.1 of FeatureNet in one launch, module.py:461-470) through a host emulation
+    that uses the kernel's own geometry helpers and weight packing (tests/cpp/front_emul.hip): XPAIR packing of both layers, every LDS
+    index, tile origins and the masks at ragged image edges, against a direct evaluation of the two layers in double."""
+    if not (os.path.exists(HIPCC) or shutil.which("hipcc")):
+        pytest.skip("needs hipcc to compile the host emulation")
+    exe = tmp_path / "front_emul"
+    subprocess.check_call([HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-Wno-unused-function",
+                           "-Wno-pass-failed", "-Wno-unused-result", os.path.join(ROOT, "tests", "cpp", "front_emul.hip"), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("front ")]
+    assert len(lines) == 4 and all(l.endswith(" ok") for l in lines), out.stdout

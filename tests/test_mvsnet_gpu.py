@@ -312,6 +312,43 @@ def test_fused_skip_equals_the_two_kernel_path(trained_blob, monkeypatch, parity
         assert np.array_equal(a.depth, b.depth) and np.array_equal(a.confidence, b.confidence)
 
 
+def test_fused_front_equals_the_three_kernel_path(trained_blob, monkeypatch):
+    """FeatureNet's first block (module.py:461-470; u8 -> float as dr_mvsnet.cpp:184-217) in one launch (k_fn_front, csrc/fn_front.h: the
+    float image and conv0.0's output never leave the CU) against k_preprocess + the two convolution launches in their direct form: the same
+    products in the same order, so `fn.conv0.1` agrees bit for bit wherever the direct plan keeps one accumulator per position tile (every
+    instance except the narrow K loop's CT * PT = 1, which adds two partial sums: fp32 reassociation there).  Widths that are not a multiple
+    of the kernel's 64-pixel tile included."""
+    import re
+    from synth import scene
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    shapes = ((64, 96, 3), (96, 160, 4), (224, 352, 3))
+    runs = []
+    for env in ({}, {"DR_FN_FRONT": "0", "DR_CONV_WINO": "0", "DR_CONV_NO_TUNED": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = DrMvsnet(trained_blob)
+        res = []
+        for (h, w, v) in shapes:
+            win = scene.make_window(h, w, v, seed=11)
+            m.upload(h, w, v, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), 0.5, 5.0, 2.5)
+            m.forward(1)
+            prof = {r["op"]: r["kernel"] for r in m.profile()}
+            res.append((m.tensor("fn.conv0.1").copy(), prof))
+        runs.append(res)
+        m.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    for (fa, pa), (fb, pb) in zip(*runs):
+        assert pa.get("fn.front") == "k_fn_front" and "fn.conv0.0" not in pa, pa
+        assert "fn.front" not in pb and "preprocess" in pb and pb["fn.conv0.1"].startswith("k_conv"), pb
+        assert fa.shape == fb.shape and np.isfinite(fa).all() and np.abs(fb).max() > 0.1
+        single_chain = all(int(re.findall(r"\d+", pb[n])[2]) >= 2 for n in ("fn.conv0.0", "fn.conv0.1"))
+        if single_chain:
+            assert np.array_equal(fa, fb), (pb["fn.conv0.0"], pb["fn.conv0.1"], np.abs(fa - fb).max())
+        else:
+            assert np.abs(fa - fb).max() <= 2e-6 * np.abs(fb).max(), (pb["fn.conv0.0"], pb["fn.conv0.1"], np.abs(fa - fb).max())
+
+
 def test_fused_skip_on_the_marching_kernel(trained_blob, monkeypatch, parity_hooks):
     """out.stage3 with the skip computed by k_conv_m's producer waves (conv_march.h, march_producer_fz) against the same
     layer on k_conv's fused staging: same fmaf chain in the skip, same channel-pass and tap order in the 3x3 layer, so

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5's GPU script: ONE parameterised entry point for every gpurun call (the r4 per-call scripts were folded into this form).
 #   tools/gpu_r5.sh <tag> <step> [<step> ...]       results under gpurun_out/<tag>_*
-# steps: fused_sweep fused_prio corun batch_proxy ops tests tests_fast smoke bench bench_quick shipped pmc prof_seq prof_driver
+# steps: fused_sweep fused_prio corun batch_proxy ops ab_front tests tests_fast smoke bench bench_quick shipped pmc prof_seq prof_driver
 #   the round's closing evidence, in the order bench.py needs it:  tools/gpu_r5.sh final pmc tests smoke bench shipped prof_seq prof_driver
 set -u
 cd "$(dirname "$0")/.."
@@ -58,6 +58,12 @@ PY
       for f in 1 2 4; do echo "DR_PROB_ROWS=$f: $(DR_PROB_ROWS=$f timeout 300 python tools/profile_ops.py "prob" 2>&1 | tail -1)"; done ;;
     ops_tail)  # per-op profile with the fused tail forms beside the default
       for f in 0 1 2; do DR_TAIL_FUSED=$f timeout 300 python tools/profile_ops.py "tail|conv11|prob" > $OUT/${TAG}_ops_tail$f.txt 2>&1; echo "DR_TAIL_FUSED=$f: $(tail -1 $OUT/${TAG}_ops_tail$f.txt)"; done ;;
+    ab_front)  # k_fn_front against the three launches it replaces: per-op times, then the quick bench line, both ways
+      for f in 1 0; do echo "DR_FN_FRONT=$f: $(DR_FN_FRONT=$f timeout 300 python tools/profile_ops.py "preprocess|fn.front|fn.conv0|fn.conv1.0" 2>&1 | tail -1)"; done | tee $OUT/${TAG}_front_ops.txt
+      for f in 1 0 1 0; do
+        DR_FN_FRONT=$f timeout 600 python bench.py --gpus 1 --steps 60 --warmup 5 --no-cpu --no-loop --no-boundary --no-tsdf > $OUT/${TAG}_bench_front$f.json 2> $OUT/${TAG}_bench_front$f.err
+        python -c "import json; d=json.load(open('$OUT/${TAG}_bench_front$f.json')); print('DR_FN_FRONT=$f: value %.1f /s  ms_per_step %.3f  single_window %.3f ms' % (d['value'], d['ms_per_step'], d['single_window_ms']))"
+      done | tee -a $OUT/${TAG}_front_ops.txt ;;
     ops) timeout 600 python tools/profile_ops.py > $OUT/${TAG}_ops.txt 2>&1; tail -4 $OUT/${TAG}_ops.txt ;;
     pmc)  # counters in their own passes (--kernel-trace only), strictly sequential kernels (one engine, side stream off) -> profiles/r05_pmc_traffic.json, stamped with this tree's source hash
       export DR_MVS_NO_SIDE_STREAM=1
