@@ -16,7 +16,7 @@ LDFLAGS := -shared -fPIC -Wl,-Bsymbolic
 
 all: $(LIB) $(HLIB) oracle/libtsdf_oracle.so oracle/libtsdf_oracle_omp.so oracle/libtracker_oracle.so oracle/libtracker_oracle_left.so
 
-MVS_DEPS := $(CSRC)/dr_mvsnet.hip $(CSRC)/conv_mfma.h $(CSRC)/conv_bf3.h $(CSRC)/conv_march.h $(CSRC)/conv_wino.h $(CSRC)/march_plan.h $(CSRC)/conv_tuned.h $(CSRC)/mvs_kernels.h $(CSRC)/tail_kernels.h $(CSRC)/fn_front.h $(CSRC)/dr_common.h include/dr_mi355x.h
+MVS_DEPS := $(CSRC)/dr_mvsnet.hip $(CSRC)/conv_mfma.h $(CSRC)/conv_bf3.h $(CSRC)/conv_march.h $(CSRC)/conv_wino.h $(CSRC)/march_plan.h $(CSRC)/conv_tuned.h $(CSRC)/mvs_kernels.h $(CSRC)/tail_kernels.h $(CSRC)/fn_front.h $(CSRC)/fn_head3.h $(CSRC)/dr_common.h include/dr_mi355x.h
 FUS_DEPS := $(CSRC)/dr_fusion.hip $(CSRC)/mesh_kernels.h $(CSRC)/mc_tables.h $(CSRC)/dr_common.h include/dr_mi355x.h
 # the depth pipeline is held to a float tolerance, not to bit-exactness: let hipcc contract a*b+c into FMAs there (the
 # vector-pipe kernels -- cost volume, prob -- are VALU-bound, and the reference's cuDNN/ATen kernels use FMAs too)

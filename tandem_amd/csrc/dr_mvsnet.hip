@@ -23,6 +23,7 @@
 #include "mvs_kernels.h"
 #include "tail_kernels.h"
 #include "fn_front.h"
+#include "fn_head3.h"
 
 namespace dr {
 
@@ -113,7 +114,7 @@ struct DevTensor {
 };
 
 struct Op {
-  enum Kind { PREPROCESS, CONV, SKIPUP, PROB, COSTVOL, REGRESS, EDGE, HIST, SCAN, APPLY, BORDERFIX, TAIL, FRONT } kind;
+  enum Kind { PREPROCESS, CONV, SKIPUP, PROB, COSTVOL, REGRESS, EDGE, HIST, SCAN, APPLY, BORDERFIX, TAIL, FRONT, HEAD3 } kind;
   const float *p0 = nullptr, *p1 = nullptr, *p3 = nullptr, *p4 = nullptr;
   float *p2 = nullptr;
   int d0 = 0, d1 = 0, d2 = 0;
@@ -121,6 +122,7 @@ struct Op {
   ConvLaunch conv;
   TailArgs tail{};                        // TAIL only: conv11 + prob in one launch (tail_kernels.h)
   FrontArgs front{};                      // FRONT only: preprocess + conv0.0 + conv0.1 in one launch (fn_front.h)
+  Head3Args head3{};                      // HEAD3 only: FeatureNet's folded stage-3 head in one launch (fn_head3.h)
   std::function<ConvLaunch(int)> replan;  // CONV only: build candidate `rank` of the planner's ranking
   std::string sig;                        // CONV only: layer signature in conv_tuned.h's column order
   int ncand = 0;
@@ -205,6 +207,7 @@ struct MvsSwitches {
   // at stages 2 / 3 against the two-kernel path's 0.100 / 0.096 (profiles/r05_tail.txt)
   int tail_fused = num("DR_TAIL_FUSED", 0);              // 0: the two-kernel path; 1: k_tail_m (transposed convolution on the matrix pipe); 2: k_tail (on the vector pipe)
   bool fn_front = num("DR_FN_FRONT", 1) != 0;          // 1: FeatureNet's first block (u8 -> float, conv0.0, conv0.1) in one launch (k_fn_front); 0: the three launches
+  bool fn_head3 = num("DR_FN_HEAD3", 1) != 0;          // 1: the folded stage-3 head of FeatureNet (fn.out3a..d) in one launch (k_fn_head3); 0: the four launches
   int tail_qy = num("DR_TAIL_QY", 0), tail_zchunk = num("DR_TAIL_ZCHUNK", 0);  // tuning: k_tail's tile (quad rows: 4, 8, 16, 32) and depth planes per workgroup (0: chosen by size)
   bool vol_split = !on("DR_VOL_NO_SPLIT");               // stage 1's 32-channel cost volume as two 16-channel halves (DevTensor::split); off: one (D,h,w,32) tensor (A/B)
 #ifdef DR_PARITY_HOOKS
@@ -583,6 +586,7 @@ class MvsEngine {
       else if (o.kind == Op::REGRESS) snprintf(kn, sizeof kn, "k_regress");
       else if (o.kind == Op::PREPROCESS) snprintf(kn, sizeof kn, "k_preprocess");
       else if (o.kind == Op::FRONT) snprintf(kn, sizeof kn, "k_fn_front");
+      else if (o.kind == Op::HEAD3) snprintf(kn, sizeof kn, "k_fn_head3");
       else if (o.kind == Op::SKIPUP) snprintf(kn, sizeof kn, "k_skip_up<%d>", o.stage);
       else if (o.kind == Op::BORDERFIX) snprintf(kn, sizeof kn, "k_out3_border");
       else snprintf(kn, sizeof kn, "k_filter");
@@ -880,6 +884,22 @@ class MvsEngine {
         }
       for (int co = 0; co < 8; ++co) { double b = 0; for (int t = 0; t < 9; ++t) b += (double)T[t * 8 + co]; bint[co] = (float)b; }
       DevTensor &f3 = alloc("feat3", c3.D, c3.H, c3.W, 8, fpad);
+      if (sw_.fn_head3 && !conv_bf3_policy()) {  // one launch: the three terms meet in one accumulator (fn_head3.h)
+        Op o; o.kind = Op::HEAD3; o.name = "fn.head3";
+        Head3Args &a = o.head3;
+        a.c0 = c3.d; a.i2 = i2.d;
+        a.wa = reinterpret_cast<const float4 *>(plan_arena_->upload(h3_pack_a(wa.data())));
+        a.wb = reinterpret_cast<const float4 *>(plan_arena_->upload(h3_pack_b(wo3.data.data())));
+        std::vector<float> b16(16);
+        for (int r = 0; r < 16; ++r) b16[r] = bint[r & 7];
+        a.bias16 = plan_arena_->upload(b16); a.T = plan_arena_->upload(T);
+        a.out = f3.interior(); a.V = c3.D; a.H = c3.H; a.W = c3.W;
+        a.out_row = (f3.W + 2 * f3.pad) * 8; a.out_plane = (f3.H + 2 * f3.pad) * a.out_row;
+        a.tilesY = cdiv(c3.H, kH3TY); a.tilesX = cdiv(c3.W, kH3TXP); a.ntiles = c3.D * a.tilesY * a.tilesX;
+        o.flops = 2.0 * c3.D * c3.H * c3.W * (9.0 * 8 * 8 + 4.0 * 32 * 8);  // (as the four launches count them: 9 taps of the composed layer, 2 x 2 half-resolution pixels per output pixel)
+        o.bytes = 4.0 * (c3.n() + i2.n() + (double)c3.D * c3.H * c3.W * 8);
+        ops_.push_back(o);
+      } else {
       ConvLayer LA; LA.Cin = 8; LA.Cout = 8; LA.kd = 1; LA.kh = 3; LA.kw = 3; LA.weight = wa.data(); LA.bias = bint; LA.out_pad = fpad;
       emit_conv("fn.out3a", LA, CONV_XPAIR, c3, f3, nullptr, 0, 0);
       for (int py = 0; py < 2; ++py) {
@@ -889,6 +909,7 @@ class MvsEngine {
       Op o; o.kind = Op::BORDERFIX; o.name = "fn.out3d"; o.p2 = f3.interior(); o.p1 = plan_arena_->upload(T); o.d0 = c3.D; o.d1 = c3.H; o.d2 = c3.W;
       o.stage = fpad; o.bytes = 64.0 * c3.D * (c3.H + c3.W);
       ops_.push_back(o);
+      }
     } else
     if (!sw_.no_skip_fusion && !sw_.skip_on_conv && kParityHooks && w3.dims[0] == 32 && w3.dims[1] == 8 && c3.C == 8 && i2.C == 32 &&
         i2.H * 2 == c3.H && i2.W * 2 == c3.W) {  // (parity build only: the fused-skip kernel instances are not in the product library)
@@ -1198,6 +1219,9 @@ class MvsEngine {
           break;
         case Op::FRONT:
           launch_fn_front(o.front, stream_);
+          break;
+        case Op::HEAD3:
+          launch_fn_head3(o.head3, stream_);
           break;
         case Op::COSTVOL: {
           const CostVolArgs &a = cv_[o.stage - 1];

@@ -124,3 +124,19 @@ def test_fused_front_kernel_emulation_matches_the_two_layers(tmp_path):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("front ")]
     assert len(lines) == 4 and all(l.endswith(" ok") for l in lines), out.stdout
+
+
+def test_fused_head3_kernel_emulation_matches_the_definition(tmp_path):
+    """k_fn_head3 (csrc/fn_head3.h: FeatureNet's folded stage-3 head in one launch, module.py:480-485,524-529) through a host emulation that
+    uses the kernel's own geometry helpers and weight packing (tests/cpp/head3_emul.hip): the XPAIR packing of the composed layer, the
+    summed kernel rows / columns of the upsampled axes per parity, every LDS index, tile origins, ragged edges, the padded output, against
+    conv3x3(conv0) + conv3x3(nearest_up2(inter2)) + the bias shares of the taps inside the image, in double."""
+    if not (os.path.exists(HIPCC) or shutil.which("hipcc")):
+        pytest.skip("needs hipcc to compile the host emulation")
+    exe = tmp_path / "head3_emul"
+    subprocess.check_call([HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-Wno-unused-function",
+                           "-Wno-pass-failed", "-Wno-unused-result", os.path.join(ROOT, "tests", "cpp", "head3_emul.hip"), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("head3 ")]
+    assert len(lines) == 4 and all(l.endswith(" ok") for l in lines), out.stdout

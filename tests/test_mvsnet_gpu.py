@@ -349,6 +349,38 @@ def test_fused_front_equals_the_three_kernel_path(trained_blob, monkeypatch):
             assert np.abs(fa - fb).max() <= 2e-6 * np.abs(fb).max(), (pb["fn.conv0.0"], pb["fn.conv0.1"], np.abs(fa - fb).max())
 
 
+def test_fused_head3_equals_the_four_launch_form(trained_blob, monkeypatch):
+    """FeatureNet's folded stage-3 head (module.py:480-485,524-529) in one launch (k_fn_head3, csrc/fn_head3.h: conv3x3(conv0; Wout . Wskip),
+    the two row-parity phase layers over inter2 and the border term meet in one accumulator) against the four launches fn.out3a..d: the
+    same three terms, their partial sums added in another order (and fn.out3a in the Winograd form there) -- fp32 reassociation, held to
+    5e-6 of feat3's range; the zero border of the padded tensor stays untouched.  Widths that are not a multiple of the 64-pixel tile included."""
+    from synth import scene
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    shapes = ((64, 96, 3), (96, 160, 4), (224, 352, 3))
+    runs = []
+    for env in ({}, {"DR_FN_HEAD3": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = DrMvsnet(trained_blob)
+        res = []
+        for (h, w, v) in shapes:
+            win = scene.make_window(h, w, v, seed=12)
+            m.upload(h, w, v, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), 0.5, 5.0, 2.5)
+            m.forward(1)
+            prof = {r["op"]: r["kernel"] for r in m.profile()}
+            res.append((m.tensor("feat3").copy(), prof, m.download().depth_dense.copy()))
+        runs.append(res)
+        m.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    for (fa, pa, da), (fb, pb, db) in zip(*runs):
+        assert pa.get("fn.head3") == "k_fn_head3" and "fn.out3a" not in pa, pa
+        assert "fn.head3" not in pb and all(n in pb for n in ("fn.out3a", "fn.out3b", "fn.out3c", "fn.out3d")), pb
+        assert fa.shape == fb.shape and np.isfinite(fa).all() and np.abs(fb).max() > 0.1
+        assert np.abs(fa - fb).max() <= 5e-6 * np.abs(fb).max(), np.abs(fa - fb).max() / np.abs(fb).max()
+        assert np.abs(da - db).mean() < 1e-4
+
+
 def test_fused_skip_on_the_marching_kernel(trained_blob, monkeypatch, parity_hooks):
     """out.stage3 with the skip computed by k_conv_m's producer waves (conv_march.h, march_producer_fz) against the same
     layer on k_conv's fused staging: same fmaf chain in the skip, same channel-pass and tap order in the 3x3 layer, so
@@ -422,8 +454,9 @@ def test_folded_out_stage3_equals_the_literal_order(trained_blob, monkeypatch, p
     from synth import scene
     from tandem_amd.dr_mvsnet import DrMvsnet
     res = []
-    for folded in ("1", "0"):
+    for folded, head3 in (("1", "1"), ("1", "0"), ("0", "1")):  # the folded form in one launch (k_fn_head3, the default since round 5) and in four; the literal order
         monkeypatch.setenv("DR_OUT3_FOLDED", folded)
+        monkeypatch.setenv("DR_FN_HEAD3", head3)
         m = DrMvsnet(trained_blob)
         out = []
         for (h, w, v) in ((96, 160, 4), (224, 352, 3), (64, 96, 2)):
@@ -434,13 +467,15 @@ def test_folded_out_stage3_equals_the_literal_order(trained_blob, monkeypatch, p
             out.append((m.tensor("feat3").copy(), m.download().depth_dense.copy(), ops))
         res.append(out)
         m.close()
-    for (fa, da, oa), (fb, db, ob) in zip(*res):
-        assert "fn.out3a" in oa and "fn.out3d" in oa and "fn.out3" in ob, (oa, ob)
+    for (f1, d1, o1), (f4, d4, o4), (fb, db, ob) in zip(*res):
+        assert "fn.head3" in o1 and "fn.out3a" not in o1, o1
+        assert "fn.out3a" in o4 and "fn.out3d" in o4 and "fn.out3" in ob and "fn.head3" not in ob, (o4, ob)
         scale = np.abs(fb).max()
-        assert np.abs(fa - fb).max() <= 2e-5 * scale, np.abs(fa - fb).max() / scale
-        for sl in (np.s_[:, 0], np.s_[:, -1], np.s_[:, :, 0], np.s_[:, :, -1]):  # the four image borders
-            assert np.abs(fa[sl] - fb[sl]).max() <= 2e-5 * scale
-        assert np.abs(da - db).mean() < 1e-4 and np.abs(da - db).max() < 5e-2
+        for fa, da in ((f1, d1), (f4, d4)):
+            assert np.abs(fa - fb).max() <= 2e-5 * scale, np.abs(fa - fb).max() / scale
+            for sl in (np.s_[:, 0], np.s_[:, -1], np.s_[:, :, 0], np.s_[:, :, -1]):  # the four image borders
+                assert np.abs(fa[sl] - fb[sl]).max() <= 2e-5 * scale
+            assert np.abs(da - db).mean() < 1e-4 and np.abs(da - db).max() < 5e-2
 
 
 @pytest.mark.parametrize("views", [2, 3, 4, 6, 7])

@@ -64,6 +64,12 @@ PY
         DR_FN_FRONT=$f timeout 600 python bench.py --gpus 1 --steps 60 --warmup 5 --no-cpu --no-loop --no-boundary --no-tsdf > $OUT/${TAG}_bench_front$f.json 2> $OUT/${TAG}_bench_front$f.err
         python -c "import json; d=json.load(open('$OUT/${TAG}_bench_front$f.json')); print('DR_FN_FRONT=$f: value %.1f /s  ms_per_step %.3f  single_window %.3f ms' % (d['value'], d['ms_per_step'], d['single_window_ms']))"
       done | tee -a $OUT/${TAG}_front_ops.txt ;;
+    ab_head3)  # k_fn_head3 against the four launches it replaces
+      for f in 1 0; do echo "DR_FN_HEAD3=$f: $(DR_FN_HEAD3=$f timeout 300 python tools/profile_ops.py "fn.head3|fn.out3|fn.out2|fn.skip2" 2>&1 | tail -1)"; done | tee $OUT/${TAG}_head3_ops.txt
+      for f in 1 0 1 0; do
+        DR_FN_HEAD3=$f timeout 600 python bench.py --gpus 1 --steps 60 --warmup 5 --no-cpu --no-loop --no-boundary --no-tsdf > $OUT/${TAG}_bench_head3$f.json 2> $OUT/${TAG}_bench_head3$f.err
+        python -c "import json; d=json.load(open('$OUT/${TAG}_bench_head3$f.json')); print('DR_FN_HEAD3=$f: value %.1f /s  ms_per_step %.3f  single_window %.3f ms' % (d['value'], d['ms_per_step'], d['single_window_ms']))"
+      done | tee -a $OUT/${TAG}_head3_ops.txt ;;
     ops) timeout 600 python tools/profile_ops.py > $OUT/${TAG}_ops.txt 2>&1; tail -4 $OUT/${TAG}_ops.txt ;;
     pmc)  # counters in their own passes (--kernel-trace only), strictly sequential kernels (one engine, side stream off) -> profiles/r05_pmc_traffic.json, stamped with this tree's source hash
       export DR_MVS_NO_SIDE_STREAM=1
