@@ -772,7 +772,8 @@ class MvsEngine {
     const HostTensor &wa = blob_.at(fn + "conv0.0.conv.weight"), &wb = blob_.at(fn + "conv0.1.conv.weight");
     const bool shape_ok = wa.dims.size() == 4 && wa.dims[0] == 8 && wa.dims[1] == 3 && wa.dims[2] == 3 && wa.dims[3] == 3 &&
                           wb.dims.size() == 4 && wb.dims[0] == 8 && wb.dims[1] == 8 && wb.dims[2] == 3 && wb.dims[3] == 3;
-    if (!sw_.fn_front || conv_bf3_policy() || !shape_ok) {
+    const bool fits32 = (double)V * H * W * 32.0 < 2147483648.0 && ((uintptr_t)d_bgr_ & 3) == 0;  // (the kernel addresses both tensors with 32-bit byte offsets from an aligned base)
+    if (!sw_.fn_front || conv_bf3_policy() || !shape_ok || !fits32) {
       DevTensor &img = alloc("image", V, H, W, 4);
       { Op o; o.kind = Op::PREPROCESS; o.name = "preprocess"; o.bytes = (double)V * H * W * (3 + 16); ops_.push_back(o); }
       DevTensor &c3a = cbr2("fn.conv0.0", fn + "conv0.0", img, 3, 1, CONV_XPAIR);
@@ -884,7 +885,7 @@ class MvsEngine {
         }
       for (int co = 0; co < 8; ++co) { double b = 0; for (int t = 0; t < 9; ++t) b += (double)T[t * 8 + co]; bint[co] = (float)b; }
       DevTensor &f3 = alloc("feat3", c3.D, c3.H, c3.W, 8, fpad);
-      if (sw_.fn_head3 && !conv_bf3_policy()) {  // one launch: the three terms meet in one accumulator (fn_head3.h)
+      if (sw_.fn_head3 && !conv_bf3_policy() && (double)f3.n() * 4.0 < 2147483648.0 && (double)i2.n() * 4.0 < 2147483648.0) {  // one launch: the three terms meet in one accumulator (fn_head3.h)
         Op o; o.kind = Op::HEAD3; o.name = "fn.head3";
         Head3Args &a = o.head3;
         a.c0 = c3.d; a.i2 = i2.d;

@@ -51,7 +51,7 @@ static_assert(kFrontG2 % kFrontWaves == 0 && kFrontAW % 2 == 0, "tile shape");
 constexpr size_t kFrontLdsBytes = (size_t)kFrontNPI * 16 + (size_t)kFrontAH * kFrontAW * kFrontCIS2 * 4 + (size_t)(kFrontNU1 + kFrontNU2) * 64 * 16 + 256 * 4;
 
 struct FrontArgs {
-  const uint8_t *bgr;     // [V][H][W][3], followed by at least 8 readable bytes (the kernel fetches a pixel as the two aligned words around it)
+  const uint8_t *bgr;     // [V][H][W][3], 4-byte aligned, followed by at least 8 readable bytes (the kernel fetches a pixel as the two aligned words around it)
   const float *lut;       // 256 floats: float(double(b) / 255.0)
   const float4 *w1, *w2;  // packed weights [chunk][lane]: lane (i = l & 15, g = l >> 4) holds K = 16 u + 4 g .. + 3 of XPAIR row i
   const float *sb1, *sb2; // 16 scales then 16 biases per layer (row r = 8 * (x of the pair) + channel)
@@ -125,20 +125,25 @@ __global__ __launch_bounds__(kFrontThreads, 4) void k_fn_front(const FrontArgs a
   // an s_waitcnt vmcnt in front of the K loops; a 32-bit word is left alone until it is used.  A pixel outside the image reads the first
   // words of the buffer and is replaced by table entry 0 (= 0.f, the padding value) when it is converted.
   unsigned plo[kFrontPPT], phi[kFrontPPT], pin = 0;  // pin: per pixel 1 bit "inside" (bit e) and 2 bits byte offset inside plo (bits 8 + 2e ..)
+  int fy[kFrontPPT], fx[kFrontPPT], frel[kFrontPPT];  // this thread's pixels: image-tile row / column, bytes from the tile's first pixel (the same for every tile)
+#pragma unroll
+  for (int e = 0; e < kFrontPPT; ++e) {
+    const int n = e * kFrontThreads + tid;
+    fy[e] = n / kFrontIW; fx[e] = n - fy[e] * kFrontIW;
+    frel[e] = n < kFrontNPI ? (fy[e] * a.W + fx[e]) * 3 : -1;
+  }
   auto fetch = [&](int k) {
     int v, y0, x0;
     origin(k, v, y0, x0);
     pin = 0;
+    const int o0 = ((v * a.H + y0 - 2) * a.W + x0 - 2) * 3;  // (scalar; 32-bit byte offsets from the 4-byte aligned base: scalar-base loads, the host refuses 2 GB and more)
 #pragma unroll
     for (int e = 0; e < kFrontPPT; ++e) {
-      const int n = e * kFrontThreads + tid, iy = n / kFrontIW, ix = n - iy * kFrontIW;
-      const int gy = y0 - 2 + iy, gx = x0 - 2 + ix;
-      const bool in = n < kFrontNPI && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-      const unsigned long long u = (unsigned long long)a.bgr + (in ? (((size_t)v * a.H + gy) * a.W + gx) * 3 : (size_t)0);
-      typedef const unsigned __attribute__((address_space(1))) *gptr_t;  // a GLOBAL pointer: an integer cast to a plain pointer is generic, and a flat load makes hipcc wait for it before every LDS access
-      const gptr_t q = (gptr_t)(u & ~3ull);
+      const bool in = frel[e] >= 0 && (unsigned)(y0 - 2 + fy[e]) < (unsigned)a.H && (unsigned)(x0 - 2 + fx[e]) < (unsigned)a.W;
+      const unsigned ob = in ? (unsigned)(o0 + frel[e]) : 0u;
+      const unsigned *q = reinterpret_cast<const unsigned *>(a.bgr + (size_t)(ob & ~3u));
       plo[e] = q[0]; phi[e] = q[1];
-      pin |= (in ? 1u << e : 0u) | ((unsigned)(u & 3ull) << (8 + 2 * e));
+      pin |= (in ? 1u << e : 0u) | ((ob & 3u) << (8 + 2 * e));
     }
   };
 
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(kFrontThreads, 4) void k_fn_front(const FrontArgs a
         o.y = fmaxf(acc[pt][1] * sc2.y + bi2.y, 0.f);
         o.z = fmaxf(acc[pt][2] * sc2.z + bi2.z, 0.f);
         o.w = fmaxf(acc[pt][3] * sc2.w + bi2.w, 0.f);
-        *reinterpret_cast<float4 *>(a.out + (((size_t)v * a.H + gy) * a.W + gx) * 8 + 4 * (g & 1)) = o;
+        *reinterpret_cast<float4 *>(reinterpret_cast<char *>(a.out) + (size_t)((unsigned)(((v * a.H + gy) * a.W + gx) * 8 + 4 * (g & 1)) * 4u)) = o;
       }
     }
   }

@@ -54,7 +54,7 @@ struct Head3Args {
   const float *bias16;     // interior bias per XPAIR row (16)
   const float *T;          // [9][8]: the bias share of every tap (border correction)
   float *out;              // first LOGICAL pixel of feat3 (padded tensor: strides below)
-  int V, H, W;             // full resolution (H, W even)
+  int V, H, W;             // full resolution (H, W even); every tensor below 2 GB (32-bit byte offsets)
   int out_row, out_plane;  // floats between two rows / two views of `out`
   int tilesY, tilesX, ntiles;
 };
@@ -125,37 +125,40 @@ __global__ __launch_bounds__(kH3Threads, 4) void k_fn_head3(const Head3Args a) {
   };
   const int H2 = a.H >> 1, W2 = a.W >> 1;
 
-  // this thread's float4s of the two tiles: tile-relative coordinates and LDS destinations are the same for every tile
-  int ay[kH3PA], ax[kH3PA], adst[kH3PA], aoff[kH3PA];  // conv0: tile row / column, LDS float index (-1: none), c4 * 4
-  int by[kH3PB], bx[kH3PB], bdst[kH3PB], boff[kH3PB];
+  // this thread's float4s of the two tiles: tile-relative coordinates, LDS destinations and the offset from the tile's first element are the same
+  // for every tile (32-bit byte offsets from the tensor's base: the loads take the scalar-base form, no 64-bit address arithmetic per element;
+  // the host refuses tensors of 2 GB and more)
+  int ay[kH3PA], ax[kH3PA], adst[kH3PA], arel[kH3PA];  // conv0: tile row / column, LDS float index (-1: none), floats from the tile origin
+  int by[kH3PB], bx[kH3PB], bdst[kH3PB], brel[kH3PB];
 #pragma unroll
   for (int e = 0; e < kH3PA; ++e) {
     const int n = e * kH3Threads + tid, pos = n >> 1, c4 = n & 1;
     ay[e] = pos / kH3AW; ax[e] = pos - ay[e] * kH3AW;
-    adst[e] = n < kH3NA4 ? pos * kH3CISA + 4 * c4 : -1; aoff[e] = 4 * c4;
+    adst[e] = n < kH3NA4 ? pos * kH3CISA + 4 * c4 : -1; arel[e] = (ay[e] * a.W + ax[e]) * 8 + 4 * c4;
   }
 #pragma unroll
   for (int e = 0; e < kH3PB; ++e) {
     const int n = e * kH3Threads + tid, pos = n >> 3, c4 = n & 7;
     by[e] = pos / kH3BW; bx[e] = pos - by[e] * kH3BW;
-    bdst[e] = n < kH3NB4 ? pos * kH3CISB + 4 * c4 : -1; boff[e] = 4 * c4;
+    bdst[e] = n < kH3NB4 ? pos * kH3CISB + 4 * c4 : -1; brel[e] = (by[e] * W2 + bx[e]) * 32 + 4 * c4;
   }
   float4 pa[kH3PA], pb[kH3PB];
   auto fetch = [&](int k) {  // nothing is waited for here
     int v, y0, x0;
     origin(k, v, y0, x0);
+    const int oa = ((v * a.H + y0 - 1) * a.W + x0 - 1) * 8;  // (scalar; negative for the first tile: its out-of-image elements are not loaded)
 #pragma unroll
     for (int e = 0; e < kH3PA; ++e) {
-      const int gy = y0 - 1 + ay[e], gx = x0 - 1 + ax[e];
       pa[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (adst[e] >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) pa[e] = *reinterpret_cast<const float4 *>(a.c0 + (((size_t)v * a.H + gy) * a.W + gx) * 8 + aoff[e]);
+      if (adst[e] >= 0 && (unsigned)(y0 - 1 + ay[e]) < (unsigned)a.H && (unsigned)(x0 - 1 + ax[e]) < (unsigned)a.W)
+        pa[e] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.c0) + (size_t)((unsigned)(oa + arel[e]) * 4u));
     }
-    const int m0 = y0 >> 1, n0 = x0 >> 1;
+    const int m0 = y0 >> 1, n0 = x0 >> 1, ob = ((v * H2 + m0 - 1) * W2 + n0 - 1) * 32;
 #pragma unroll
     for (int e = 0; e < kH3PB; ++e) {
-      const int gy = m0 - 1 + by[e], gx = n0 - 1 + bx[e];
       pb[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (bdst[e] >= 0 && gy >= 0 && gy < H2 && gx >= 0 && gx < W2) pb[e] = *reinterpret_cast<const float4 *>(a.i2 + (((size_t)v * H2 + gy) * W2 + gx) * 32 + boff[e]);
+      if (bdst[e] >= 0 && (unsigned)(m0 - 1 + by[e]) < (unsigned)H2 && (unsigned)(n0 - 1 + bx[e]) < (unsigned)W2)
+        pb[e] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.i2) + (size_t)((unsigned)(ob + brel[e]) * 4u));
     }
   };
   auto stage = [&]() {
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(kH3Threads, 4) void k_fn_head3(const Head3Args a) {
           }
         o.x -= corr.x; o.y -= corr.y; o.z -= corr.z; o.w -= corr.w;
       }
-      *reinterpret_cast<float4 *>(a.out + (size_t)v * a.out_plane + (size_t)gy * a.out_row + (size_t)gx * 8 + 4 * (g & 1)) = o;
+      *reinterpret_cast<float4 *>(reinterpret_cast<char *>(a.out) + (size_t)((unsigned)(v * a.out_plane + gy * a.out_row + gx * 8 + 4 * (g & 1)) * 4u)) = o;
     }
   }
 }

@@ -46,7 +46,8 @@ def main():
     ms = m.forward(1)
     print("hip forward %.3f ms" % ms)
     image, _, _ = O.preprocess(win["bgrs"], win["K"], win["c2ws"], win["ref_index"])
-    report("image", m.tensor("image")[..., :3], image.permute(0, 2, 3, 1).numpy())
+    if os.environ.get("DR_FN_FRONT") == "0":  # (k_fn_front, the default, keeps the float image in LDS: the tensor exists in the three-launch form only)
+        report("image", m.tensor("image")[..., :3], image.permute(0, 2, 3, 1).numpy())
     for s in (1, 2, 3):
         report(f"feat{s}", m.tensor(f"feat{s}"), ref["debug"]["features"][s - 1].permute(0, 2, 3, 1).numpy())
     for s in (1, 2, 3):

@@ -70,6 +70,12 @@ PY
         DR_FN_HEAD3=$f timeout 600 python bench.py --gpus 1 --steps 60 --warmup 5 --no-cpu --no-loop --no-boundary --no-tsdf > $OUT/${TAG}_bench_head3$f.json 2> $OUT/${TAG}_bench_head3$f.err
         python -c "import json; d=json.load(open('$OUT/${TAG}_bench_head3$f.json')); print('DR_FN_HEAD3=$f: value %.1f /s  ms_per_step %.3f  single_window %.3f ms' % (d['value'], d['ms_per_step'], d['single_window_ms']))"
       done | tee -a $OUT/${TAG}_head3_ops.txt ;;
+    fn_quick)  # the two fused FeatureNet kernels as they stand: per-op times and the quick bench line, twice
+      echo "$(timeout 300 python tools/profile_ops.py "fn.front|fn.head3" 2>&1 | tail -1)" | tee $OUT/${TAG}_fn_quick.txt
+      for r in 1 2; do
+        timeout 600 python bench.py --gpus 1 --steps 60 --warmup 5 --no-cpu --no-loop --no-boundary --no-tsdf > $OUT/${TAG}_bench_fnq.json 2> $OUT/${TAG}_bench_fnq.err
+        python -c "import json; d=json.load(open('$OUT/${TAG}_bench_fnq.json')); print('value %.1f /s  ms_per_step %.3f  single_window %.3f ms' % (d['value'], d['ms_per_step'], d['single_window_ms']))"
+      done | tee -a $OUT/${TAG}_fn_quick.txt ;;
     ops) timeout 600 python tools/profile_ops.py > $OUT/${TAG}_ops.txt 2>&1; tail -4 $OUT/${TAG}_ops.txt ;;
     pmc)  # counters in their own passes (--kernel-trace only), strictly sequential kernels (one engine, side stream off) -> profiles/r05_pmc_traffic.json, stamped with this tree's source hash
       export DR_MVS_NO_SIDE_STREAM=1
