@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5's GPU script: ONE parameterised entry point for every gpurun call (the r4 per-call scripts were folded into this form).
 #   tools/gpu_r5.sh <tag> <step> [<step> ...]       results under gpurun_out/<tag>_*
-# steps: fused_sweep fused_prio corun batch_proxy ops ab_front tests tests_fast smoke bench bench_quick shipped pmc prof_seq prof_driver
+# steps: fused_sweep fused_prio corun batch_proxy ops ab_front ab_head3 fn_quick engines ab_ops ab_tail ops_tail ops_prob cv_sweep loop_raycast bench_host tune tests tests_fast smoke bench bench_quick shipped pmc prof_seq prof_driver
 #   the round's closing evidence, in the order bench.py needs it:  tools/gpu_r5.sh final pmc tests smoke bench shipped prof_seq prof_driver
 set -u
 cd "$(dirname "$0")/.."
@@ -76,6 +76,11 @@ PY
         timeout 600 python bench.py --gpus 1 --steps 60 --warmup 5 --no-cpu --no-loop --no-boundary --no-tsdf > $OUT/${TAG}_bench_fnq.json 2> $OUT/${TAG}_bench_fnq.err
         python -c "import json; d=json.load(open('$OUT/${TAG}_bench_fnq.json')); print('value %.1f /s  ms_per_step %.3f  single_window %.3f ms' % (d['value'], d['ms_per_step'], d['single_window_ms']))"
       done | tee -a $OUT/${TAG}_fn_quick.txt ;;
+    engines)  # windows in flight: 2 / 3 / 4 engines (the quick bench line each)
+      for n in 3 4 2 3 4; do
+        timeout 600 python bench.py --gpus 1 --steps 60 --warmup 5 --engines $n --no-cpu --no-loop --no-boundary --no-tsdf > $OUT/${TAG}_bench_eng.json 2> $OUT/${TAG}_bench_eng.err
+        python -c "import json; d=json.load(open('$OUT/${TAG}_bench_eng.json')); print('engines $n: value %.1f /s  ms_per_step %.3f' % (d['value'], d['ms_per_step']))"
+      done | tee $OUT/${TAG}_engines.txt ;;
     ops) timeout 600 python tools/profile_ops.py > $OUT/${TAG}_ops.txt 2>&1; tail -4 $OUT/${TAG}_ops.txt ;;
     pmc)  # counters in their own passes (--kernel-trace only), strictly sequential kernels (one engine, side stream off) -> profiles/r05_pmc_traffic.json, stamped with this tree's source hash
       export DR_MVS_NO_SIDE_STREAM=1
