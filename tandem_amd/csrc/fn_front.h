@@ -8,8 +8,9 @@
 //
 // One workgroup = 8 waves, persistent over its tiles (XCD k owns the k-th contiguous range of tiles, as k_conv_a).  A tile is 8 rows x 64 pixels of
 // output.  Per tile:
-//   1. the 12 x 68 pixels of the input around it (2-pixel halo), fetched as bytes into registers ONE TILE AHEAD (under the previous tile's two K
-//      loops), go through the 256-entry table (in LDS) into the image tile: one float4 (R, G, B, 0) per pixel;
+//   1. the 12 x 68 pixels of the input around it (2-pixel halo), fetched into registers ONE TILE AHEAD (under the previous tile's two K loops; a
+//      pixel as the two aligned 32-bit words around its three bytes), go through the 256-entry table (in LDS) into the image tile: one float4
+//      (R, G, B, 0) per pixel -- written between conv0.1's K loop and its stores, so that the wait for the prefetch is not a wait for the stores;
 //   2. conv0.0 on the matrix pipe over the 10 x 66 pixels conv0.1 needs (1-pixel halo): XPAIR rows (8 channels x 2 adjacent x, 4-wide x window,
 //      K = 12 taps x 4 channels = 3 chunks), the 10 x 33 pixel pairs enumerated row-major and dealt to the waves in groups of 16 -- a B operand is
 //      16 ARBITRARY positions, so the region needs no padding to a multiple of 16 pairs per row (21 groups instead of 30);
