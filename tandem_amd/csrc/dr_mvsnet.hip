@@ -208,6 +208,8 @@ struct MvsSwitches {
   int tail_fused = num("DR_TAIL_FUSED", 0);              // 0: the two-kernel path; 1: k_tail_m (transposed convolution on the matrix pipe); 2: k_tail (on the vector pipe)
   bool fn_front = num("DR_FN_FRONT", 1) != 0;          // 1: FeatureNet's first block (u8 -> float, conv0.0, conv0.1) in one launch (k_fn_front); 0: the three launches
   bool fn_head3 = num("DR_FN_HEAD3", 1) != 0;          // 1: the folded stage-3 head of FeatureNet (fn.out3a..d) in one launch (k_fn_head3); 0: the four launches
+  bool filter_fused = num("DR_FILTER_FUSED", 1) != 0;    // 1: the radix select's scans run as the prologue of the kernels that follow them (5 launches); 0: a k_scan launch per level (8)
+  bool prob_regress = num("DR_PROB_REGRESS", 1) != 0;    // 1: where a stage's planes are one depth chunk of k_prob2 (D = 8), the regression runs in the same launch (k_prob2_regress)
   int tail_qy = num("DR_TAIL_QY", 0), tail_zchunk = num("DR_TAIL_ZCHUNK", 0);  // tuning: k_tail's tile (quad rows: 4, 8, 16, 32) and depth planes per workgroup (0: chosen by size)
   bool vol_split = !on("DR_VOL_NO_SPLIT");               // stage 1's 32-channel cost volume as two 16-channel halves (DevTensor::split); off: one (D,h,w,32) tensor (A/B)
 #ifdef DR_PARITY_HOOKS
@@ -580,6 +582,7 @@ class MvsEngine {
       }
       else if (o.kind == Op::PROB) {
         if (sw_.prob_v1) snprintf(kn, sizeof kn, "k_prob");
+        else if (o.stage >= 1 && o.stage <= 3 && prob_fused_last_[o.stage - 1]) snprintf(kn, sizeof kn, "k_prob2_regress<8>");
         else snprintf(kn, sizeof kn, "k_prob2<%d>", sw_.prob_rows == 2 || sw_.prob_rows == 4 ? sw_.prob_rows : 1);
       }
       else if (o.kind == Op::TAIL) snprintf(kn, sizeof kn, o.tail.wmf ? "k_tail_m<%d>" : "k_tail<%d>", std::max(3, tail_nout(o.tail.QY, o.tail.QX)));
@@ -839,9 +842,10 @@ class MvsEngine {
     has_output_ = false;
     DR_HIP(hipHostMalloc((void **)&h_in_, (size_t)V * H * W * 3, hipHostMallocDefault));
     d_bgr_ = dalloc<uint8_t>((size_t)V * H * W * 3 + 16); misc_.push_back(d_bgr_);  // (+16: k_fn_front fetches a pixel as the two aligned words around it)
-    d_state_ = dalloc<unsigned>(8); misc_.push_back(d_state_);
-    d_hist_ = dalloc<unsigned>(2048); misc_.push_back(d_hist_);
-    DR_HIP(hipMemset(d_hist_, 0, 2048 * 4));
+    d_state_ = dalloc<unsigned>(16); misc_.push_back(d_state_);   // four 4-word slots (the fused-scan form keeps one per level)
+    d_hist_ = dalloc<unsigned>(3 * 2048); misc_.push_back(d_hist_);  // one histogram per level (the k_scan form uses the first only)
+    DR_HIP(hipMemset(d_hist_, 0, 3 * 2048 * 4));
+    DR_HIP(hipMemset(d_state_, 0, 16 * 4));
 
     const std::string fn = "feature_net.";
     DevTensor &c3 = front_block(fn, V, H, W);
@@ -998,10 +1002,12 @@ class MvsEngine {
     { Op o; o.kind = Op::EDGE; o.name = "filter.edge"; o.bytes = 8.0 * H * W; ops_.push_back(o); }
     const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
     for (int i = 0; i < 3; ++i) {
-      Op o; o.kind = Op::HIST; o.shift = shifts[i]; o.bits = bits[i]; o.name = "filter.hist" + std::to_string(i); o.bytes = 4.0 * H * W; ops_.push_back(o);
+      Op o; o.kind = Op::HIST; o.shift = shifts[i]; o.bits = bits[i]; o.stage = i; o.d0 = i ? shifts[i - 1] : 0; o.d1 = i ? bits[i - 1] : 0;
+      o.name = "filter.hist" + std::to_string(i); o.bytes = 4.0 * H * W; ops_.push_back(o);
+      if (sw_.filter_fused) continue;  // (the scan of level i is the prologue of the next kernel: mvs_kernels.h k_hist_s / k_apply_s)
       Op q; q.kind = Op::SCAN; q.shift = shifts[i]; q.bits = bits[i]; q.name = "filter.scan" + std::to_string(i); ops_.push_back(q);
     }
-    { Op o; o.kind = Op::APPLY; o.name = "filter.apply"; o.bytes = 20.0 * H * W; ops_.push_back(o); }
+    { Op o; o.kind = Op::APPLY; o.name = "filter.apply"; o.shift = shifts[2]; o.bits = bits[2]; o.bytes = 20.0 * H * W; ops_.push_back(o); }
   }
 
   // Copies the window into pinned memory in model order [ref, others] (dr_mvsnet.cpp:190-197), enqueues
@@ -1212,7 +1218,14 @@ class MvsEngine {
             if (!big.load()) { DR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_prob2<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); big.store(1); }
             hipLaunchKernelGGL(k_prob2<4>, dim3(8 * cdiv(nw, 8)), dim3(256), pl, stream_, o.p0, o.p1, o.p2, o.d0, o.d1, o.d2, zc, gxp, gyp, gzp, nw);
           } else if (NR == 2) hipLaunchKernelGGL(k_prob2<2>, dim3(8 * cdiv(nw, 8)), dim3(256), pl, stream_, o.p0, o.p1, o.p2, o.d0, o.d1, o.d2, zc, gxp, gyp, gzp, nw);
-          else hipLaunchKernelGGL(k_prob2<1>, dim3(8 * cdiv(nw, 8)), dim3(256), pl, stream_, o.p0, o.p1, o.p2, o.d0, o.d1, o.d2, zc, gxp, gyp, gzp, nw);
+          else if (sw_.prob_regress && gzp == 1 && o.d0 == 8 && o.stage >= 1 && o.stage <= 3 && !sw_.regress_generic && !idle_stage) {
+            // all planes are one depth chunk: the regression follows in the lane that produced the logits (k_prob2_regress); the REGRESS op of this stage then has nothing to launch
+            hipLaunchKernelGGL(k_prob2_regress<8>, dim3(8 * cdiv(nw, 8)), dim3(256), pl, stream_, o.p0, o.p1, o.p2, o.d1, o.d2, gxp, gyp, nw, rg_[o.stage - 1]);
+            regress_done_[o.stage - 1] = true; prob_fused_last_[o.stage - 1] = true;
+          } else {
+            hipLaunchKernelGGL(k_prob2<1>, dim3(8 * cdiv(nw, 8)), dim3(256), pl, stream_, o.p0, o.p1, o.p2, o.d0, o.d1, o.d2, zc, gxp, gyp, gzp, nw);
+            if (o.stage >= 1 && o.stage <= 3) prob_fused_last_[o.stage - 1] = false;
+          }
           break;
         }
         case Op::TAIL:
@@ -1290,7 +1303,9 @@ class MvsEngine {
         }
         case Op::REGRESS: {
           const RegressArgs &r = rg_[o.stage - 1];
-          if (!idle_stage) {
+          const bool done = regress_done_[o.stage - 1];  // (k_prob2_regress did it)
+          regress_done_[o.stage - 1] = false;
+          if (!idle_stage && !done) {
             const dim3 grid(cdiv(r.h * r.w, 256)), block(256);
             const int D = sw_.regress_generic ? 0 : r.planes.D;  // DR_REGRESS_GENERIC=1: the three-pass kernel for every plane count (A/B and parity hook)
             if (D == 48) hipLaunchKernelGGL(k_regress_r<48>, grid, block, 0, stream_, r);
@@ -1312,17 +1327,24 @@ class MvsEngine {
           break;
         }
         case Op::EDGE:
-          hipLaunchKernelGGL(k_edge, dim3(cdiv(H_ * W_, 256)), dim3(256), 0, stream_, T("depth3").d, T("edge").d, H_, W_, d_state_, filter_rank_);
+          if (sw_.filter_fused) hipLaunchKernelGGL(k_edge2, dim3(cdiv(H_ * W_, 256)), dim3(256), 0, stream_, T("depth3").d, T("edge").d, H_, W_, d_state_, d_hist_, filter_rank_);
+          else hipLaunchKernelGGL(k_edge, dim3(cdiv(H_ * W_, 256)), dim3(256), 0, stream_, T("depth3").d, T("edge").d, H_, W_, d_state_, filter_rank_);
           break;
         case Op::HIST:
-          hipLaunchKernelGGL(k_hist, dim3(std::min(cdiv(H_ * W_, 256), sw_.hist_blocks)), dim3(256), 0, stream_, T("edge").d, H_ * W_, o.shift, o.bits, d_state_, d_hist_);
+          if (sw_.filter_fused && o.stage > 0)
+            hipLaunchKernelGGL(k_hist_s, dim3(std::min(cdiv(H_ * W_, 256), sw_.hist_blocks)), dim3(256), 0, stream_, T("edge").d, H_ * W_, o.d0, o.d1, o.shift, o.bits, o.stage,
+                               d_state_, d_hist_);
+          else hipLaunchKernelGGL(k_hist, dim3(std::min(cdiv(H_ * W_, 256), sw_.hist_blocks)), dim3(256), 0, stream_, T("edge").d, H_ * W_, o.shift, o.bits, d_state_, d_hist_);
           break;
         case Op::SCAN:
           hipLaunchKernelGGL(k_scan, dim3(1), dim3(256), 0, stream_, d_state_, d_hist_, o.shift, o.bits);
           break;
         case Op::APPLY:
-          hipLaunchKernelGGL(k_apply, dim3(cdiv(H_ * W_, 256)), dim3(256), 0, stream_, T("edge").d, d_state_, T("depth3").d, T("conf3").d,
-                             T("depth").d, T("confidence").d, H_ * W_);
+          if (sw_.filter_fused)
+            hipLaunchKernelGGL(k_apply_s, dim3(cdiv(H_ * W_, 256)), dim3(256), 0, stream_, T("edge").d, d_state_, d_hist_, o.shift, o.bits, T("depth3").d, T("conf3").d,
+                               T("depth").d, T("confidence").d, H_ * W_);
+          else hipLaunchKernelGGL(k_apply, dim3(cdiv(H_ * W_, 256)), dim3(256), 0, stream_, T("edge").d, d_state_, T("depth3").d, T("conf3").d,
+                                  T("depth").d, T("confidence").d, H_ * W_);
           break;
       }
       // the side stream's results are published after whichever op ends them (fn.out2; the LAST op of the fork range: a
@@ -1374,6 +1396,8 @@ class MvsEngine {
   hipEvent_t ev_h2d_ = nullptr;    // completion of a window uploaded straight from the caller's page-locked images
   unsigned *d_state_ = nullptr, *d_hist_ = nullptr;
   unsigned filter_rank_ = 0;
+  bool prob_fused_last_[3] = {false, false, false};  // (reporting: the last forward ran this stage's prob as k_prob2_regress)
+  bool regress_done_[3] = {false, false, false};  // set by a PROB op that also ran its stage's regression, consumed by the REGRESS op behind it
   int H_ = 0, W_ = 0, V_ = 0;
   int shard_nsrc_ = 0;  // > 0: view-shard rank, cost-volume divisor = source views of the whole window
   ncclComm_t comm_ = nullptr;  // view-shard communicator (drm_comm_init); the volumes are reduced in stream order when set

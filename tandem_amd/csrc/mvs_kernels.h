@@ -799,17 +799,20 @@ constexpr int kProbTY = 4, kProbTX = 64, kProbPos = (kProbTY + 2) * (kProbTX + 2
 // bit-identical for every NR.  MEASURED (MI355X, gpurun call c17 of round 5): 0.019 / 0.028 / 0.026 ms per stage at NR = 1, 0.029 / 0.044 / 0.038 at NR = 2,
 // 0.059 / 0.084 / 0.074 at NR = 4 -- half / a quarter of the workgroups, each with 1.7 / 3 x the LDS, lose more latency hiding than the shared reads save: the
 // product runs NR = 1 (DR_PROB_ROWS selects the others for A/B).
+// (the body as a device function: k_prob2_regress below runs it and the stage's regression in one launch).  Returns false for a surplus workgroup;
+// (yo, xo) = the lane's first pixel.
 template <int NR>
-__global__ __launch_bounds__(256) void k_prob2(const float *__restrict__ x, const float *__restrict__ wt /*[27][8]*/,
-                                               float *__restrict__ out, int D, int h, int w, int zchunk, int gx, int gy, int gz, int nwg) {
+__device__ inline bool prob2_body(const float *__restrict__ x, const float *__restrict__ wt /*[27][8]*/, float *__restrict__ out, int D, int h, int w, int zchunk,
+                                  int gx, int gy, int gz, int nwg, int &yo_out, int &xo_out) {
   constexpr int TY = kProbTY * NR, POS = (TY + 2) * (kProbTX + 2), NS = (POS + 255) / 256;
   extern __shared__ float4 prob_lds[];  // [buffer 2][channel half 2][POS]
   const int per = (nwg + 7) >> 3, nid = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);  // XCD k walks the k-th band of tile rows
-  if (nid >= nwg) return;
+  if (nid >= nwg) return false;
   const int bz = nid % gz, bxy = nid / gz, bx = bxy % gx, by = bxy / gx;
   const int tid = threadIdx.x, tx = tid & 63, ty = (tid >> 6) * NR;
   const int x0 = bx * kProbTX, y0 = by * TY, xo = x0 + tx, yo = y0 + ty;
   const int z0 = bz * zchunk, z1 = min(D, z0 + zchunk);
+  yo_out = yo; xo_out = xo;
   // this thread's share of a plane: staged positions tid, tid + 256, ... (both halves each)
   int spos[NS];
   const float *sptr[NS];
@@ -879,6 +882,13 @@ __global__ __launch_bounds__(256) void k_prob2(const float *__restrict__ x, cons
     }
     if (zz + 1 <= z1) stash(b ^ 1);
   }
+  return true;
+}
+template <int NR>
+__global__ __launch_bounds__(256) void k_prob2(const float *__restrict__ x, const float *__restrict__ wt /*[27][8]*/,
+                                               float *__restrict__ out, int D, int h, int w, int zchunk, int gx, int gy, int gz, int nwg) {
+  int yo, xo;
+  (void)prob2_body<NR>(x, wt, out, D, h, w, zchunk, gx, gy, gz, nwg, yo, xo);
 }
 inline size_t prob2_lds_bytes(int NR) { return (size_t)2 * 2 * (kProbTY * NR + 2) * (kProbTX + 2) * sizeof(float4); }
 
@@ -954,13 +964,7 @@ __global__ __launch_bounds__(256) void k_regress(const RegressArgs a) {
 // one round of loads, issued back to back, instead of three dependent passes over global memory plus the confidence window.
 // The arithmetic and its order are k_regress's.
 template <int D>
-__global__ __launch_bounds__(256) void k_regress_r(const RegressArgs a) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x, hw = a.h * a.w;
-  if (n >= hw) return;
-  const int y = n / a.w, x = n - y * a.w;
-  float v[D];
-#pragma unroll
-  for (int k = 0; k < D; ++k) v[k] = a.logits[(size_t)k * hw + n];
+__device__ inline void regress_regs(float (&v)[D], const RegressArgs &a, int y, int x, int n) {
   const PixelPlanes pp = make_planes(a.planes, y, x);
   float mx = -INFINITY;
 #pragma unroll
@@ -986,6 +990,33 @@ __global__ __launch_bounds__(256) void k_regress_r(const RegressArgs a) {
   a.depth[n] = dep;
   a.conf[n] = c;
 }
+template <int D>
+__global__ __launch_bounds__(256) void k_regress_r(const RegressArgs a) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x, hw = a.h * a.w;
+  if (n >= hw) return;
+  const int y = n / a.w, x = n - y * a.w;
+  float v[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) v[k] = a.logits[(size_t)k * hw + n];
+  regress_regs<D>(v, a, y, x, n);
+}
+// prob + regression in one launch (round 5; stage 3 of the headline configuration: its D = 8 planes are one depth chunk of k_prob2 already, so the
+// lane that owns a pixel has written all RD logits of it itself): k_prob2's march unchanged, then the lane reads its own logits back (a thread
+// observes its own stores; they come from L2) and k_regress_r's arithmetic follows -- the same expressions on the same values, bit-identical to
+// the two launches.  (Keeping the logits in registers instead needs the march unrolled RD + 2 times; hipcc then stops unrolling the tap loops.)
+template <int RD>
+__global__ __launch_bounds__(256) void k_prob2_regress(const float *__restrict__ x, const float *__restrict__ wt /*[27][8]*/, float *out, int h, int w,
+                                                       int gx, int gy, int nwg, const RegressArgs rg) {
+  int yo, xo;
+  if (!prob2_body<1>(x, wt, out, RD, h, w, RD, gx, gy, 1, nwg, yo, xo)) return;
+  if (yo >= h || xo >= w) return;
+  const int n = yo * w + xo;
+  const size_t hw = (size_t)h * w;
+  float v[RD];
+#pragma unroll
+  for (int k = 0; k < RD; ++k) v[k] = out[(size_t)k * hw + n];
+  regress_regs<RD>(v, rg, yo, xo, n);
+}
 
 // ------------------------------------------------------------------ edge filter
 // edge(x,y) = 15th smallest of |d(nb) - d(c)| over the zero-padded 5x5 window (incl. the centre's 0).
@@ -993,10 +1024,7 @@ __global__ __launch_bounds__(256) void k_regress_r(const RegressArgs a) {
 // bits -- which used to be a launch of its own.  Round 4 also moved each level's scan into the histogram kernel's last workgroup (ticket +
 // fence): 9 -> 5 launches, bit-identical, but 0.070 ms against 0.058 for the filter -- the scan behind a device-wide fence and a ticket round
 // trip costs more than the 6 us launch it saves; removed.)
-__global__ __launch_bounds__(256) void k_edge(const float *__restrict__ depth, float *__restrict__ edge, int h, int w, unsigned *__restrict__ state, unsigned rank) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n < 4) state[n] = n == 2 ? rank : 0u;
-  if (n >= h * w) return;
+__device__ inline void edge_pixel(const float *__restrict__ depth, float *__restrict__ edge, int h, int w, int n) {
   const int y = n / w, x = n - y * w;
   const float c = depth[n];
   float v[25];
@@ -1039,6 +1067,20 @@ __global__ __launch_bounds__(256) void k_edge(const float *__restrict__ depth, f
 #undef CE
   edge[n] = v[14];  // k = 15 (1-based), module.py:1336,1343
 #endif
+}
+__global__ __launch_bounds__(256) void k_edge(const float *__restrict__ depth, float *__restrict__ edge, int h, int w, unsigned *__restrict__ state, unsigned rank) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < 4) state[n] = n == 2 ? rank : 0u;
+  if (n >= h * w) return;
+  edge_pixel(depth, edge, h, w, n);
+}
+__global__ __launch_bounds__(256) void k_edge2(const float *__restrict__ depth, float *__restrict__ edge, int h, int w, unsigned *__restrict__ state, unsigned *__restrict__ hist,
+                                               unsigned rank) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < 4) state[n] = n == 2 ? rank : 0u;
+  for (int i = n; i < 3 * 2048; i += gridDim.x * blockDim.x) hist[i] = 0u;
+  if (n >= h * w) return;
+  edge_pixel(depth, edge, h, w, n);
 }
 
 // Exact k-th smallest of non-negative floats by a 3-level radix select on the bit pattern
@@ -1095,6 +1137,84 @@ __global__ __launch_bounds__(256) void k_scan(unsigned *__restrict__ state, unsi
     state[2] = rank - sel[1];
     state[3] = v;
   }
+}
+
+// ---- the same radix select with every level's scan folded into the kernel that needs its result (round 5: 8 -> 5 launches) ----
+// A one-workgroup k_scan between two histogram levels costs a launch and a dependent kernel boundary for 2 us of work.  Here EVERY workgroup of
+// the next kernel repeats that scan over the previous level's 2048 bins (8 KB from L2) before it starts -- no ticket, no device-wide fence (round
+// 4's last-workgroup form paid more for those than the launch it saved): the kernel boundary that is there anyway orders the histogram before
+// its readers.  The select's state lives in one 4-word slot per level -- slot L is written by workgroup 0 of the kernel that finished level L - 1 and
+// is only read by later kernels -- and every level has its own histogram (zeroed by k_edge2, which runs before all of them).
+//   state slot: [0] prefix value, [1] prefix mask, [2] remaining rank, [3] threshold bits (complete after the last level)
+struct SelectState { unsigned pv, pm, rank, thr; };
+// block-wide: the bin of `hist` (1 << bits bins, 2048 words allocated, zero beyond) that holds rank st.rank, appended to the prefix
+__device__ inline SelectState select_scan(const unsigned *__restrict__ hist, const SelectState st, int shift, int bits, unsigned *part /*[256]*/, unsigned *sel /*[2]*/) {
+  const int t = threadIdx.x;
+  const unsigned nb = 1u << bits;
+  unsigned loc[8], s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { loc[i] = hist[t * 8 + i]; s += loc[i]; }
+  part[t] = s;
+  if (t == 0) { sel[0] = nb - 1u; sel[1] = 0; }
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {  // Hillis-Steele inclusive scan (k_scan's)
+    const unsigned add = t >= off ? part[t - off] : 0u;
+    __syncthreads();
+    part[t] += add;
+    __syncthreads();
+  }
+  const unsigned excl = part[t] - s;
+  if (s && excl <= st.rank && st.rank < excl + s) {
+    unsigned cum = excl;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (cum + loc[i] > st.rank) { sel[0] = t * 8 + i; sel[1] = cum; break; }
+      cum += loc[i];
+    }
+  }
+  __syncthreads();
+  SelectState r;
+  r.pv = st.pv | (sel[0] << shift);
+  r.pm = st.pm | ((nb - 1u) << shift);
+  r.rank = st.rank - sel[1];
+  r.thr = r.pv;
+  __syncthreads();  // (part / sel may be reused by the caller)
+  return r;
+}
+// (k_edge2 above = k_edge + the three zeroed histograms; level 0 is k_hist on slot 0 and the first histogram)
+// histogram of level `level` (1 or 2: level 0 is k_hist on slot 0); prologue: the scan of level - 1
+__global__ __launch_bounds__(256) void k_hist_s(const float *__restrict__ edge, int n, int shift_prev, int bits_prev, int shift, int bits, int level,
+                                                unsigned *__restrict__ state, unsigned *__restrict__ hist) {
+  __shared__ unsigned sh[2048];
+  __shared__ unsigned part[256], sel[2];
+  const SelectState *slots = reinterpret_cast<const SelectState *>(state);
+  const SelectState st = select_scan(hist + (level - 1) * 2048, slots[level - 1], shift_prev, bits_prev, part, sel);
+  if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<SelectState *>(state)[level] = st;
+  for (int i = threadIdx.x; i < 2048; i += blockDim.x) sh[i] = 0;
+  __syncthreads();
+  const unsigned mask = (1u << bits) - 1u;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const unsigned key = __float_as_uint(edge[i]);
+    if ((key & st.pm) == st.pv) atomicAdd(&sh[(key >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  unsigned *out = hist + level * 2048;
+  for (int i = threadIdx.x; i < 2048; i += blockDim.x)
+    if (sh[i]) atomicAdd(&out[i], sh[i]);
+}
+// k_apply with the last level's scan as its prologue
+__global__ __launch_bounds__(256) void k_apply_s(const float *__restrict__ edge, unsigned *__restrict__ state, const unsigned *__restrict__ hist, int shift_last, int bits_last,
+                                                 const float *__restrict__ depth_dense, const float *__restrict__ conf_dense,
+                                                 float *__restrict__ depth, float *__restrict__ conf, int n) {
+  __shared__ unsigned part[256], sel[2];
+  const SelectState st = select_scan(hist + 2 * 2048, reinterpret_cast<const SelectState *>(state)[2], shift_last, bits_last, part, sel);
+  if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<SelectState *>(state)[3] = st;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float thr = __uint_as_float(st.thr);
+  const bool m = edge[i] > thr;  // strict, module.py:1357
+  depth[i] = m ? 0.f : depth_dense[i];
+  conf[i] = m ? 0.f : conf_dense[i];
 }
 
 __global__ __launch_bounds__(256) void k_apply(const float *__restrict__ edge, const unsigned *__restrict__ state,

@@ -381,6 +381,50 @@ def test_fused_head3_equals_the_four_launch_form(trained_blob, monkeypatch):
         assert np.abs(da - db).mean() < 1e-4
 
 
+def test_fewer_launches_at_the_tail_are_bit_identical(trained_blob, tmp_path, monkeypatch):
+    """Round 5's two launch reductions behind the last convolution, each against the form it replaces, bit for bit on every output:
+    (1) the edge filter's radix select with every level's scan as the prologue of the kernel that follows it (k_hist_s / k_apply_s, 8 -> 5
+    launches; module.py:1320-1361) -- integers only; (2) softmax / expectation / confidence in the launch that computes the logits where a
+    stage's planes are one depth chunk (k_prob2_regress, D = 8; module.py:1116-1133) -- the same expressions on the same values."""
+    from synth import scene
+    from tandem_amd import weights as Wt
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    _, tens = Wt.read_blob(trained_blob)
+    blobs = [trained_blob]
+    p = str(tmp_path / "w_48_8_8.tdmw")  # a second plane configuration: two stages with D = 8
+    Wt.write_blob(p, Wt.random_state((48, 8, 8), seed=3), depth_num=(48, 8, 8), view_aggregation=True)
+    blobs.append(p)
+    monkeypatch.setenv("DR_PROB_ZCHUNK", "8")  # (small frames: keep a D = 8 stage in one depth chunk, as the full-size frame has it by itself)
+    for blob in blobs:
+        runs = []
+        for env in ({}, {"DR_FILTER_FUSED": "0"}, {"DR_PROB_REGRESS": "0"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            m = DrMvsnet(blob)
+            res = []
+            for (h, w, v, disc) in ((64, 96, 3, 2.5), (96, 160, 4, 10.0), (224, 352, 3, 0.0)):
+                win = scene.make_window(h, w, v, seed=13)
+                m.upload(h, w, v, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), 0.5, 5.0, disc)
+                m.forward(1)
+                prof = {r["op"]: r["kernel"] for r in m.profile()}
+                out = m.download()
+                res.append((prof, m.tensor("edge").copy(), out.depth.copy(), out.confidence.copy(), out.depth_dense.copy(), out.confidence_dense.copy(),
+                            m.tensor("depth2").copy(), m.tensor("conf2").copy()))
+            runs.append(res)
+            m.close()
+            for k in env:
+                monkeypatch.delenv(k)
+        for a, b, c in zip(*runs):
+            assert "filter.scan0" not in a[0] and "filter.scan0" in b[0] and "filter.scan2" in b[0], (a[0], b[0])
+            assert a[0]["s3.prob"] == "k_prob2_regress<8>" and c[0]["s3.prob"] == "k_prob2<1>", (a[0]["s3.prob"], c[0]["s3.prob"])
+            if blob != trained_blob:
+                assert a[0]["s2.prob"] == "k_prob2_regress<8>" and a[0]["s1.prob"] == "k_prob2<1>"
+            for other in (b, c):
+                for x, y in zip(a[1:], other[1:]):
+                    assert np.array_equal(x, y)
+            assert np.isfinite(a[4]).all()
+
+
 def test_fused_skip_on_the_marching_kernel(trained_blob, monkeypatch, parity_hooks):
     """out.stage3 with the skip computed by k_conv_m's producer waves (conv_march.h, march_producer_fz) against the same
     layer on k_conv's fused staging: same fmaf chain in the skip, same channel-pass and tap order in the 3x3 layer, so

@@ -81,6 +81,12 @@ PY
         timeout 600 python bench.py --gpus 1 --steps 60 --warmup 5 --engines $n --no-cpu --no-loop --no-boundary --no-tsdf > $OUT/${TAG}_bench_eng.json 2> $OUT/${TAG}_bench_eng.err
         python -c "import json; d=json.load(open('$OUT/${TAG}_bench_eng.json')); print('engines $n: value %.1f /s  ms_per_step %.3f' % (d['value'], d['ms_per_step']))"
       done | tee $OUT/${TAG}_engines.txt ;;
+    ab_launches)  # the edge filter's folded scans and prob + regression in one launch, against the forms they replace
+      for f in 1 0; do echo "DR_FILTER_FUSED=$f DR_PROB_REGRESS=$f: $(DR_FILTER_FUSED=$f DR_PROB_REGRESS=$f timeout 300 python tools/profile_ops.py "filter|s3.prob|s3.regress" 2>&1 | tail -1)"; done | tee $OUT/${TAG}_launches_ops.txt
+      for f in 1 0 1 0; do
+        DR_FILTER_FUSED=$f DR_PROB_REGRESS=$f timeout 600 python bench.py --gpus 1 --steps 60 --warmup 5 --no-cpu --no-loop --no-boundary --no-tsdf > $OUT/${TAG}_bench_l$f.json 2> $OUT/${TAG}_bench_l$f.err
+        python -c "import json; d=json.load(open('$OUT/${TAG}_bench_l$f.json')); print('fused=$f: value %.1f /s  ms_per_step %.3f  single_window %.3f ms' % (d['value'], d['ms_per_step'], d['single_window_ms']))"
+      done | tee -a $OUT/${TAG}_launches_ops.txt ;;
     ops) timeout 600 python tools/profile_ops.py > $OUT/${TAG}_ops.txt 2>&1; tail -4 $OUT/${TAG}_ops.txt ;;
     pmc)  # counters in their own passes (--kernel-trace only), strictly sequential kernels (one engine, side stream off) -> profiles/r05_pmc_traffic.json, stamped with this tree's source hash
       export DR_MVS_NO_SIDE_STREAM=1
