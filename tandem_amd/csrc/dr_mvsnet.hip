@@ -1149,6 +1149,7 @@ class MvsEngine {
     // view shard, reduce-to-root form: between a stage's cost volume and its regression only rank 0 works
     const bool rooted = comm_ && shard_nsrc_ && !phase_mode_ && !sw_.shard_allreduce;
     bool idle_stage = false;
+    for (bool &f : regress_done_) f = false;  // (a PROB op and the REGRESS op it may answer for always lie in the same call; nothing is carried over from a call that threw)
     size_t i = 0;
     for (const Op &o : ops_) {
       if (ev) DR_HIP(hipEventRecord((*ev)[i], stream_));
