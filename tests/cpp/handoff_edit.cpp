@@ -33,7 +33,7 @@ extern "C" int edit_dense_handoff(int W, int H, const float *depth, const float 
     CudaCoarseTracker tracker(W, H, 9.f, 20.f), *cudaCoarseTracker = &tracker;
     tracker.setK(W, H, K9[0], K9[4], K9[2], K9[5]);
     tracker.init();
-    DenseDepth dd{true, c2w_dense, depth}, *dense_depth = &dd;
+    DenseDepth dd{true, c2w_dense, depth}, *dense_depth = depth ? &dd : nullptr;  // depth == nullptr: a reference frame without a rendered depth map
     const bool dense_depth_on_device = false;
     Mat44 last;
     for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) last(r, c) = c2w_last[4 * r + c];
@@ -51,6 +51,7 @@ extern "C" int edit_dense_handoff(int W, int H, const float *depth, const float 
     float *pc_u[1] = {pc_u0}, *pc_v[1] = {pc_v0}, *pc_idepth[1] = {pc_idepth0}, *pc_color[1] = {pc_color0};
 
 #include "CoarseTracker_dense_handoff.inc"
+    // (the reference's function ends here once its :732 is deleted, as the .inc's header says: nothing re-uploads the host arrays)
 
     int n = 0;
     if (drt_get_points(tracker.c_handle(), pc_u0, pc_v0, pc_idepth0, pc_color0, cap, &n) != DR_OK || n != pc_n[0]) return -2;

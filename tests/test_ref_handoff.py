@@ -40,7 +40,11 @@ def same_points(ref, o, n):
     for name, a, b in (("u", ref["u"], u), ("v", ref["v"], v), ("idepth", ref["idepth"], idp), ("color", ref["color"], col)):
         assert np.array_equal(a[:n0].view(np.uint32), b[:n0].view(np.uint32)), name  # the sparse points are untouched
         assert np.array_equal(a[n0 + 1:n + 1].view(np.uint32), b[n0:n].view(np.uint32)), "%s: appended points differ" % name
-    assert np.isnan(ref["u"][n0]) or n0 == 0 or True  # slot n0 is whatever it was (never written by the reference)
+    # the declared deviation, checked: the reference's pre-increment never writes slot n0 (oracle/ref_handoff.py pre-fills its arrays with NaN) ...
+    for name in ("u", "v", "idepth", "color"):
+        assert np.isnan(ref[name][n0]), "%s: the reference wrote slot n0" % name
+    # ... and its last point lands in slot pc_n, one past what pc_n[0] counts: it equals the restatement's last point
+    assert np.array_equal(ref["u"][n:n + 1].view(np.uint32), u[n - 1:n].view(np.uint32)) and np.isnan(ref["u"][n + 1])
     return n - n0
 
 
