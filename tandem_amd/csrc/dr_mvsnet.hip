@@ -214,7 +214,7 @@ struct MvsSwitches {
   bool vol_split = !on("DR_VOL_NO_SPLIT");               // stage 1's 32-channel cost volume as two 16-channel halves (DevTensor::split); off: one (D,h,w,32) tensor (A/B)
 #ifdef DR_PARITY_HOOKS
   bool costvol_v1 = on("DR_COSTVOL_V1");                 // round 2's k_costvol on unpadded feature maps
-  bool costvol_v3 = on("DR_COSTVOL_V3");                 // k_costvol3 everywhere, also where DR_CV4_STAGES selects the LDS-staged k_costvol4 (the only place the switch is read: cv4_applies)
+  bool costvol_v3 = on("DR_COSTVOL_V3");                 // k_costvol3 everywhere: also where the product runs k_costvol5 and where DR_CV4_STAGES selects the LDS-staged k_costvol4
   int costvol_cpl = num("DR_COSTVOL_CPL", 4) == 8 ? 8 : 4;
   bool prob_v1 = on("DR_PROB_V1");                       // round 2's k_prob (L1 gathers)
   int prob_block = std::max(64, std::min(256, num("DR_PROB_BLOCK", 256) / 64 * 64)), prob_xo = num("DR_PROB_XO", 1);
@@ -224,12 +224,19 @@ struct MvsSwitches {
   bool d2h_copy = getenv("DR_MVS_D2H") && !strcmp(getenv("DR_MVS_D2H"), "copy");  // four copy-engine transfers instead of k_publish4
   // k_costvol4 (round 4: source taps staged through LDS -- north_star's "LDS staging of per-pixel feature slices"): bit-identical to
   // k_costvol3 and measured 8-15 % SLOWER (0.121 / 0.163 / 0.105 against 0.106 / 0.150 / 0.099 ms per stage), so it is not in the product
+  // k_costvol5's two choices (round 6, profiles/r06_costvol_ab.txt): a sample whose footprint is the previous plane's issues no gathers (0.109 / 0.172 / 0.120 ->
+  // 0.084 / 0.150 / 0.117 ms at depth chunks of 4 / 8 / 8 planes); the workgroup tile is four rows of a quarter segment at stage 3 only (C = 8: 0.106 -> 0.095 ms
+  // there, 0.083 -> 0.089 at stage 1, nothing at stage 2)
+  int cv5_rows = num("DR_CV5_ROWS", 0);                  // 0: the product's rule (4 rows where C = 8); 1 / 4: that tile at every stage
+  bool cv5_reuse = num("DR_CV5_REUSE", 1) != 0;          // 0: every sample gathers its four taps
+  int cv5_abl = num("DR_CV5_ABL", 0);                    // measuring hook: k_costvol5 without its gathers (1), stores (2), tap arithmetic (4)
   int cv4_stages = num("DR_CV4_STAGES", 0);              // bit s-1 set = stage s builds its cost volume with k_costvol4 where it applies
   int cv4_sp8 = num("DR_CV4_SP8", 0);                    // bit s-1 set = 8 planes per k_costvol4 step at stage s (else 4)
 #else
   static constexpr bool costvol_v1 = false, costvol_v3 = false, prob_v1 = false, prob_launch_order = false, prob_on_conv = false, skip_on_conv = false,
                         no_skip_fusion = false, out3_folded = true, d2h_copy = false;
-  static constexpr int costvol_cpl = 4, prob_block = 256, prob_xo = 1, cv4_stages = 0, cv4_sp8 = 0;
+  static constexpr int costvol_cpl = 4, prob_block = 256, prob_xo = 1, cv4_stages = 0, cv4_sp8 = 0, cv5_abl = 0, cv5_rows = 0;
+  static constexpr bool cv5_reuse = true;
 #endif
 };
 
@@ -578,6 +585,7 @@ class MvsEngine {
         const int Cc = 32 >> (o.stage - 1), dch = ca.planes.D >= 8 ? 8 : 4;
         const bool v4 = cv4_applies(o.stage);
         if (v4) snprintf(kn, sizeof kn, "k_costvol4<%d,%d>", Cc, dch);
+        else if (cv5_applies(o.stage)) snprintf(kn, sizeof kn, "k_costvol5<%d,%d>", Cc, cv_[o.stage - 1].dchunk);
         else snprintf(kn, sizeof kn, sw_.costvol_v1 ? "k_costvol<%d>" : (sw_.costvol_v2 ? "k_costvol2<%d>" : "k_costvol3<%d>"), Cc);
       }
       else if (o.kind == Op::PROB) {
@@ -1084,8 +1092,10 @@ class MvsEngine {
       a.split = T("volume" + std::to_string(s)).split;
       a.V = V; a.h = h; a.w = w;
       a.dchunk = s == 1 ? 4 : (D >= 16 ? 8 : D);  // enough workgroups to fill 256 CUs at every stage
-      if (sw_.cv_dchunk[s - 1] > 0) a.dchunk = std::min(D, sw_.cv_dchunk[s - 1]);  // tuning hook
       a.view_aggregation = blob_.view_aggregation;
+      // k_costvol5 holds a chunk's planes in registers: 4 planes leave room for six waves per SIMD (0.150 -> 0.131 ms at stage 2, 0.117 -> 0.106 at stage 3)
+      if (a.view_aggregation && a.fpad && D % 4 == 0 && !sw_.costvol_v2 && !sw_.costvol_v3 && !sw_.cv4_stages) a.dchunk = 4;
+      if (sw_.cv_dchunk[s - 1] > 0) a.dchunk = std::min(D, sw_.cv_dchunk[s - 1]);  // tuning hook
       // view sharding: this rank's window holds a subset of the source views, the divisor stays the whole window's
       if (shard_nsrc_ && !blob_.view_aggregation) fail(DR_ERR_UNSUPPORTED, "view sharding needs a view-aggregation model (the variance volume is not a sum over views)");
       a.nsrc_f = shard_nsrc_ ? (float)shard_nsrc_ : (float)(V - 1);
@@ -1247,6 +1257,7 @@ class MvsEngine {
           }
           CostVolArgs b = a;
           b.gz = cdiv(a.planes.D, a.dchunk);
+          b.abl = sw_.cv5_abl;
 #ifdef DR_PARITY_HOOKS
           if (!a.fpad) {  // DR_COSTVOL_V1: round 2's kernel on unpadded feature maps; channels per lane 4 (fewest L1 line accesses per byte) or 8
             const int cpl = C >= 16 ? sw_.costvol_cpl : 4, pxb = 256 / (C / cpl);
@@ -1281,7 +1292,28 @@ class MvsEngine {
               else hipLaunchKernelGGL((k_costvol4<8, 4, 4>), g4, dim3(256), 0, stream_, c4);
             } else
 #endif
-            {
+            if (cv5_applies(o.stage)) {  // view-outer / plane-inner sweep, the chunk's planes accumulate in registers (bit-identical to k_costvol3)
+              const bool d8 = a.dchunk == 8;
+              CostVolArgs b4 = b;  // the four-row tile: x segments of a quarter of the pixels, four rows per workgroup
+              b4.gx = cdiv(a.w, 256 / C); b4.nwg = b4.gx * b4.gz * cdiv(a.h, 4);
+              const dim3 grid4(8 * cdiv(b4.nwg, 8));
+              const bool rows4 = sw_.cv5_rows ? sw_.cv5_rows == 4 : C == 8;
+#ifdef DR_PARITY_HOOKS
+#define DR_CV5(CC, DD) do { if (!sw_.cv5_reuse) hipLaunchKernelGGL((k_costvol5<CC, DD, 0, 1>), grid, dim3(256), 0, stream_, b); \
+                            else if (rows4) hipLaunchKernelGGL((k_costvol5<CC, DD, 1, 4>), grid4, dim3(256), 0, stream_, b4); \
+                            else hipLaunchKernelGGL((k_costvol5<CC, DD, 1, 1>), grid, dim3(256), 0, stream_, b); } while (0)
+#else
+#define DR_CV5(CC, DD) do { if (rows4) hipLaunchKernelGGL((k_costvol5<CC, DD, 1, (CC == 8 ? 4 : 1)>), grid4, dim3(256), 0, stream_, b4); \
+                            else hipLaunchKernelGGL((k_costvol5<CC, DD, 1, (CC == 8 ? 4 : 1)>), grid, dim3(256), 0, stream_, b); } while (0)
+#endif
+              if (C == 32 && d8) DR_CV5(32, 8);
+              else if (C == 32) DR_CV5(32, 4);
+              else if (C == 16 && d8) DR_CV5(16, 8);
+              else if (C == 16) DR_CV5(16, 4);
+              else if (d8) DR_CV5(8, 8);
+              else DR_CV5(8, 4);
+#undef DR_CV5
+            } else {
             // k_costvol3 (the lanes of a pixel share the per-sample set-up) needs whole batches of 4 iterations per depth chunk
             const bool v3 = !sw_.costvol_v2 && a.dchunk % 4 == 0 && a.planes.D % 4 == 0;
             if (v3 && C == 32) hipLaunchKernelGGL((k_costvol3<32>), grid, dim3(256), 0, stream_, b);
@@ -1357,6 +1389,12 @@ class MvsEngine {
     DR_HIP(hipGetLastError());
   }
 
+  // k_costvol5 (view-outer / plane-inner sweep): view-aggregation models, bordered feature maps, depth chunks of exactly 4 or 8 planes
+  bool cv5_applies(int stage) const {
+    const CostVolArgs &a = cv_[stage - 1];
+    return !sw_.costvol_v1 && !sw_.costvol_v2 && !sw_.costvol_v3 && a.fpad && a.view_aggregation && a.V > 1 && (a.dchunk == 4 || a.dchunk == 8) &&
+           a.planes.D % a.dchunk == 0;
+  }
   // k_costvol4 (taps staged through LDS): view-aggregation models, bordered feature maps, whole pixel tiles, whole depth chunks
   bool cv4_applies(int stage) const {
     const CostVolArgs &a = cv_[stage - 1];

@@ -136,6 +136,7 @@ struct CostVolArgs {
   int view_aggregation;
   int gx, gz, nwg;       // workgroup grid: x-blocks per row, depth chunks, total (rows = nwg / (gx * gz))
   int fpad;              // k_costvol2: the feature maps carry a zero border of this many pixels (1)
+  int abl;               // ablations for measurements (parity build only, DR_CV5_ABL): 1 = no gathers, 2 = no stores, 4 = no arithmetic on the taps
   int split;             // 16: the 32-channel volume of stage 1 is stored as TWO (D,h,w,16) halves one after the other (channels 0-15 | 16-31), so
                          // that each 16-channel pass of conv0 reads whole 64-byte records instead of half of every 128-byte one; 0: (D,h,w,C)
 };
@@ -296,10 +297,19 @@ __device__ inline float cv_dpp_add(float s, int ctrl) {  // s + s[dpp permutatio
 // The arithmetic of one (plane, view) sample, shared by k_costvol2 and k_costvol3 with every multiply-add spelled out: the two
 // kernels then agree bit for bit whatever the compiler would have contracted in either context.
 struct CvProj { int o; float w00, w01, w10, w11; int ix, iy, inside; };  // (ix, iy) = the sample's upper-left tap, -1 .. w-1 / h-1
+struct CvRay { float rx, ry, rz; };  // M[:3,:3] * (x, y, 1): the part of a sample's projection that does not depend on the plane (module.py:820-822)
+__device__ __forceinline__ CvRay cv_ray(const float *m, float xf, float yf) {
+  CvRay R;
+  R.rx = __builtin_fmaf(m[0], xf, __builtin_fmaf(m[1], yf, m[2])); R.ry = __builtin_fmaf(m[4], xf, __builtin_fmaf(m[5], yf, m[6]));
+  R.rz = __builtin_fmaf(m[8], xf, __builtin_fmaf(m[9], yf, m[10]));
+  return R;
+}
+__device__ __forceinline__ CvProj cv_project_ray(const float *m, const CvRay &R, float depth, float fw, float fh, int wp, int C);
 __device__ __forceinline__ CvProj cv_project(const float *m, float depth, float xf, float yf, float fw, float fh, int wp, int C) {
-  const float rx = __builtin_fmaf(m[0], xf, __builtin_fmaf(m[1], yf, m[2])), ry = __builtin_fmaf(m[4], xf, __builtin_fmaf(m[5], yf, m[6])),
-              rz = __builtin_fmaf(m[8], xf, __builtin_fmaf(m[9], yf, m[10]));
-  const float px = __builtin_fmaf(rx, depth, m[3]), py = __builtin_fmaf(ry, depth, m[7]), pz = __builtin_fmaf(rz, depth, m[11]);
+  return cv_project_ray(m, cv_ray(m, xf, yf), depth, fw, fh, wp, C);
+}
+__device__ __forceinline__ CvProj cv_project_ray(const float *m, const CvRay &R, float depth, float fw, float fh, int wp, int C) {
+  const float px = __builtin_fmaf(R.rx, depth, m[3]), py = __builtin_fmaf(R.ry, depth, m[7]), pz = __builtin_fmaf(R.rz, depth, m[11]);
   const float rcp = __builtin_amdgcn_rcpf(pz);
   const float u = px * rcp, vv = py * rcp;
   const bool inside = pz >= 0.001f && u > -1.f && u < fw && vv > -1.f && vv < fh;  // module.py:861,887; NaN fails too
@@ -521,6 +531,127 @@ __global__ __launch_bounds__(256, DR_CV3_MIN_WAVES) void k_costvol3(const CostVo
       if (++v == nsrc) { v = 0; ++d; }
     }
     P = Pn;
+  }
+}
+
+// k_costvol5 (round 6): the sweep in VIEW-OUTER / PLANE-INNER order.  k_costvol2/3 walk (plane outer, view inner) with one accumulator: every
+// iteration changes the view, so the view's matrix, its row bases and the pixel's ray M[:3,:3](x, y, 1) are per-iteration work, the loop is a
+// run-time (plane, view) counter with a reset and a store hidden behind branches, and consecutive gathers of a lane land in six different
+// images.  Here a workgroup takes its DCH planes of ONE view after the other with DCH float4 accumulators in registers:
+//   * per voxel the views are still added in the order v = 0 .. nsrc - 1 with the same products (cv_project_ray / cv_warp / the gate are
+//     k_costvol3's, every multiply-add spelled out), so the volume is BIT-IDENTICAL to k_costvol3's;
+//   * the view's matrix is wave-uniform again (scalar loads from the kernel arguments, no LDS copy), the ray is computed once per view
+//     (6 of the set-up's FMAs leave the plane loop), the plane loop is fully unrolled (no counters, no reset / store branches), and the four
+//     gathers are one 32-bit byte offset against two scalar row bases with immediate offsets 0 / 4 C (no 64-bit vector address arithmetic);
+//   * the lanes of a pixel still share the set-up as in k_costvol3: lane q of a batch of LPB planes projects plane q, the tap offset and
+//     the four weights travel by DPP;
+//   * consecutive iterations of a lane walk ONE epipolar line, plane by plane: at the headline shape and depth range 66 / 39 / 13 % of the
+//     steps (stage 1 / 2 / 3) land in the SAME 2 x 2 footprint and 17 / 24 / 14 % one texel beside it (tools/study/costvol_footprint_stat.py),
+//     so a sample's lines are in the L1 from the plane before.
+// View-aggregation models, depth chunks of exactly DCH planes; everything else stays on k_costvol3 / k_costvol2.
+template <int C, int DCH, int REUSE, int ROWS>
+__global__ __launch_bounds__(256) void k_costvol5(const CostVolArgs a) {
+  constexpr int LPV = C / 4;            // lanes per pixel, 4 channels each
+  constexpr int PXB = 256 / LPV;        // pixels per block
+  constexpr int LPB = LPV >= 4 ? 4 : 2; // planes per batch = lanes of a pixel (within one quad) that share their set-up
+  constexpr int NB = DCH / LPB;         // batches per view
+  static_assert(DCH % LPB == 0 && DCH % 2 == 0, "whole batches, and every view starts in tap set A");
+  const int tid = threadIdx.x, q = tid % LPV, qb = q & (LPB - 1);
+  const int per = (a.nwg + 7) >> 3;     // XCD-aware order, as k_costvol
+  const int nid = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+  if (nid >= a.nwg) return;
+  const int bz = nid % a.gz, bxy = nid / a.gz;
+  // ROWS = 4: the workgroup's four waves take four consecutive rows of one x segment (a.gx segments of PXB / 4 pixels) -- the footprints of rows y and
+  // y + 1 share a source row, so the workgroup touches 5 source rows where four row segments side by side touch 8
+  const int x = ROWS == 4 ? (bxy % a.gx) * (PXB / 4) + (tid & 63) / LPV : (bxy % a.gx) * PXB + tid / LPV, y = ROWS == 4 ? (bxy / a.gx) * 4 + (tid >> 6) : bxy / a.gx;
+  const int d0 = bz * DCH;
+  const bool live = x < a.w && y < a.h;
+  const int xc = min(x, a.w - 1), yc = min(y, a.h - 1);    // dead lanes keep running for the cross-lane gate sum
+  const int h = a.h, w = a.w, nsrc = a.V - 1, wp = w + 2;
+  const size_t vplane = (size_t)(h + 2) * wp * C;  // floats per padded view
+  const float fw = (float)w, fh = (float)h, xf = (float)xc, yf = (float)yc;
+  if (nsrc <= 0) return;
+
+  const float4 ref = ld4(a.feat + ((size_t)(yc + 1) * wp + xc + 1) * C + q * 4);
+  const float4 gw = make_float4(a.gw[q * 4], a.gw[q * 4 + 1], a.gw[q * 4 + 2], a.gw[q * 4 + 3]);
+  const PixelPlanes pp = make_planes(a.planes, yc, xc);
+  const float rcp_n = 1.f / a.nsrc_f;
+  float dep[NB];                        // this lane's own plane of every batch
+#pragma unroll
+  for (int b = 0; b < NB; ++b) dep[b] = plane_depth(pp, a.planes, d0 + b * LPB + qb);
+  // byte offset of a sample's upper-left tap from pixel (-1, -1) of the padded view (never negative: ix, iy >= -1), this lane's channels included
+  const unsigned obias = (unsigned)((wp + 1) * C + q * 4) * 4u;
+  const char *const f0 = reinterpret_cast<const char *>(a.feat);
+  const size_t vbytes = vplane * 4, rowbytes = (size_t)wp * C * 4;
+
+  unsigned ob_prev = 0;
+  // plane j of the batch: lane j's set-up, view v (uniform).  REUSE: where the sample's footprint is the one of the lane's previous plane (`prev`, same
+  // view), its four taps are already in registers: the lane issues no gather (no L1 request) and copies them.
+  auto gather = [&](const CvProj &P, int j, int v, CvTaps &T, const CvTaps &prev, bool first) {
+    const unsigned ob = (unsigned)cv_bcast_i(P.o, LPB, j) * 4u + obias;
+    T.w00 = cv_bcast_f(P.w00, LPB, j); T.w01 = cv_bcast_f(P.w01, LPB, j); T.w10 = cv_bcast_f(P.w10, LPB, j); T.w11 = cv_bcast_f(P.w11, LPB, j);
+    const char *r0 = f0 + (size_t)(v + 1) * vbytes, *r1 = r0 + rowbytes;  // wave-uniform bases: rows y0 and y0 + 1
+    if (REUSE && !first && ob == ob_prev) {
+      T.t00 = prev.t00; T.t01 = prev.t01; T.t10 = prev.t10; T.t11 = prev.t11;
+#ifdef DR_PARITY_HOOKS
+    } else if (a.abl & 1) {
+      T.t00 = T.t01 = T.t10 = T.t11 = make_float4(T.w00, T.w01, T.w10, T.w11);
+#endif
+    } else {
+      T.t00 = ld4(reinterpret_cast<const float *>(r0 + ob)); T.t01 = ld4(reinterpret_cast<const float *>(r0 + ob) + C);
+      T.t10 = ld4(reinterpret_cast<const float *>(r1 + ob)); T.t11 = ld4(reinterpret_cast<const float *>(r1 + ob) + C);
+    }
+    if (REUSE) ob_prev = ob;
+  };
+  float4 acc[DCH];
+#pragma unroll
+  for (int j = 0; j < DCH; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto consume = [&](float4 &ac, const CvTaps &T) {
+#ifdef DR_PARITY_HOOKS
+    if (a.abl & 4) { ac.x += T.t00.x + T.t01.y; ac.y += T.t10.z; ac.z += T.t11.w; ac.w += T.w00; return; }
+#endif
+    const float4 wv = cv_warp(T);
+    const float4 df = make_float4(wv.x - ref.x, wv.y - ref.y, wv.z - ref.z, wv.w - ref.w);
+    const float4 d2 = make_float4(df.x * df.x, df.y * df.y, df.z * df.z, df.w * df.w);
+    float s = cv_gate_dot(gw, d2);
+    if constexpr (LPV >= 2) s = cv_dpp_add(s, 0);
+    if constexpr (LPV >= 4) s = cv_dpp_add(s, 1);
+    if constexpr (LPV >= 8) s = cv_dpp_add(s, 2);
+    const float g1 = fmaxf(__builtin_fmaf(a.gA1, s, a.gB1), 0.f);
+    const float g = fmaxf(__builtin_fmaf(a.gA2, g1, a.gB2), 0.f) + 1.f;
+    ac.x = __builtin_fmaf(g, d2.x, ac.x); ac.y = __builtin_fmaf(g, d2.y, ac.y); ac.z = __builtin_fmaf(g, d2.z, ac.z); ac.w = __builtin_fmaf(g, d2.w, ac.w);
+  };
+  CvRay R = cv_ray(a.M[0], xf, yf);
+  CvProj P = cv_project_ray(a.M[0], R, dep[0], fw, fh, wp, C);
+  CvTaps TA, TB;
+  gather(P, 0, 0, TA, TA, true);
+  for (int v = 0; v < nsrc; ++v) {
+    const int vn = min(v + 1, nsrc - 1);  // past the last view: a harmless extra sample of the last view's first plane
+    const CvRay Rn = cv_ray(a.M[vn], xf, yf);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const CvProj Pn = b + 1 < NB ? cv_project_ray(a.M[v], R, dep[b + 1 < NB ? b + 1 : 0], fw, fh, wp, C) : cv_project_ray(a.M[vn], Rn, dep[0], fw, fh, wp, C);
+#pragma unroll
+      for (int jj = 0; jj < LPB; ++jj) {
+        const int j = b * LPB + jj;
+        CvTaps &cur = (j & 1) ? TB : TA, &nxt = (j & 1) ? TA : TB;
+        if (jj + 1 < LPB) gather(P, jj + 1, v, nxt, cur, false);
+        else gather(Pn, 0, b + 1 < NB ? v : vn, nxt, cur, b + 1 == NB);  // (the first plane of a view always gathers)
+        consume(acc[j], cur);
+      }
+      P = Pn;
+    }
+    R = Rn;
+  }
+#ifdef DR_PARITY_HOOKS
+  if ((a.abl & 2) && acc[0].x != 123.456f) return;
+#endif
+  if (live) {
+#pragma unroll
+    for (int j = 0; j < DCH; ++j) {
+      const float4 o4 = make_float4(acc[j].x * rcp_n, acc[j].y * rcp_n, acc[j].z * rcp_n, acc[j].w * rcp_n);
+      *reinterpret_cast<float4 *>(a.vol + cv_vol_index<C>(a, (size_t)(d0 + j) * h * w + (size_t)y * w + x, q * 4)) = o4;
+    }
   }
 }
 

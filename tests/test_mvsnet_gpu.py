@@ -552,9 +552,61 @@ def test_shared_setup_cost_volume_is_bit_identical(trained_blob, tmp_path, monke
             if old:
                 monkeypatch.delenv("DR_COSTVOL_V2")
         for (va, ka), (vb, kb) in zip(*vols):
-            assert ka.startswith("k_costvol3") and kb.startswith("k_costvol2"), (ka, kb)
+            # (since round 6 the view-aggregation model's volumes come from k_costvol5, the plain-variance model's still from k_costvol3)
+            assert ka.startswith("k_costvol5" if blob == trained_blob else "k_costvol3") and kb.startswith("k_costvol2"), (ka, kb)
             for a, b in zip(va, vb):
                 assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), np.abs(a - b).max()
+
+
+@pytest.mark.parametrize("views,dmin,dmax", [(7, 0.5, 5.0), (7, 0.01, 10.0), (3, 0.5, 5.0), (2, 0.3, 1.2), (5, 2.0, 40.0), (8, 0.5, 5.0)])
+def test_view_outer_cost_volume_is_bit_identical(trained_blob, monkeypatch, views, dmin, dmax, parity_hooks):
+    """k_costvol5 (round 6: view outer, the planes of a depth chunk inner, one float4 accumulator per plane in registers, the view's matrix
+    in scalar registers, the pixel's ray hoisted out of the plane loop) against k_costvol3 (plane outer, view inner, one accumulator):
+    per voxel the views are added in the same order with the same products, so the three cost volumes -- and everything behind them --
+    are equal bit for bit.  Depth ranges as in the LDS-staged kernel's test (samples behind the camera, outside every view, sub-pixel
+    steps); 1 to 7 source views; depth chunks of 4 planes (the product's choice) and of 8 (DR_CV_DCHUNK*); and the kernel's two A/B forms of
+    the parity build: every sample gathering its taps (DR_CV5_REUSE=0: the product skips a sample's gathers where its footprint is the
+    previous plane's and copies the taps), one-row and four-row workgroup tiles at every stage (DR_CV5_ROWS)."""
+    from synth import scene
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    variants = [(None, {}), ("8", {})]
+    if views in (7, 3):
+        variants += [(None, {"DR_CV5_REUSE": "0"}), (None, {"DR_CV5_ROWS": "1"}), ("8", {"DR_CV5_ROWS": "4"})]
+    for dch, extra in variants:
+        for s in (1, 2, 3):
+            if dch:
+                monkeypatch.setenv("DR_CV_DCHUNK%d" % s, dch)
+            else:
+                monkeypatch.delenv("DR_CV_DCHUNK%d" % s, raising=False)
+        vols = []
+        for old in (False, True):
+            for k in ("DR_CV5_REUSE", "DR_CV5_ROWS"):
+                monkeypatch.delenv(k, raising=False)
+            if old:
+                monkeypatch.setenv("DR_COSTVOL_V3", "1")
+            else:
+                monkeypatch.delenv("DR_COSTVOL_V3", raising=False)
+                for k, v in extra.items():
+                    monkeypatch.setenv(k, v)
+            m = DrMvsnet(trained_blob)
+            res = []
+            for (h, w) in ((96, 160), (64, 224), (256, 320)):
+                win = scene.make_window(h, w, views, seed=17)
+                m.upload(h, w, views, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), dmin, dmax, 2.5)
+                m.forward(1)
+                kern = {r["op"]: r["kernel"] for r in m.profile()}
+                res.append(([m.tensor("volume%d" % s).copy() for s in (1, 2, 3)], [kern["s%d.costvol" % s] for s in (1, 2, 3)], m.download().depth_dense.copy()))
+            vols.append(res)
+            m.close()
+        for k in ("DR_COSTVOL_V3", "DR_CV5_REUSE", "DR_CV5_ROWS"):
+            monkeypatch.delenv(k, raising=False)
+        for (va, ka, da), (vb, kb, db) in zip(*vols):
+            assert all(k.startswith("k_costvol5") for k in ka) and all(k.startswith("k_costvol3") for k in kb), (ka, kb)
+            assert all(k.endswith(",%s>" % (dch or "4")) for k in ka), ka
+            for a, b in zip(va, vb):
+                assert np.isfinite(a).all()
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (np.abs(a - b).max(), (a != b).mean())
+            assert np.array_equal(da.view(np.uint32), db.view(np.uint32))
 
 
 @pytest.mark.parametrize("views,dmin,dmax", [(7, 0.5, 5.0), (7, 0.01, 10.0), (3, 0.5, 5.0), (2, 0.3, 1.2), (5, 2.0, 40.0)])
@@ -569,6 +621,10 @@ def test_lds_staged_cost_volume_is_bit_identical(trained_blob, monkeypatch, view
     vols = []
     for old in (False, True):
         monkeypatch.setenv("DR_CV4_STAGES", "0" if old else "7")  # (k_costvol4 lives in the parity build: measured slower than k_costvol3)
+        if old:
+            monkeypatch.setenv("DR_COSTVOL_V3", "1")                # (the product's own sweep is k_costvol5 since round 6: compare with the kernel k_costvol4 was derived from)
+        else:
+            monkeypatch.delenv("DR_COSTVOL_V3", raising=False)
         monkeypatch.setenv("DR_CV4_SP8", "0" if views == 3 else "6")
         m = DrMvsnet(trained_blob)
         res = []
@@ -580,6 +636,7 @@ def test_lds_staged_cost_volume_is_bit_identical(trained_blob, monkeypatch, view
             res.append(([m.tensor("volume%d" % s).copy() for s in (1, 2, 3)], [kern["s%d.costvol" % s] for s in (1, 2, 3)], m.download().depth_dense.copy()))
         vols.append(res)
         m.close()
+    monkeypatch.delenv("DR_COSTVOL_V3", raising=False)
     for (va, ka, da), (vb, kb, db) in zip(*vols):
         assert all(k.startswith("k_costvol4") for k in ka) and all(k.startswith("k_costvol3") for k in kb), (ka, kb)
         for a, b in zip(va, vb):

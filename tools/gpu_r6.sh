@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round 5's GPU script: ONE parameterised entry point for every gpurun call (the r4 per-call scripts were folded into this form).
-#   tools/gpu_r5.sh <tag> <step> [<step> ...]       results under gpurun_out/<tag>_*
+# Round 6's GPU script (round 5's, carried on): ONE parameterised entry point for every gpurun call.
+#   tools/gpu_r6.sh <tag> <step> [<step> ...]       results under gpurun_out/<tag>_*
 # steps: fused_sweep fused_prio corun batch_proxy ops ab_front ab_head3 fn_quick engines ab_ops ab_tail ops_tail ops_prob cv_sweep loop_raycast bench_host tune tests tests_fast smoke bench bench_quick shipped pmc prof_seq prof_driver
-#   the round's closing evidence, in the order bench.py needs it:  tools/gpu_r5.sh final pmc tests smoke bench shipped prof_seq prof_driver
+#   the round's closing evidence, in the order bench.py needs it:  tools/gpu_r6.sh final pmc tests smoke bench shipped prof_seq prof_driver
 set -u
 cd "$(dirname "$0")/.."
 TAG=$1; shift
@@ -19,6 +19,23 @@ for step in "$@"; do
     corun)
       (cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 mfma_valu_corun.hip -o mfma_valu_corun 2>&1 | grep -E "error"; timeout 120 ./mfma_valu_corun) > $OUT/${TAG}_corun.txt 2>&1; cat $OUT/${TAG}_corun.txt ;;
     batch_proxy) timeout 900 python tools/exp_batch_proxy.py > $OUT/${TAG}_batch_proxy.txt 2>&1; tail -12 $OUT/${TAG}_batch_proxy.txt ;;
+    ab_costvol)  # k_costvol5 (product) against k_costvol3 (DR_COSTVOL_V3, parity build) and against its own A/B forms, headline shape and depth range 0.01 .. 10
+      export DR_MI355X_LIB=$PWD/tandem_amd/libdr_mi355x_hooks.so DR_OPS_RANGE=0.01,10
+      for r in 1 2; do
+        echo "k_costvol5 (chunks of 4 planes, footprint reuse, 4-row tiles at stage 3): $(timeout 300 python tools/profile_ops.py "costvol" 2>&1 | tail -1)"
+        echo "k_costvol5 one-row tiles everywhere: $(DR_CV5_ROWS=1 timeout 300 python tools/profile_ops.py "costvol" 2>&1 | tail -1)"
+        echo "k_costvol5 four-row tiles everywhere: $(DR_CV5_ROWS=4 timeout 300 python tools/profile_ops.py "costvol" 2>&1 | tail -1)"
+        echo "k_costvol5 chunks of 8 planes: $(DR_CV_DCHUNK1=8 DR_CV_DCHUNK2=8 DR_CV_DCHUNK3=8 timeout 300 python tools/profile_ops.py "costvol" 2>&1 | tail -1)"
+        echo "k_costvol5 without footprint reuse: $(DR_CV5_REUSE=0 timeout 300 python tools/profile_ops.py "costvol" 2>&1 | tail -1)"
+        echo "k_costvol3: $(DR_COSTVOL_V3=1 timeout 300 python tools/profile_ops.py "costvol" 2>&1 | tail -1)"
+      done | tee $OUT/${TAG}_costvol_ab.txt
+      DR_OPS_RANGE=0.5,5 bash -c 'echo "scene range 0.5 .. 5: k_costvol5: $(timeout 300 python tools/profile_ops.py costvol 2>&1 | tail -1)"; echo "scene range 0.5 .. 5: k_costvol3: $(DR_COSTVOL_V3=1 timeout 300 python tools/profile_ops.py costvol 2>&1 | tail -1)"' | tee -a $OUT/${TAG}_costvol_ab.txt
+      unset DR_MI355X_LIB DR_OPS_RANGE ;;
+    abl_costvol)  # where k_costvol5's time goes: ablations (parity build), depth chunks of 4, one-row tiles
+      export DR_MI355X_LIB=$PWD/tandem_amd/libdr_mi355x_hooks.so DR_OPS_RANGE=0.01,10 
+      for abl in 0 1 2 4 3 5 7; do echo "DR_CV5_ABL=$abl (1 no gathers, 2 no stores, 4 no tap arithmetic): $(DR_CV5_ABL=$abl timeout 300 python tools/profile_ops.py "costvol" 2>&1 | tail -1)"; done | tee $OUT/${TAG}_costvol_abl.txt
+      unset DR_MI355X_LIB DR_OPS_RANGE ;;
+    tests_cv) timeout 1200 python -m pytest tests/test_mvsnet_gpu.py -m gpu -x -q -k "cost_volume or golden" > $OUT/${TAG}_gpu_tests_cv.log 2>&1; tail -5 $OUT/${TAG}_gpu_tests_cv.log ;;
     tests) timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/${TAG}_gpu_tests.log 2>&1; tail -5 $OUT/${TAG}_gpu_tests.log ;;
     tests_fast) timeout 1200 python -m pytest tests -m gpu -x -q -k "${DR_TESTS_K:-mvsnet or conv}" > $OUT/${TAG}_gpu_tests_fast.log 2>&1; tail -5 $OUT/${TAG}_gpu_tests_fast.log ;;
     smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/${TAG}_smoke.txt 2>&1; tail -2 $OUT/${TAG}_smoke.txt ;;
@@ -88,7 +105,7 @@ PY
         python -c "import json; d=json.load(open('$OUT/${TAG}_bench_l$f.json')); print('fused=$f: value %.1f /s  ms_per_step %.3f  single_window %.3f ms' % (d['value'], d['ms_per_step'], d['single_window_ms']))"
       done | tee -a $OUT/${TAG}_launches_ops.txt ;;
     ops) timeout 600 python tools/profile_ops.py > $OUT/${TAG}_ops.txt 2>&1; tail -4 $OUT/${TAG}_ops.txt ;;
-    pmc)  # counters in their own passes (--kernel-trace only), strictly sequential kernels (one engine, side stream off) -> profiles/r05_pmc_traffic.json, stamped with this tree's source hash
+    pmc)  # counters in their own passes (--kernel-trace only), strictly sequential kernels (one engine, side stream off) -> profiles/r06_pmc_traffic.json, stamped with this tree's source hash
       export DR_MVS_NO_SIDE_STREAM=1
       S="--no-cpu --engines 1 --no-boundary --no-loop --no-tsdf-native"; A="--steps 3 --warmup 1 --tsdf-frames 60 $S"
       rm -rf $OUT/pm1 $OUT/pm2 $OUT/pm3 $OUT/pm4
@@ -97,8 +114,8 @@ PY
       timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pm3 -o pmc -- python bench.py $A > $OUT/pm3.log 2>&1
       timeout 600 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_WAIT_INST_LDS TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pm4 -o pmc -- python bench.py $A > $OUT/pm4.log 2>&1
       for i in 1 2 3 4; do d=$(dirname $(find $OUT/pm$i -name "pmc_counter_collection.csv" | head -1)); echo "== pass $i"; python tools/pmc_summary.py $d 2>&1 | grep -v "^at::\|elementwise\|    .*at::\|rocclr\|^void at" ; done > $OUT/${TAG}_pmc_summary.txt
-      python tools/pmc_to_json.py profiles/r05_pmc_traffic.json $(for i in 1 2 3; do dirname $(find $OUT/pm$i -name "pmc_counter_collection.csv" | head -1); done)
-      cp profiles/r05_pmc_traffic.json $OUT/; rm -rf $OUT/pm1 $OUT/pm2 $OUT/pm3 $OUT/pm4
+      python tools/pmc_to_json.py profiles/r06_pmc_traffic.json $(for i in 1 2 3; do dirname $(find $OUT/pm$i -name "pmc_counter_collection.csv" | head -1); done)
+      cp profiles/r06_pmc_traffic.json $OUT/; rm -rf $OUT/pm1 $OUT/pm2 $OUT/pm3 $OUT/pm4
       unset DR_MVS_NO_SIDE_STREAM ;;
     shipped) timeout 600 python bench.py --config shipped --steps 240 --no-tsdf --no-loop --no-cpu > $OUT/${TAG}_bench_shipped.json 2> $OUT/${TAG}_bench_shipped.err; head -c 300 $OUT/${TAG}_bench_shipped.json; echo ;;
     prof_seq)  # per-kernel durations without overlap: one engine, side stream off

@@ -7,7 +7,8 @@ from tandem_amd.dr_mvsnet import DrMvsnet
 H, W, V = 480, 640, 7
 m = DrMvsnet(os.path.join(ROOT, "weights", "tandem_va.tdmw"))
 win = scene.make_window(H, W, V, seed=0)
-m.upload(H, W, V, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), win["depth_min"], win["depth_max"], 10.0)
+dmin, dmax = (float(t) for t in os.environ["DR_OPS_RANGE"].split(",")) if os.environ.get("DR_OPS_RANGE") else (win["depth_min"], win["depth_max"])  # the headline runs 0.01,10
+m.upload(H, W, V, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), dmin, dmax, 10.0)
 m.forward(5)
 pat = re.compile(sys.argv[1] if len(sys.argv) > 1 else ".")
 rows = [m.profile() for _ in range(3)]
