@@ -243,7 +243,12 @@ def mvsnet_leg(args, rank, dev, world):
         res["pipeline"] = dict(gflop_per_depth_map=flops / 1e9, gb_per_depth_map=nbytes / 1e9,
                                tflops=flops / step_s / 1e12, frac_mfma=flops / step_s / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                                gbps=nbytes / step_s / 1e9, frac_hbm=nbytes / step_s / 1e9 / PEAK_HBM_GBPS,
-                               kernels={k: round(v["ms"], 4) for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])})
+                               kernels={k: round(v["ms"], 4) for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])},
+                               # every launch of one sequential forward against BOTH roofs: algorithmic flops / 157.3 TFLOP/s and
+                               # algorithmic bytes (the engine's layer-boundary model: inputs + outputs + weights of the launch) / 8 TB/s over its hipEvent span
+                               launches=[dict(op=r["op"], kernel=r["kernel"], ms=round(r["ms"], 4),
+                                              mfma_frac=round(r["flops"] / (r["ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 3) if r["ms"] > 0 else None,
+                                              hbm_frac=round(r["bytes"] / (r["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS, 3) if r["ms"] > 0 else None) for r in prof])
         res["roofline"]["traffic_source"] = pmc_profile_state()
         # the same window at the scene's own depth range (synth/scene.py: 0.5 .. 5.0 m, what the parity tests run): the FLOPs do
         # not change with the range, the gather footprint of the cost-volume kernels does
@@ -256,6 +261,30 @@ def mvsnet_leg(args, rank, dev, world):
             res["cpu_baseline"] = mvsnet_cpu_baseline(win, blob)
     m.close()
     return res
+
+
+def golden_parity(dev):
+    """Self-check printed in the line: the committed headline fixture -- the REFERENCE model's own outputs at 640x480x7,
+    planes (48,32,8), depth range 0.01 .. 10 (tests/golden/mvsnet_v7_480x640_headline.npz, written by oracle/gen_golden.py from the imported
+    reference) -- through CallAsync / GetResult of the library that is about to be timed, with the error figures tests/test_mvsnet_gpu.py::compare
+    bounds (mean 1e-4 m, max 5e-3 m, mask flips 2e-3).  A data file is read; nothing under oracle/ runs."""
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    path = os.path.join(ROOT, "tests", "golden", "mvsnet_v7_480x640_headline.npz")
+    if not os.path.isfile(path) or PLANES != (48, 32, 8):
+        return None
+    g = np.load(path)
+    bgrs = [np.ascontiguousarray(b) for b in g["bgrs"]]
+    m = DrMvsnet(model_blob(), device=dev)
+    m.CallAsync(bgrs[0].shape[0], bgrs[0].shape[1], len(bgrs), int(g["ref_index"]), bgrs, g["K"], list(g["c2ws"]), float(g["depth_min"]), float(g["depth_max"]), float(g["discard"]))
+    out = m.GetResult()
+    m.close()
+    err = np.abs(out.depth_dense - g["ref_s3_depth_dense"])
+    cerr = np.abs(out.confidence_dense - g["ref_s3_confidence_dense"])
+    flips = float(((out.depth == 0) != (g["ref_s3_depth"] == 0)).mean())
+    ok = bool(err.mean() < 1e-4 and err.max() < 5e-3 and flips < 2e-3 and cerr.mean() < 1e-4)
+    return dict(fixture="tests/golden/mvsnet_v7_480x640_headline.npz (outputs of the reference's own CvaMVSNet, imported from /root/reference by oracle/gen_golden.py)",
+                mean_abs_err=float(err.mean()), max_err=float(err.max()), unit="m", confidence_mean_abs_err=float(cerr.mean()), mask_flips=flips,
+                bounds=dict(mean_abs_err=1e-4, max_err=5e-3, mask_flips=2e-3), within_bounds=ok)
 
 
 def mvsnet_cpu_baseline(win, blob):
@@ -283,12 +312,14 @@ def mvsnet_cpu_baseline(win, blob):
         from oracle import mvsnet_oracle as O
         w = O.Weights(meta, tens)
         run = lambda: O.forward(w, win["bgrs"], win["K"], win["c2ws"], win["ref_index"], DEPTH_MIN, DEPTH_MAX, DISCARD)
+    pinned_by = ("tests/test_oracle_mvsnet.py::test_oracle_reproduces_reference_bit_exactly (the port is bit-identical to the imported reference model on the eight committed "
+                 "fixtures of tests/golden/, this window's shape and depth range among them: mvsnet_v7_480x640_headline.npz)")
     run(); run()  # two warm-ups
     times = []
     while len(times) < 5 and sum(times) < 90.0:  # >= 5 timed forwards (about 11 s each on the GPU box's host)
         t0 = time.perf_counter(); run(); times.append(time.perf_counter() - t0)
     med = sorted(times)[len(times) // 2]
-    return dict(value=1.0 / med, unit="depth-maps/s", cores=torch.get_num_threads(), physical_cores=phys, logical_cpus=logical, kind=kind,
+    return dict(value=1.0 / med, unit="depth-maps/s", cores=torch.get_num_threads(), physical_cores=phys, logical_cpus=logical, kind=kind, pinned_by=pinned_by,
                 sample="%d timed forwards of the same %dx%dx7-view (%d,%d,%d) window (depth range %g .. %g) after 2 warm-ups, torch CPU fp32, %d threads; median %.2f s, best %.2f s"
                        % ((len(times), W, H) + PLANES + (DEPTH_MIN, DEPTH_MAX, torch.get_num_threads(), med, min(times))))
 
@@ -331,41 +362,6 @@ def shipped_leg(args, dev):
                 single_engine=dict(ms_per_depth_map=lat, depth_maps_per_s=1e3 / lat, forwards=n1),
                 engines_3=dict(depth_maps_per_s=3 * per / dt, windows=3 * per),
                 gflop_per_depth_map=flops / 1e9, reference_published_fps=4.96)
-
-
-def bf16x3_leg(args, dev):
-    """The opt-in precision mode DR_CONV_BF16X3=1 (csrc/conv_bf3.h): every convolution with Cin % 8 == 0 on the bf16 matrix cores, both
-    operands split into two bf16 terms, the three leading products accumulated in fp32.  Operands then carry 16 mantissa bits, not 24:
-    the depth maps stay inside the bounds the fp32 path is held to (tests: test_bf16x3_mode_stays_inside_the_fp32_bounds), but this is
-    NOT fp32 arithmetic -- reported here as its own object, never as `value` / `dtype`."""
-    import threading
-    from synth import scene
-    from tandem_amd.dr_mvsnet import DrMvsnet
-    os.environ["DR_CONV_BF16X3"] = "1"  # read when an engine plans its layers
-    try:
-        engines = []
-        for e in range(3):
-            win = scene.make_window(H, W, V, seed=80 + e)
-            m = DrMvsnet(model_blob(), device=dev)
-            m.upload(H, W, V, win["ref_index"], win["bgrs"], win["K"], list(win["c2ws"]), DEPTH_MIN, DEPTH_MAX, DISCARD)
-            m.forward(5)
-            engines.append(m)
-    finally:
-        del os.environ["DR_CONV_BF16X3"]
-    n1 = max(20, min(100, args.steps))
-    lat = engines[0].forward(n1) / n1
-    per = max(20, min(100, args.steps // 3))
-    threads = [threading.Thread(target=lambda m=m: m.forward(per)) for m in engines]
-    t0 = time.perf_counter()
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    dt = time.perf_counter() - t0
-    for m in engines:
-        m.close()
-    return dict(mode="DR_CONV_BF16X3=1: convolutions on bf16 MFMA with two-term split operands (3 products, fp32 accumulation); operand precision 16 bits",
-                dtype="bf16x3 (not f32)", single_window_ms=lat, depth_maps_per_s_3_engines=3 * per / dt, windows=3 * per)
 
 
 def boundary_leg(args, dev):
@@ -417,6 +413,56 @@ def boundary_leg(args, dev):
     return out
 
 
+def raycast_steps(k):
+    """Mean samples per ray over the first k frames of the TSDF loop, counted by the parity build's measuring launch of k_raycast2 (tools/raycast_stats.py,
+    a subprocess: the product library has no counting kernel).  None where the parity build is absent."""
+    import re
+    import subprocess
+    hooks = os.path.join(ROOT, "tandem_amd", "libdr_mi355x_hooks.so")
+    if not os.path.isfile(hooks):
+        return None
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "raycast_stats.py"), str(k)], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, DR_MI355X_LIB=hooks, DR_RAYCAST_STATS="1"))
+        it = [float(x) for x in re.findall(r"iterations/lane ([0-9.]+)", r.stderr)]
+        wl = [float(x) for x in re.findall(r"mean wave-longest ([0-9.]+)", r.stderr)]
+        return dict(frames=len(it), samples_per_ray=sum(it) / len(it), wave_longest_ray=sum(wl) / len(wl)) if it else None
+    except Exception as e:  # noqa: BLE001 -- reporting only
+        return dict(error=str(e)[:160])
+
+
+def tsdf_boundary(fr, poses, opt, dev, hook_stats):
+    """The same frames through the operator API the way TANDEM and the reference's own driver call it (dr_debug_example.cpp:121,147,151;
+    tandem_backend.cpp:166-177): HOST buffers into IntegrateScanAsync, RenderAsync from the frame's pose, GetRenderResult (which host-synchronises
+    before the next scan can be queued -- the allocation of scan k + 1 therefore cannot overlap the ray-cast of scan k as it does in the
+    device-resident hook).  Wall clock over the whole loop, map starting empty; the final map must equal the hook run's (block and update counts)."""
+    from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
+    n = len(poses)
+    hb, hd = fr["bgr"].cpu().numpy(), fr["depth"].cpu().numpy()
+    f = DrFusion(DrFusionOptions(**opt), device=dev)
+    for i in range(2):  # pinned staging, streams
+        f.IntegrateScanAsync(hb[i], hd[i], poses[i]); f.RenderAsync([poses[i]]); f.GetRenderResult(copy=False)
+    f.close()
+    f = DrFusion(DrFusionOptions(**opt), device=dev)
+    t_int = t_ren = t_get = 0.0
+    t0 = time.perf_counter()
+    for i in range(n):
+        a = time.perf_counter(); f.IntegrateScanAsync(hb[i], hd[i], poses[i])
+        b = time.perf_counter(); f.RenderAsync([poses[i]])
+        c = time.perf_counter(); f.GetRenderResult(copy=False)
+        d = time.perf_counter()
+        t_int += b - a; t_ren += c - b; t_get += d - c
+    t1 = time.perf_counter()
+    st = f.stats()
+    f.close()
+    return dict(ms_per_frame=1e3 * (t1 - t0) / n, frames_per_s=n / (t1 - t0), value=st["updated_total"] / (t1 - t0), unit="voxels/s", frames=n,
+                host_ms_per_frame=dict(IntegrateScanAsync=1e3 * t_int / n, RenderAsync=1e3 * t_ren / n, GetRenderResult=1e3 * t_get / n),
+                same_map_as_hook_run=bool(st["blocks"] == hook_stats["blocks"] and st["updated_total"] == hook_stats["updated_total"]),
+                note="IntegrateScanAsync(host bgr, host depth, pose) -> RenderAsync({pose}) -> GetRenderResult per frame through the C ABI (ctypes mirror of "
+                     "dr_fusion.h), PCIe-inclusive (2.15 MB up, 2.15 MB down per frame), wall clock; the device-resident figure beside it comes from the "
+                     "measuring hook drf_bench_sequence, whose allocate(k+1) / ray-cast(k) overlap this call order cannot reach")
+
+
 def tsdf_leg(args, rank, dev, world):
     """BASELINE configs[3] as dr_debug_example.cpp:78-162 runs it: `--tsdf-frames` DISTINCT depth maps from a camera loop
     through an analytic room (synth/room.py, generated straight into HBM), per frame allocate + integrate and one
@@ -432,6 +478,8 @@ def tsdf_leg(args, rank, dev, world):
     opt = dict(voxel_size=0.005, num_buckets=500000, bucket_size=10, num_blocks=2500000, block_size=8, max_sdf_weight=64,
                truncation_distance=0.02, max_sensor_depth=10.0, min_sensor_depth=0.1, num_render_streams=1,
                fx=fr["fx"], fy=fr["fy"], cx=fr["cx"], cy=fr["cy"], height=H, width=W)
+    if args.tsdf_blocks > 0:  # SURVEY 8(d)'s pool size (>= 16 M blocks = 64 GB of voxels) instead of the default 2.5 M
+        opt.update(num_blocks=args.tsdf_blocks, num_buckets=max(500000, args.tsdf_blocks // 5))
     torch.cuda.synchronize()
     warm = DrFusion(DrFusionOptions(**dict(opt, num_blocks=400000)), device=dev)  # loads the kernels; its map is thrown away
     warm.bench_sequence(fr["bgr"].data_ptr(), fr["depth"].data_ptr(), poses[:2], render=True)
@@ -454,9 +502,11 @@ def tsdf_leg(args, rank, dev, world):
                                         render_d2h=ms["d2h"] / n),  # hipEvents on the engine's streams; `integrate` brackets k_integrate alone
                integrate_only_voxels_per_s=vox / (ms["integrate"] * 1e-3),
                config=dict(workload="%d distinct synthetic 640x480 depth maps (camera loop through a 6x4x3 m room with a sphere, 2.5 %% invalid "
-                                    "pixels) fused into an initially empty 5 mm hashed voxel grid (truncation 20 mm; num_blocks = 2.5 M = 10 GB of voxels, NOT the >= 16 M of SURVEY 8d: "
-                                    "the loop allocates 378 k blocks, and bump allocation makes the pool size irrelevant to every kernel -- a 16 M pool only adds 55 GB of hipMalloc): per frame "
-                                    "allocate + integrate + one ray-cast from the frame's pose incl. D2H of the render; frames resident in HBM" % n))
+                                    "pixels) fused into an initially empty 5 mm hashed voxel grid (truncation 20 mm; num_blocks = %.1f M = %.0f GB of voxels; SURVEY 8d asks for >= 16 M: "
+                                    "the loop allocates 378 k blocks and bump allocation makes the pool size irrelevant to every kernel -- shown once with --tsdf-blocks 16000000, "
+                                    "profiles/r06_tsdf_16m_blocks.json): per frame allocate + integrate + one ray-cast from the frame's pose incl. D2H of the render; frames resident in HBM; "
+                                    "THIS figure is produced by the measuring hook drf_bench_sequence (device pointers in, allocate(k+1) beside ray-cast(k)); the same frames through "
+                                    "the public call order are `boundary` below" % (n, opt["num_blocks"] / 1e6, opt["num_blocks"] * 4096 / 1e9)))
     if rank == 0:
         visited = f.visited_blocks()
         # what k_integrate really moves: every visible block is READ whole (4 KB, updated or not), every updated voxel is written (8 B)
@@ -468,6 +518,22 @@ def tsdf_leg(args, rank, dev, world):
         res["roofline"] = dict(bound="hbm", kernel="k_integrate", avg_launch_ms=ms["integrate"] / n, bytes_per_launch=16.0 * vox / n,
                                achieved=ach, peak=PEAK_HBM_GBPS, unit="GB/s", frac=ach / PEAK_HBM_GBPS, traffic=pmc_traffic("k_integrate", fetch="raw"),
                                traffic_if_fetch_doubled=pmc_traffic("k_integrate"))
+        # the ray-cast (74 % of the frame) against SURVEY 8(d)'s own lower bound: 7 B written + steps x 8 corners x 8 B read per output pixel, with the
+        # measured step count; and against what the counters say actually left the caches
+        rs = None if args.no_tsdf_boundary else raycast_steps(min(n, 200))
+        rc_ms = ms["raycast"] / n
+        rc = dict(bound="hbm", kernel="k_raycast2", avg_launch_ms=rc_ms, steps=rs, peak=PEAK_HBM_GBPS, unit="GB/s",
+                  traffic=pmc_traffic("k_raycast2", fetch="raw"), traffic_if_fetch_doubled=pmc_traffic("k_raycast2"))
+        if rs and "samples_per_ray" in rs:
+            lb = H * W * (7.0 + rs["samples_per_ray"] * 64.0)
+            rc.update(bytes_per_launch=lb, achieved=lb / (rc_ms * 1e-3) / 1e9, frac=lb / (rc_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                      note="bytes_per_launch = pixels x (7 + samples_per_ray x 8 corners x 8 B): SURVEY 8(d)'s lower bound with the measured step count; these are "
+                           "requests the caches serve (every sample of a ray re-reads 7 of the 8 corners' lines of its neighbour), `traffic` is what reached the memory side")
+        if rc["traffic"]:
+            rc["hbm_frac_of_counter_traffic"] = rc["traffic"] / (rc_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS
+        res["roofline_raycast"] = rc
+        if world == 1 and not args.no_tsdf_boundary:
+            res["boundary"] = tsdf_boundary(fr, poses, opt, dev, st)
         # marching cubes (DrFusion::ExtractMeshAsync + GetMeshSync) of the fused map over TANDEM's (-5..5 m)^3 box
         # (tandem_backend.cpp:80-81): device time = until the triangle count is known, total adds the D2H copy
         lo, hi = (-5.0, -5.0, -5.0), (5.0, 5.0, 5.0)
@@ -478,7 +544,8 @@ def tsdf_leg(args, rank, dev, world):
                            lattice="2000^3 cells at 5 mm, visited per allocated block")
         if world == 1 and not args.no_cpu:
             k = min(n, 24)
-            res["cpu_baseline"] = tsdf_cpu_baseline([(fr["bgr"][i].cpu().numpy(), fr["depth"][i].cpu().numpy(), poses[i]) for i in range(k)], opt)
+            res["cpu_baseline"] = tsdf_cpu_baseline([(fr["bgr"][i].cpu().numpy(), fr["depth"][i].cpu().numpy(), poses[i]) for i in range(k)], opt, dev)
+            res["parity"] = res["cpu_baseline"].pop("parity", None)
     f.close()
     if rank == 0 and not args.no_tsdf_native:  # the reference's native setting (FullSystem.cpp:260,266: 1 cm voxels, 4 cm truncation), same frames
         g = DrFusion(DrFusionOptions(**dict(opt, voxel_size=0.01, truncation_distance=0.04, num_blocks=600000)), device=dev)
@@ -535,6 +602,24 @@ def tandem_loop_leg(args, dev):
                 continue
             out[name] = json.loads(r.stdout.strip().splitlines()[-1])
             out[name]["depth_range"] = [0.01, dmax]
+            if name == "640x480_10mm" and exe.endswith("tandem_backend_run"):
+                # the window SLIDES as TANDEM's does (six of a window's seven images were in the previous one, one is new), first without, then with the
+                # key-frame feature cache (drm_set_feature_cache: FeatureNet on the new image only).  Its own leg: the legs above re-send one window and
+                # would hit the cache with every image -- they never enable it, and neither does anything that feeds `value` / `single_window_ms`.
+                sl = {}
+                for cache in (0, 16, 0, 16, 0, 16):
+                    r = subprocess.run([exe, blob, sample, str(3 * args.loop_keyframes), vs, "0", "1", "1", str(cache)], capture_output=True, text=True, timeout=900, env=env)
+                    if r.returncode != 0:
+                        sl["error"] = (r.stdout + r.stderr)[-500:]
+                        break
+                    d = json.loads(r.stdout.strip().splitlines()[-1])
+                    sl.setdefault("cache_%d" % cache, []).append(dict(keyframes_per_s=d["keyframes_per_s"], ms_per_keyframe=d["ms_per_keyframe"], mean_ms=d["mean_ms"]))
+                if "error" not in sl:
+                    off, on = (sorted(x["keyframes_per_s"] for x in sl["cache_%d" % c])[1] for c in (0, 16))  # the median of three
+                    sl.update(keyframes_per_s_cache_off=off, keyframes_per_s_cache_on=on, speedup=on / off,
+                              note="1 cm voxels (TANDEM's setting), sliding synthetic sequence: each key frame drops the oldest image of the window and adds a new one; "
+                                   "three alternating runs of %d key frames each, the median reported; feature cache of 16 key frames" % (3 * args.loop_keyframes))
+                out["sliding_window"] = sl
     out["note"] = ("tandem_backend.cpp's own call order (the reference's file, unchanged, where oracle/_ref/tandem_backend_run exists); depth network of "
                    "keyframe k overlaps fusion + ray-cast of keyframe k-1; (48,32,8) planes, discard 10 %, dense tracking render on; TANDEM's own setting is 10 mm")
     return out
@@ -668,12 +753,16 @@ def view_shard_leg(args, rank, dev, world):
                 note="one window sharded over the ranks; 3 fp32 volume reductions (RCCL) per depth map")
 
 
-def tsdf_cpu_baseline(scans, opt):
+def tsdf_cpu_baseline(scans, opt, dev=0):
     """the C restatement on one core, and its OpenMP-over-blocks build (integration parallel over the
-    allocated blocks, allocation serial) on the physical cores of this box -- same frames, bounded sample."""
+    allocated blocks, allocation serial) on the physical cores of this box -- same frames, bounded sample.  The state the single-core run
+    ends with is not thrown away: the engine fuses the same frames through IntegrateScanAsync and the two maps are compared
+    block for block, bit for bit (`parity`)."""
     from oracle.tsdf_oracle import TsdfOracle
     phys, _ = host_cores()
     out = {}
+    parity = None
+    mism_free = lambda st: st["mismatches"] == 0  # noqa: E731 -- (an OpenMP run whose blocks raced is void and is not a checker either)
     for omp in (False, True):
         if omp:
             os.environ["OMP_NUM_THREADS"] = str(phys)
@@ -691,11 +780,22 @@ def tsdf_cpu_baseline(scans, opt):
         st = o.stats()
         key = "openmp" if omp else "single"
         out[key] = dict(value=st["updated_total"] / t, frames=n, seconds=t, cores=phys if omp else 1, mismatches=st["mismatches"])
+        if mism_free(st) and (parity is None or n > parity["tsdf_frames_equal"]):  # the run that got furthest in its time budget is the one compared
+            from tandem_amd.dr_fusion import DrFusion, DrFusionOptions
+            f = DrFusion(DrFusionOptions(**dict(opt, num_blocks=600000)), device=dev)
+            for bgr, depth, pose in scans[:n]:
+                f.IntegrateScanAsync(bgr, depth, pose); f.RenderAsync([pose]); f.GetRenderResult(copy=False)
+            a, b = f.export_blocks(), o.export_blocks()
+            f.close()
+            equal = a.keys() == b.keys() and all(np.array_equal(a[k], b[k]) for k in a)
+            parity = dict(tsdf_frames_equal=n if equal else 0, blocks=len(a), oracle_blocks=len(b), voxel_state="bit-exact" if equal else "DIFFERS",
+                          checker="oracle/tsdf_oracle.c%s (pinned to the reference's own sources compiled for the host by tests/test_ref_fusion.py), the first %d frames of this "
+                                  "leg's workload through IntegrateScanAsync, maps compared block for block" % (", OpenMP build" if omp else "", n))
     best = out.get("openmp", out["single"])
     if best is not out["single"] and best["mismatches"] != 0:  # blocks were NOT independent in the parallel run: its figure is void
         out["openmp"]["void"] = "round-trip mismatches != 0: the OpenMP integration raced; single-core figure reported"
         best = out["single"]
-    return dict(value=best["value"], unit="voxels/s", cores=best["cores"], kind="port", single_core=out["single"], openmp=out.get("openmp"),
+    return dict(value=best["value"], unit="voxels/s", cores=best["cores"], kind="port", single_core=out["single"], openmp=out.get("openmp"), parity=parity,
                 sample="allocate + integrate of the first %d of the same frames, C restatement (oracle/tsdf_oracle.c, pinned to the reference build by "
                        "tests/test_ref_fusion.py): one core, and integration parallel over blocks with OpenMP on %d physical cores (allocation serial)"
                        % (best["frames"], phys))
@@ -726,6 +826,8 @@ def main():
     ap.add_argument("--no-tsdf-native", action="store_true", help="skip the extra TSDF run at the reference's native 1 cm / 4 cm setting (profiling runs: keeps "
                                                                    "per-kernel averages to the 5 mm loop the roofline is quoted on)")
     ap.add_argument("--no-view-shard", action="store_true", help="N > 1 only: skip the view-sharded (configs[2]) leg")
+    ap.add_argument("--no-tsdf-boundary", action="store_true", help="skip the TSDF leg's API-level run (host buffers through IntegrateScanAsync / RenderAsync / GetRenderResult) and the ray-cast step count")
+    ap.add_argument("--tsdf-blocks", type=int, default=0, help="voxel-block pool of the TSDF leg (0: 2.5 M = 10 GB; SURVEY 8d's configuration is 16000000 = 64 GB)")
     ap.add_argument("--config", choices=["headline", "shipped"], default="headline",
                     help="headline: BASELINE.json's metric configuration, 640x480x7 views, planes (48,32,8).  shipped: the model TANDEM exports and runs "
                          "(tandem_512x320: 320x512x7 views, planes (48,4,4)); every leg of the line (value, roofline, cpu_baseline, boundary) is then on that shape")
@@ -764,13 +866,13 @@ def main():
     torch.cuda.set_device(local_rank)
     replicas.init("gloo" if one_dev else "nccl", local_rank)
 
+    par = golden_parity(local_rank) if (rank == 0 and args.config == "headline") else None  # before anything is timed
     mv = mvsnet_leg(args, rank, local_rank, world)
     ts = None if args.no_tsdf else tsdf_leg(args, rank, local_rank, world)
     tr = tracker_leg(args, local_rank) if (rank == 0 and not args.no_tsdf) else None
     bd = boundary_leg(args, local_rank) if (rank == 0 and world == 1 and not args.no_boundary) else None
     lp = tandem_loop_leg(args, local_rank) if (rank == 0 and world == 1 and not args.no_loop) else None
     sh = shipped_leg(args, local_rank) if (rank == 0 and world == 1 and not args.no_boundary) else None
-    b3 = bf16x3_leg(args, local_rank) if (rank == 0 and world == 1 and not args.no_boundary) else None
     vs, vs_hung = None, False
     if world > 1 and not args.no_view_shard:
         # The sharded leg is the only part of this program with a data-path collective.  It runs under a watchdog: if a
@@ -816,14 +918,14 @@ def main():
             out["boundary_single_engine_ms"] = bd["engines_1"]["ms_per_depth_map_per_engine"]
             out["boundary_single_engine_depth_maps_per_s"] = bd["engines_1"]["depth_maps_per_s"]
             out["boundary_pinned_single_engine_ms"] = bd["engines_1_pinned"]["ms_per_depth_map_per_engine"]
+        if par is not None:
+            out["parity"] = par
         if ts is not None:
             out["tsdf"] = ts
         if bd is not None:
             out["boundary"] = bd
         if sh is not None:
             out["shipped_model"] = sh
-        if b3 is not None:
-            out["bf16x3_mode"] = b3
         if lp is not None:
             out["tandem_loop"] = lp
         if tr is not None:

@@ -72,6 +72,18 @@ int drm_get_result_view(drm_t *h, const float **depth, const float **confidence,
 void *drm_host_alloc(size_t bytes);
 void drm_host_free(void *p);
 
+/* Extension (no reference counterpart): the KEY-FRAME FEATURE CACHE.  TANDEM's sliding window re-sends six of its seven images with every key frame
+ * (ref: tandem/src/FullSystem/FullSystem.cpp:1162-1171 pushes frameHessians[i]->image_bgr for every active key frame), and FeatureNet
+ * (ref: cva_mvsnet/models/module.py:496-531) is per image.  drm_set_feature_cache(h, capacity) makes the engine keep the three feature maps (and the
+ * u8 image) of the last `capacity` images (0 = off, the default; capacity must exceed the window's view count): a window of which at most one image
+ * is new runs FeatureNet on that one view.  A hit is found by a 128-bit key over a sample of the image and made exact on the device: every uploaded
+ * image is compared byte for byte with the cached copy, and a difference drops the cache and repeats the window without it before a result leaves the
+ * engine.  Results are bit-identical with the cache on and off.  Call it before the first window; changing it on a configured engine re-plans the
+ * engine (upload the window again).  drm_feature_cache_stats: out[0] views answered by the cache, [1] views computed, [2] windows that took the batch
+ * path, [3] key collisions caught by the device compare, [4] 1 if the single-view plan exists for the current window shape, [5] entries. */
+int drm_set_feature_cache(drm_t *h, int capacity);
+int drm_feature_cache_stats(drm_t *h, uint64_t out[6]);
+
 /* --- device-resident / measurement / introspection hooks (no reference counterpart) --- */
 /* Upload a window (same arguments as drm_call_async) and keep it resident in HBM. Synchronous. */
 int drm_upload(drm_t *h, int height, int width, int view_num, int ref_index, const uint8_t *const *bgrs,

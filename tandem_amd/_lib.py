@@ -104,6 +104,8 @@ SIGNATURES = {
     "dr_memcpy_d2d": (C.c_int, [vp, vp, C.c_size_t]),
     "dr_memcpy_h2d": (C.c_int, [vp, vp, C.c_size_t]),
     "dr_memcpy_d2h": (C.c_int, [vp, vp, C.c_size_t]),
+    "drm_set_feature_cache": (C.c_int, [vp, C.c_int]),
+    "drm_feature_cache_stats": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "drf_bench_sequence": (C.c_int, [vp, vp, vp, f32p, C.c_int, C.c_int, f32p]),
     "drf_visited_blocks": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "drf_bench_render_host": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp)]),

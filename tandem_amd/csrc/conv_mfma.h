@@ -539,7 +539,9 @@ __global__ __launch_bounds__(kConvThreads, DR_KCONV_MIN_WAVES(CT, FZ)) void k_co
   conv_epilogue<CT, PT>(a, cls, acc, scv, biv, wave, j, g, ct0, pz0, py0, px0);
 }
 
-#include "conv_bf3.h"  // k_conv_b: k_conv on the bf16 matrix cores with three-term split operands (opt-in)
+#ifdef DR_PARITY_HOOKS  // the bf16 x 3 precision mode is not fp32 arithmetic and never the product's: its kernel is built into the parity library only
+#include "conv_bf3.h"  // k_conv_b: k_conv on the bf16 matrix cores with three-term split operands (DR_CONV_BF16X3=1)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // k_conv_a: the same implicit GEMM as a PERSISTENT workgroup whose staging is asynchronous.
@@ -834,7 +836,7 @@ inline std::vector<DimTaps> axis_classes_unpruned(int k, int s, bool transposed,
 // Winograd forms are written for exactly three y taps)
 inline std::vector<DimTaps> axis_classes(int k, int s, bool transposed, int in_size, bool split = false, bool prune = false) {
   std::vector<DimTaps> r = axis_classes_unpruned(k, s, transposed, in_size, split);
-  if (prune && !getenv("DR_CONV_NO_TAP_PRUNE"))
+  if (prune && !hook_env("DR_CONV_NO_TAP_PRUNE"))
     for (DimTaps &d : r) prune_taps(d, in_size);
   return r;
 }
@@ -991,7 +993,7 @@ inline size_t conv_a_slots(int np, int ci) { return (size_t)cdiv(((np + 1) & ~1)
 // useful).  Default by measurement at 640x480 (profiles/r03_experiments.txt): conv11 (Cout 8) 0.076 / 0.073 / 0.126 ms, conv9 (Cout 16)
 // 0.039 / 0.030 / 0.034, conv7 (Cout 32) 0.0265 / 0.0233 / 0.0221 for forms 0 / 1 / 2.  DR_DECONV_FORM overrides (A/B hook).
 inline int conv_deconv_form(int Cout) {
-  if (const char *e = getenv("DR_DECONV_FORM")) return std::max(0, std::min(2, atoi(e)));
+  if (const char *e = hook_env("DR_DECONV_FORM")) return std::max(0, std::min(2, atoi(e)));
   return Cout >= 32 ? 2 : 1;
 }
 // which kernel family the planner may use: 0 = k_conv only, 1 = k_conv_a only (falls back to k_conv when no async plan
@@ -999,7 +1001,7 @@ inline int conv_deconv_form(int Cout) {
 // Opt-in precision mode (DR_CONV_BF16X3=1): every layer with Cin % 8 == 0 runs on k_conv_b -- k_conv's data flow on the bf16 matrix cores
 // with both operands split into two bf16 terms and the three leading products accumulated in fp32 (conv_bf3.h has the numerics).
 inline int conv_bf3_policy() {
-  const char *e = getenv("DR_CONV_BF16X3");
+  const char *e = hook_env("DR_CONV_BF16X3");
   return e && atoi(e) > 0 ? 1 : 0;
 }
 inline unsigned short bf16_rne(float f) {  // round to nearest even, as v_cvt_pk_bf16_f32 does
@@ -1132,7 +1134,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   }
   // k_conv_m: the stride-1 3x3 / 3x3x3 layers on the marching producer/consumer kernel (conv_march.h)
   // (a fused FeatureNet skip runs on it in exactly one form: 8-channel source, 32 -> 8 XPAIR 3x3 layer, producers compute the tile)
-  const bool march_fz_ok = !fz || (fz->cin == 8 && L.Cin == 32 && L.kd == 1 && mode == CONV_XPAIR && !getenv("DR_FZ_NO_MARCH"));
+  const bool march_fz_ok = !fz || (fz->cin == 8 && L.Cin == 32 && L.kd == 1 && mode == CONV_XPAIR && !hook_env("DR_FZ_NO_MARCH"));
   const int march_policy = (march_fz_ok && !bf3) ? conv_march_policy() : 0;
   const bool march_ok = march_policy >= 1 && ncls == 1 && !L.transposed && !L.up2 && mode != CONV_X8 && L.kh == 3 && L.kw == 3 && (L.kd == 1 || L.kd == 3) &&
                         (int)cz[0].t.size() == L.kd &&  // (a depth axis with pruned taps -- extent 1 or 2 -- stays on the tile kernels)
@@ -1469,7 +1471,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   cl.bf3 = bf3 ? 1 : 0;
   a.zero16 = nullptr; a.a_slots = 0; a.a_wbufs = 1;
   // k_conv with pipelined passes (see the kernel): small multi-pass layers on the one-position-tile instances whose tile is at most 6 loads per lane
-  if (ASYNC == 0 && !bf3 && !fz && PT == 1 && CT <= 2 && npass >= 2 && (size_t)TZI * TYI * TXI * (CI / 4) <= 6 * kConvThreads && !getenv("DR_CONV_NO_PIPE") &&
+  if (ASYNC == 0 && !bf3 && !fz && PT == 1 && CT <= 2 && npass >= 2 && (size_t)TZI * TYI * TXI * (CI / 4) <= 6 * kConvThreads && !hook_env("DR_CONV_NO_PIPE") &&
       cl.lds_bytes + (size_t)nu_max * CT * 1024 <= kConvMaxLds) {
     a.a_wbufs = 2;
     cl.lds_bytes += (size_t)nu_max * CT * 1024;
@@ -1525,7 +1527,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
     m.inHp = rm ? 1 : a.inH;
     m.err = arena.err_flag;
     m.depth = rm ? 3 : 2;  // loads each producer wave keeps in flight (rows are small and steps short: one more)
-    if (const char *e = getenv("DR_MARCH_PDEPTH")) m.depth = std::max(1, std::min(4, atoi(e)));  // A/B hook
+    if (const char *e = hook_env("DR_MARCH_PDEPTH")) m.depth = std::max(1, std::min(4, atoi(e)));  // A/B hook
     cl.lds_bytes = ms.lds_bytes;
     cl.grid = dim3(ms.grid, 1, CTtot / CT);
   }
@@ -1550,12 +1552,14 @@ inline void launch_conv_inst(const ConvLaunch &c, hipStream_t st) {
   conv_allow_big_lds(reinterpret_cast<const void *>(&k_conv<CI, CT, PT, FZ>), done, c.lds_bytes);
   hipLaunchKernelGGL((k_conv<CI, CT, PT, FZ>), c.grid, dim3(kConvThreads), c.lds_bytes, st, c.args);
 }
+#ifdef DR_PARITY_HOOKS
 template <int CI, int CT, int PT>
 inline void launch_conv_b_inst(const ConvLaunch &c, hipStream_t st) {
   static std::atomic<unsigned long long> done{0};
   conv_allow_big_lds(reinterpret_cast<const void *>(&k_conv_b<CI, CT, PT>), done, c.lds_bytes);
   hipLaunchKernelGGL((k_conv_b<CI, CT, PT>), c.grid, dim3(kConvThreads), c.lds_bytes, st, c.args);
 }
+#endif
 template <int CI, int CT, int PT>
 inline void launch_conv_a_inst(const ConvLaunch &c, hipStream_t st) {
   static std::atomic<unsigned long long> done{0};
@@ -1575,6 +1579,9 @@ inline void launch_conv_m_inst(const ConvLaunch &c, hipStream_t st) {
   hipLaunchKernelGGL((k_conv_m<CI, NUP, CT, PT, FZ, NCW, W>), c.grid, dim3(64 * (NCW + (FZ ? kMarchFzProducers : kMarchProducers))), c.lds_bytes, st, c.args, c.march);
 }
 inline void launch_conv(const ConvLaunch &c, hipStream_t st) {
+#ifndef DR_PARITY_HOOKS
+  if (c.bf3) fail(DR_ERR_UNSUPPORTED, "launch_conv: the bf16 x 3 kernel is built with -DDR_PARITY_HOOKS only");
+#else
   if (c.bf3) {
 #define DR_CONV_B_CASE(CI_, CT_)                                                \
   if (c.ci == CI_ && c.ct == CT_ && !c.async && !c.fz) {                        \
@@ -1591,6 +1598,7 @@ inline void launch_conv(const ConvLaunch &c, hipStream_t st) {
 #undef DR_CONV_B_CASE
     fail(DR_ERR_ARG, "launch_conv: no bf16x3 instance CI=%d CT=%d", c.ci, c.ct);
   }
+#endif
 #ifndef DR_PARITY_HOOKS  // the fused-skip forms (FeatureNet's stage-3 head in its literal order) are instantiated in the parity build only
   if (c.fz) fail(DR_ERR_UNSUPPORTED, "launch_conv: fused-skip kernels are built with -DDR_PARITY_HOOKS only");
 #else

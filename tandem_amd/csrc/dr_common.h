@@ -63,4 +63,13 @@ inline T *dalloc(size_t n) {
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// A DR_* switch that selects a superseded kernel generation or the losing side of a settled A/B exists only in the PARITY build
+// (-DDR_PARITY_HOOKS, libdr_mi355x_hooks.so: test infrastructure).  In the product library hook_env() is a constant: the variable is not read, the
+// branch behind it folds away.  What the product library does read from the environment is listed in INTEGRATION.md ("Environment switches").
+#ifdef DR_PARITY_HOOKS
+inline const char *hook_env(const char *name) { return getenv(name); }
+#else
+inline const char *hook_env(const char *) { return nullptr; }
+#endif
+
 }  // namespace dr

@@ -1163,7 +1163,7 @@ class FusionEngine {
     // at any moment are neighbours in the pool (sweep on the bench map: 1024 / 3072 / 4096 / 6144 / 8192 / 16384
     // workgroups -> 0.341 / 0.327 / 0.329 / 0.363 / 0.443 / 0.697 ms per scan)
     integrate_grid_ = std::min(cdiv(o.num_blocks, 4), 3072);
-    if (const char *e = getenv("DR_INT_GRID")) integrate_grid_ = std::min(65536, std::max(1, atoi(e)));  // tuning hook
+    if (const char *e = hook_env("DR_INT_GRID")) integrate_grid_ = std::min(65536, std::max(1, atoi(e)));  // tuning hook
     DR_HIP(hipEventCreateWithFlags(&int_done_, hipEventDisableTiming));
     for (int i = 0; i < o.num_render_streams; ++i) {
       Render r;
@@ -1592,7 +1592,7 @@ class FusionEngine {
   void setup_fast_div() {
     d_.vs_rcp = rcp_rn(o_.voxel_size); d_.fx_rcp = rcp_rn(o_.fx); d_.fy_rcp = rcp_rn(o_.fy);
     d_.fast_div = 0;
-    if (getenv("DR_FUSION_IEEE_DIV")) return;
+    if (hook_env("DR_FUSION_IEEE_DIV")) return;
     unsigned long long *bad = dalloc<unsigned long long>(1), h = 0;
     DR_HIP(hipMemsetAsync(bad, 0, 8, int_stream_));
     const float b[3] = {o_.voxel_size, o_.fx, o_.fy}, y[3] = {d_.vs_rcp, d_.fx_rcp, d_.fy_rcp};
@@ -1632,12 +1632,12 @@ class FusionEngine {
   // switches, read once here.  Product: the empty-space skip's A/B switch (a run-time flag of the same kernel) and DR_FUSION_IEEE_DIV (the
   // IEEE-division instances are the product's fallback when the exact fast division fails its check).  Parity build (-DDR_PARITY_HOOKS):
   // the superseded generations -- the literal ray-caster, round 2's four-stage sampler, copy-engine result transfers, statistics.
-  bool raycast_no_skip_ = getenv("DR_RAYCAST_NO_SKIP") != nullptr;
+  bool raycast_no_skip_ = hook_env("DR_RAYCAST_NO_SKIP") != nullptr;
 #ifdef DR_PARITY_HOOKS
-  bool raycast_v1_ = getenv("DR_RAYCAST_V1") != nullptr;
-  int raycast_sampler_ = getenv("DR_RAYCAST_SAMPLER") ? std::max(0, std::min(1, atoi(getenv("DR_RAYCAST_SAMPLER")))) : (getenv("DR_RAYCAST_UNSTAGED") ? 0 : 1);
-  bool render_copy_ = getenv("DR_RENDER_D2H") && !strcmp(getenv("DR_RENDER_D2H"), "copy");
-  bool raycast_stats_ = getenv("DR_RAYCAST_STATS") != nullptr;     // measuring hook: iteration statistics of k_raycast2 on stderr
+  bool raycast_v1_ = hook_env("DR_RAYCAST_V1") != nullptr;
+  int raycast_sampler_ = hook_env("DR_RAYCAST_SAMPLER") ? std::max(0, std::min(1, atoi(hook_env("DR_RAYCAST_SAMPLER")))) : (getenv("DR_RAYCAST_UNSTAGED") ? 0 : 1);
+  bool render_copy_ = hook_env("DR_RENDER_D2H") && !strcmp(hook_env("DR_RENDER_D2H"), "copy");
+  bool raycast_stats_ = hook_env("DR_RAYCAST_STATS") != nullptr;     // measuring hook: iteration statistics of k_raycast2 on stderr
   unsigned long long *d_rstats_ = nullptr;
 #else
   static constexpr bool render_copy_ = false;

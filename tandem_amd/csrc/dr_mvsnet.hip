@@ -21,7 +21,9 @@
 
 #include "conv_mfma.h"
 #include "mvs_kernels.h"
+#ifdef DR_PARITY_HOOKS  // conv11 + prob in one launch: built twice in round 5, correct, slower than the two-kernel path (profiles/r05_tail.txt): parity build only
 #include "tail_kernels.h"
+#endif
 #include "fn_front.h"
 #include "fn_head3.h"
 
@@ -120,7 +122,9 @@ struct Op {
   int d0 = 0, d1 = 0, d2 = 0;
   std::string name;
   ConvLaunch conv;
+#ifdef DR_PARITY_HOOKS
   TailArgs tail{};                        // TAIL only: conv11 + prob in one launch (tail_kernels.h)
+#endif
   FrontArgs front{};                      // FRONT only: preprocess + conv0.0 + conv0.1 in one launch (fn_front.h)
   Head3Args head3{};                      // HEAD3 only: FeatureNet's folded stage-3 head in one launch (fn_head3.h)
   std::function<ConvLaunch(int)> replan;  // CONV only: build candidate `rank` of the planner's ranking
@@ -185,59 +189,57 @@ __global__ __launch_bounds__(256) void k_publish4(const float4 *__restrict__ a, 
   }
 }
 
-// Every DR_* switch of the engine, read ONCE when the engine is created (nothing on the launch path calls getenv).  Tuning knobs and
-// the two fallback kernels (k_costvol2, k_regress) are part of the product; switches that select a SUPERSEDED kernel generation
-// exist only in the parity build (-DDR_PARITY_HOOKS, libdr_mi355x_hooks.so: what the tests that compare generations load).
+// Every DR_* switch of the engine, read ONCE when the engine is created (nothing on the launch path calls getenv).  The product library reads
+// six of them (profiling, printing, tuning knobs: listed in INTEGRATION.md); every switch that selects a superseded kernel generation, the losing side of a
+// settled A/B or a forced fallback is read through hook_env(), i.e. only in the parity build (-DDR_PARITY_HOOKS, libdr_mi355x_hooks.so: what the tests
+// that compare generations load) -- in the product those members are constants.
 struct MvsSwitches {
   static int num(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
   static bool on(const char *name) { return getenv(name) != nullptr; }
+  static int hnum(const char *name, int dflt) { const char *e = hook_env(name); return e ? atoi(e) : dflt; }  // parity build only (dr_common.h): the product returns dflt
+  static bool hon(const char *name) { return hook_env(name) != nullptr; }
+  // ---- read by the product library ("Environment switches"): profiling, printing, tuning knobs
   bool side_stream = !on("DR_MVS_NO_SIDE_STREAM");       // FeatureNet's stage-2/3 heads on a second stream (off: strictly sequential kernels, for profiles)
   int conv_print = num("DR_CONV_PRINT", 0);              // autotune / debug printing
   std::string autotune_only = getenv("DR_AUTOTUNE_ONLY") ? getenv("DR_AUTOTUNE_ONLY") : "";  // tuning: restrict autotune to layers whose name contains this
   int cv_dchunk[3] = {num("DR_CV_DCHUNK1", 0), num("DR_CV_DCHUNK2", 0), num("DR_CV_DCHUNK3", 0)};  // tuning: depth planes per cost-volume workgroup (0: default)
   int prob_zchunk = num("DR_PROB_ZCHUNK", 0);            // tuning: z-march chunk of k_prob2 (0: default)
-  int prob_rows = num("DR_PROB_ROWS", 0);                // A-B: logits per lane of k_prob2 (2 or 4: measured slower; default 1)
-  int hist_blocks = std::max(1, num("DR_HIST_BLOCKS", 128));  // workgroups of a histogram level (each flushes its bins with atomics on a few hot addresses)
-  bool costvol_v2 = on("DR_COSTVOL_V2");                 // k_costvol2 (the fallback for depth chunks that are not multiples of 4) everywhere
-  bool regress_generic = on("DR_REGRESS_GENERIC");       // k_regress (the fallback for other plane counts) everywhere
-  bool shard_allreduce = on("DR_SHARD_ALLREDUCE");       // view shard: round 2's all-reduce form instead of reduce + broadcast
-  // CostRegNet's conv11 + prob as ONE launch (tail_kernels.h).  OPT-IN: both forms are correct (tests/test_tail_gpu.py) and the memory side of the fusion works
+  int hist_blocks = std::max(1, num("DR_HIST_BLOCKS", 128));  // tuning: workgroups of a histogram level (each flushes its bins with atomics on a few hot addresses)
+  // ---- parity build only: the other side of every settled A/B, superseded generations, forced fallbacks (constants in the product)
+  int prob_rows = hnum("DR_PROB_ROWS", 0);               // logits per lane of k_prob2 (2 or 4: measured slower; default 1)
+  bool costvol_v2 = hon("DR_COSTVOL_V2");                // k_costvol2 (the product's fallback for depth chunks that are not multiples of 4) everywhere
+  bool regress_generic = hon("DR_REGRESS_GENERIC");      // k_regress (the product's fallback for other plane counts) everywhere
+  bool shard_allreduce = hon("DR_SHARD_ALLREDUCE");      // view shard: round 2's all-reduce form instead of reduce + broadcast
+  // CostRegNet's conv11 + prob as ONE launch (tail_kernels.h): both forms are correct (tests/test_tail_gpu.py) and the memory side of the fusion works
   // (the 78.6 MB tensor between the two layers is gone), but the transposed convolution x 1.8 (halo) and the prob stencil share the same issue slots -- fp32
   // MFMAs and vector work serialise on a SIMD -- and nothing overlaps the kernel's memory side: 0.128 / 0.113 ms (matrix pipe) and 0.118 / 0.109 (vector pipe)
   // at stages 2 / 3 against the two-kernel path's 0.100 / 0.096 (profiles/r05_tail.txt)
-  int tail_fused = num("DR_TAIL_FUSED", 0);              // 0: the two-kernel path; 1: k_tail_m (transposed convolution on the matrix pipe); 2: k_tail (on the vector pipe)
-  bool fn_front = num("DR_FN_FRONT", 1) != 0;          // 1: FeatureNet's first block (u8 -> float, conv0.0, conv0.1) in one launch (k_fn_front); 0: the three launches
-  bool fn_head3 = num("DR_FN_HEAD3", 1) != 0;          // 1: the folded stage-3 head of FeatureNet (fn.out3a..d) in one launch (k_fn_head3); 0: the four launches
-  bool filter_fused = num("DR_FILTER_FUSED", 1) != 0;    // 1: the radix select's scans run as the prologue of the kernels that follow them (5 launches); 0: a k_scan launch per level (8)
-  bool prob_regress = num("DR_PROB_REGRESS", 1) != 0;    // 1: where a stage's planes are one depth chunk of k_prob2 (D = 8), the regression runs in the same launch (k_prob2_regress)
-  int tail_qy = num("DR_TAIL_QY", 0), tail_zchunk = num("DR_TAIL_ZCHUNK", 0);  // tuning: k_tail's tile (quad rows: 4, 8, 16, 32) and depth planes per workgroup (0: chosen by size)
-  bool vol_split = !on("DR_VOL_NO_SPLIT");               // stage 1's 32-channel cost volume as two 16-channel halves (DevTensor::split); off: one (D,h,w,32) tensor (A/B)
-#ifdef DR_PARITY_HOOKS
-  bool costvol_v1 = on("DR_COSTVOL_V1");                 // round 2's k_costvol on unpadded feature maps
-  bool costvol_v3 = on("DR_COSTVOL_V3");                 // k_costvol3 everywhere: also where the product runs k_costvol5 and where DR_CV4_STAGES selects the LDS-staged k_costvol4
-  int costvol_cpl = num("DR_COSTVOL_CPL", 4) == 8 ? 8 : 4;
-  bool prob_v1 = on("DR_PROB_V1");                       // round 2's k_prob (L1 gathers)
-  int prob_block = std::max(64, std::min(256, num("DR_PROB_BLOCK", 256) / 64 * 64)), prob_xo = num("DR_PROB_XO", 1);
-  bool prob_launch_order = on("DR_PROB_LAUNCH_ORDER"), prob_on_conv = on("DR_PROB_ON_CONV");
-  bool skip_on_conv = on("DR_SKIP_ON_CONV"), no_skip_fusion = on("DR_NO_SKIP_FUSION");
-  bool out3_folded = num("DR_OUT3_FOLDED", 1) != 0;      // 0: FeatureNet's stage-3 head in its literal order (fused-skip kernel)
-  bool d2h_copy = getenv("DR_MVS_D2H") && !strcmp(getenv("DR_MVS_D2H"), "copy");  // four copy-engine transfers instead of k_publish4
-  // k_costvol4 (round 4: source taps staged through LDS -- north_star's "LDS staging of per-pixel feature slices"): bit-identical to
-  // k_costvol3 and measured 8-15 % SLOWER (0.121 / 0.163 / 0.105 against 0.106 / 0.150 / 0.099 ms per stage), so it is not in the product
+  int tail_fused = hnum("DR_TAIL_FUSED", 0);             // 0: the two-kernel path; 1: k_tail_m (transposed convolution on the matrix pipe); 2: k_tail (on the vector pipe)
+  int tail_qy = hnum("DR_TAIL_QY", 0), tail_zchunk = hnum("DR_TAIL_ZCHUNK", 0);  // k_tail's tile (quad rows: 4, 8, 16, 32) and depth planes per workgroup (0: chosen by size)
+  bool fn_front = hnum("DR_FN_FRONT", 1) != 0;           // 1: FeatureNet's first block (u8 -> float, conv0.0, conv0.1) in one launch (k_fn_front); 0: the three launches
+  bool fn_head3 = hnum("DR_FN_HEAD3", 1) != 0;           // 1: the folded stage-3 head of FeatureNet (fn.out3a..d) in one launch (k_fn_head3); 0: the four launches
+  bool filter_fused = hnum("DR_FILTER_FUSED", 1) != 0;   // 1: the radix select's scans run as the prologue of the kernels that follow them (5 launches); 0: a k_scan launch per level (8)
+  bool prob_regress = hnum("DR_PROB_REGRESS", 1) != 0;   // 1: where a stage's planes are one depth chunk of k_prob2 (D = 8), the regression runs in the same launch (k_prob2_regress)
+  bool vol_split = !hon("DR_VOL_NO_SPLIT");              // stage 1's 32-channel cost volume as two 16-channel halves (DevTensor::split); off: one (D,h,w,32) tensor
+  bool costvol_v1 = hon("DR_COSTVOL_V1");                // round 2's k_costvol on unpadded feature maps
+  bool costvol_v3 = hon("DR_COSTVOL_V3");                // k_costvol3 everywhere: also where the product runs k_costvol5 and where DR_CV4_STAGES selects the LDS-staged k_costvol4
+  int costvol_cpl = hnum("DR_COSTVOL_CPL", 4) == 8 ? 8 : 4;
+  bool prob_v1 = hon("DR_PROB_V1");                      // round 2's k_prob (L1 gathers)
+  int prob_block = std::max(64, std::min(256, hnum("DR_PROB_BLOCK", 256) / 64 * 64)), prob_xo = hnum("DR_PROB_XO", 1);
+  bool prob_launch_order = hon("DR_PROB_LAUNCH_ORDER"), prob_on_conv = hon("DR_PROB_ON_CONV");
+  bool skip_on_conv = hon("DR_SKIP_ON_CONV"), no_skip_fusion = hon("DR_NO_SKIP_FUSION");
+  bool out3_folded = hnum("DR_OUT3_FOLDED", 1) != 0;     // 0: FeatureNet's stage-3 head in its literal order (fused-skip kernel)
+  bool d2h_copy = hook_env("DR_MVS_D2H") && !strcmp(hook_env("DR_MVS_D2H"), "copy");  // four copy-engine transfers instead of k_publish4
   // k_costvol5's two choices (round 6, profiles/r06_costvol_ab.txt): a sample whose footprint is the previous plane's issues no gathers (0.109 / 0.172 / 0.120 ->
   // 0.084 / 0.150 / 0.117 ms at depth chunks of 4 / 8 / 8 planes); the workgroup tile is four rows of a quarter segment at stage 3 only (C = 8: 0.106 -> 0.095 ms
   // there, 0.083 -> 0.089 at stage 1, nothing at stage 2)
-  int cv5_rows = num("DR_CV5_ROWS", 0);                  // 0: the product's rule (4 rows where C = 8); 1 / 4: that tile at every stage
-  bool cv5_reuse = num("DR_CV5_REUSE", 1) != 0;          // 0: every sample gathers its four taps
-  int cv5_abl = num("DR_CV5_ABL", 0);                    // measuring hook: k_costvol5 without its gathers (1), stores (2), tap arithmetic (4)
-  int cv4_stages = num("DR_CV4_STAGES", 0);              // bit s-1 set = stage s builds its cost volume with k_costvol4 where it applies
-  int cv4_sp8 = num("DR_CV4_SP8", 0);                    // bit s-1 set = 8 planes per k_costvol4 step at stage s (else 4)
-#else
-  static constexpr bool costvol_v1 = false, costvol_v3 = false, prob_v1 = false, prob_launch_order = false, prob_on_conv = false, skip_on_conv = false,
-                        no_skip_fusion = false, out3_folded = true, d2h_copy = false;
-  static constexpr int costvol_cpl = 4, prob_block = 256, prob_xo = 1, cv4_stages = 0, cv4_sp8 = 0, cv5_abl = 0, cv5_rows = 0;
-  static constexpr bool cv5_reuse = true;
-#endif
+  int cv5_rows = hnum("DR_CV5_ROWS", 0);                 // 0: the product's rule (4 rows where C = 8); 1 / 4: that tile at every stage
+  bool cv5_reuse = hnum("DR_CV5_REUSE", 1) != 0;         // 0: every sample gathers its four taps
+  int cv5_abl = hnum("DR_CV5_ABL", 0);                   // measuring hook: k_costvol5 without its gathers (1), stores (2), tap arithmetic (4)
+  // k_costvol4 (round 4: source taps staged through LDS -- north_star's "LDS staging of per-pixel feature slices"): bit-identical to
+  // k_costvol3 and measured 8-15 % SLOWER (0.121 / 0.163 / 0.105 against 0.106 / 0.150 / 0.099 ms per stage), so it is not in the product
+  int cv4_stages = hnum("DR_CV4_STAGES", 0);             // bit s-1 set = stage s builds its cost volume with k_costvol4 where it applies
+  int cv4_sp8 = hnum("DR_CV4_SP8", 0);                   // bit s-1 set = 8 planes per k_costvol4 step at stage s (else 4)
 };
 
 // One helper thread that takes half of the operator boundary's host copies (the window into the staging block, the result maps out of
@@ -327,6 +329,7 @@ class MvsEngine {
     if (h_in_) (void)hipHostFree(h_in_);
     if (ev_h2d_) (void)hipEventDestroy(ev_h2d_);
     if (march_err_) (void)hipHostFree(march_err_);
+    if (fc_flag_) (void)hipHostFree(fc_flag_);
     (void)hipStreamSynchronize(side_);
     for (auto e : {ev_fork_, ev_feat2_, ev_feat3_}) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(side_);
@@ -377,6 +380,26 @@ class MvsEngine {
     has_output_ = false;
   }
 
+  // --- key-frame feature cache (extension; see build_fn1) ----------------------------------------
+  void set_feature_cache(int capacity) {
+    if (capacity < 0 || capacity > 64) fail(DR_ERR_ARG, "drm_set_feature_cache: capacity %d out of range (0 = off, up to 64 key frames)", capacity);
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [&] { return !unprocessed_; });
+    if (capacity == fcache_cap_) return;
+    fcache_cap_ = capacity;
+    if (H_) {  // a configured engine is re-planned: the entries are sized for the window shape
+      DR_HIP(hipSetDevice(device_));
+      const int H = H_, W = W_, V = V_;
+      H_ = W_ = V_ = 0;
+      configure(H, W, V);
+      has_output_ = false;
+    }
+  }
+  void feature_cache_stats(uint64_t out[6]) {
+    std::unique_lock<std::mutex> lk(mu_);
+    out[0] = fc_hits_; out[1] = fc_misses_; out[2] = fc_batch_windows_; out[3] = fc_collisions_; out[4] = fn1_ok_ ? 1 : 0; out[5] = (uint64_t)fcache_.size();
+  }
+
   // --- device-resident hooks -------------------------------------------------------------------
   void upload(int H, int W, int V, int ref, const uint8_t *const *bgrs, const float *K9, const float *const *c2ws,
               float dmin, float dmax, float disc) {
@@ -399,6 +422,7 @@ class MvsEngine {
     float t = 0;
     DR_HIP(hipEventElapsedTime(&t, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    cache_mismatch_recovered();
     check_march();
     if (ms) *ms = t;
   }
@@ -454,6 +478,7 @@ class MvsEngine {
     check_march();
     if (before_ms) *before_ms = (float)t_before;
     if (after_ms) *after_ms = (float)t_after;
+    if (fn1_ok_ && !match_fn1()) { fn1_ok_ = false; fc_fast_ = false; }  // (the feature cache's single-view plan follows the batch plan's instances, or stands down)
   }
 
   // ---- view sharding hooks (SURVEY 8e / BASELINE configs[2]; no reference counterpart) ----
@@ -593,7 +618,9 @@ class MvsEngine {
         else if (o.stage >= 1 && o.stage <= 3 && prob_fused_last_[o.stage - 1]) snprintf(kn, sizeof kn, "k_prob2_regress<8>");
         else snprintf(kn, sizeof kn, "k_prob2<%d>", sw_.prob_rows == 2 || sw_.prob_rows == 4 ? sw_.prob_rows : 1);
       }
+#ifdef DR_PARITY_HOOKS
       else if (o.kind == Op::TAIL) snprintf(kn, sizeof kn, o.tail.wmf ? "k_tail_m<%d>" : "k_tail<%d>", std::max(3, tail_nout(o.tail.QY, o.tail.QX)));
+#endif
       else if (o.kind == Op::REGRESS) snprintf(kn, sizeof kn, "k_regress");
       else if (o.kind == Op::PREPROCESS) snprintf(kn, sizeof kn, "k_preprocess");
       else if (o.kind == Op::FRONT) snprintf(kn, sizeof kn, "k_fn_front");
@@ -652,6 +679,11 @@ class MvsEngine {
                                (const float4 *)T("depth3").d, (const float4 *)T("conf3").d, (float4 *)h_out_dev_[blk], n / 16);
           }
           DR_HIP(hipStreamSynchronize(stream_));
+          if (cache_mismatch_recovered()) {  // a cache hit that was a key collision: the window ran again without the cache; publish THAT result
+            hipLaunchKernelGGL(k_publish4, dim3(256), dim3(256), 0, stream_, (const float4 *)T("depth").d, (const float4 *)T("confidence").d,
+                               (const float4 *)T("depth3").d, (const float4 *)T("conf3").d, (float4 *)h_out_dev_[blk], n / 16);
+            DR_HIP(hipStreamSynchronize(stream_));
+          }
           check_march();
           out_cur_ = blk;
           has_output_ = true;
@@ -664,7 +696,7 @@ class MvsEngine {
   }
 
   DevTensor &T(const std::string &name) {
-    auto it = tensors_.find(name);
+    auto it = tensors_.find(tprefix_.empty() ? name : tprefix_ + name);
     if (it == tensors_.end()) fail(DR_ERR_ARG, "unknown tensor '%s'", name.c_str());
     return it->second;
   }
@@ -672,13 +704,15 @@ class MvsEngine {
     DevTensor t; t.D = D; t.H = H; t.W = W; t.C = C; t.pad = pad;
     t.d = dalloc<float>(t.n());
     if (pad) DR_HIP(hipMemset(t.d, 0, t.n() * 4));  // the border is written once, here; producers only touch the interior
-    tensors_[name] = t;
-    return tensors_[name];
+    const std::string key = tprefix_.empty() ? name : tprefix_ + name;  // (the single-view FeatureNet of the feature cache builds into its own names)
+    tensors_[key] = t;
+    return tensors_[key];
   }
   void release() {
     for (auto &kv : tensors_) (void)hipFree(kv.second.d);
     tensors_.clear();
     ops_.clear();
+    ops1_.clear(); fcache_.clear(); fn1_ok_ = false; fc_fast_ = fc_fill_ = false;  // (a new window shape evicts everything: the entries' buffers are in misc_)
     plan_arena_.reset();
     for (void *p : misc_) (void)hipFree(p);
     misc_.clear();
@@ -838,23 +872,8 @@ class MvsEngine {
     }
     H_ = H; W_ = W; V_ = V;
   }
-  void build_plan(int H, int W, int V) {
-    plan_arena_.reset(new DeviceArena());
-    plan_arena_->err_flag = march_err_;
-    for (float *&h : h_out_) if (h) { (void)hipHostFree(h); h = nullptr; }
-    if (h_in_) { (void)hipHostFree(h_in_); h_in_ = nullptr; }
-    for (int b = 0; b < 2; ++b) {
-      DR_HIP(hipHostMalloc((void **)&h_out_[b], (size_t)H * W * 16, hipHostMallocDefault));
-      DR_HIP(hipHostGetDevicePointer((void **)&h_out_dev_[b], h_out_[b], 0));
-    }
-    has_output_ = false;
-    DR_HIP(hipHostMalloc((void **)&h_in_, (size_t)V * H * W * 3, hipHostMallocDefault));
-    d_bgr_ = dalloc<uint8_t>((size_t)V * H * W * 3 + 16); misc_.push_back(d_bgr_);  // (+16: k_fn_front fetches a pixel as the two aligned words around it)
-    d_state_ = dalloc<unsigned>(16); misc_.push_back(d_state_);   // four 4-word slots (the fused-scan form keeps one per level)
-    d_hist_ = dalloc<unsigned>(3 * 2048); misc_.push_back(d_hist_);  // one histogram per level (the k_scan form uses the first only)
-    DR_HIP(hipMemset(d_hist_, 0, 3 * 2048 * 4));
-    DR_HIP(hipMemset(d_state_, 0, 16 * 4));
-
+  // FeatureNet for a batch of V views (module.py:461-531): appends its launches to ops_ and records which of them may run on the side stream
+  void build_featurenet(int V, int H, int W) {
     const std::string fn = "feature_net.";
     DevTensor &c3 = front_block(fn, V, H, W);
     DevTensor &c2a = cbr2("fn.conv1.0", fn + "conv1.0", c3, 5, 2, CONV_NORMAL);
@@ -934,6 +953,225 @@ class MvsEngine {
       add_conv("fn.out3", fn + "out.stage3", "", false, false, i3, "feat3", 1, 3, 3, 1, 1, 1, false, CONV_XPAIR, nullptr, 0, nullptr, fpad);
     }
     fork_hi_ = ops_.size();
+  }
+
+  // ---------------------------------------------------------------- key-frame feature cache (drm_set_feature_cache)
+  // In TANDEM six of a window's seven images were in the previous window (FullSystem.cpp:1162-1171 re-sends frameHessians[i]->image_bgr), and
+  // FeatureNet is per image.  With the cache on, the engine keeps feat1..3 (and the u8 image) of the last `capacity` images; a window whose images
+  // are all cached but at most ONE runs FeatureNet on that one view (its own single-view plan, the same kernel instances as the batch plan) and the
+  // plane sweep reads every view's features where the cache holds them (CostVolArgs::vfeat): 15 launches over 7 views become 11 over one.
+  //  * identity: a 128-bit key over a sample of the image (first / last 64 bytes + 512 evenly spaced 8-byte words) finds the entry; the hit is then
+  //    made EXACT on the device -- every uploaded image is compared byte for byte with the entry's copy (k_verify_image), and a difference (a key
+  //    collision) drops the whole cache and runs the window again without it, before any result leaves the engine;
+  //  * windows with two or more uncached images (the first one, a reset) take the batch path and fill the cache from its outputs;
+  //  * same bits with the cache on and off: the single-view plan is built from the batch plan's own choices (kernel family, channel pass, tiles per wave)
+  //    -- the products and their order per output value do not depend on the tile shape or the batch size (tests: test_feature_cache_is_bit_identical);
+  //  * OFF by default and in every leg of bench.py that feeds `value` / `single_window_ms` (they repeat one window: every image would hit).
+  struct FnOut { size_t op; int stage; size_t offset; };  // launch `op` of the single-view plan stores into feat<stage + 1> at this float offset
+  struct FcEntry { uint64_t key[2] = {0, 0}; float *feat[3] = {nullptr, nullptr, nullptr}; uint8_t *bgr = nullptr; uint64_t used = 0; bool valid = false; };
+  static bool same_instance(const ConvLaunch &a, const ConvLaunch &b) {
+    return a.async == b.async && a.ci == b.ci && a.ct == b.ct && a.pt == b.pt && a.fz == b.fz && a.bf3 == b.bf3 && a.nup == b.nup && a.ncw == b.ncw &&
+           a.march.wino == b.march.wino && a.march.rm == b.march.rm;
+  }
+  void build_fn1(int H, int W) {
+    fn1_ok_ = false; ops1_.clear(); fcache_.clear();
+    if (ops_.empty() || ops_[0].kind != Op::FRONT || sw_.costvol_v1 || shard_nsrc_) return;  // (the single-view plan patches k_fn_front's image pointer per call)
+    const size_t lo = fork_lo_, hi = fork_hi_, f2 = feat2_op_;
+    std::vector<Op> batch;
+    batch.swap(ops_);
+    tprefix_ = "c1.";
+    try { build_featurenet(1, H, W); } catch (...) { tprefix_.clear(); ops_.swap(batch); fork_lo_ = lo; fork_hi_ = hi; feat2_op_ = f2; throw; }
+    tprefix_.clear();
+    ops1_.swap(ops_); ops_.swap(batch);
+    fork_lo_ = lo; fork_hi_ = hi; feat2_op_ = f2;
+    if (!match_fn1()) { ops1_.clear(); return; }
+    // the entries: three bordered feature maps + the image, per cached key frame
+    const size_t img_bytes = (size_t)H * W * 3;
+    fcache_.resize(fcache_cap_);
+    for (FcEntry &e : fcache_) {
+      for (int s = 0; s < 3; ++s) {
+        const DevTensor &t = T("c1.feat" + std::to_string(s + 1));
+        e.feat[s] = dalloc<float>(t.n()); misc_.push_back(e.feat[s]);
+        DR_HIP(hipMemset(e.feat[s], 0, t.n() * 4));  // (the zero border is written once, here: the producers store interior pixels only)
+      }
+      e.bgr = dalloc<uint8_t>(img_bytes + 16); misc_.push_back(e.bgr);
+    }
+    if (!fc_flag_) { DR_HIP(hipHostMalloc((void **)&fc_flag_, sizeof(int), hipHostMallocDefault)); *fc_flag_ = 0; }
+    // the single-view plan writes its three outputs straight into the entry of the image it runs on: which launches store into feat1..3, and where
+    fn1_out_.clear();
+    for (size_t i = 0; i < ops1_.size(); ++i) {
+      Op &o = ops1_[i];
+      float *out = o.kind == Op::CONV ? o.conv.args.out : (o.kind == Op::HEAD3 ? o.head3.out : nullptr);
+      for (int s = 0; s < 3 && out; ++s) {
+        const DevTensor &t = T("c1.feat" + std::to_string(s + 1));
+        if (out >= t.d && out < t.d + t.n()) fn1_out_.push_back({i, s, (size_t)(out - t.d)});
+      }
+    }
+    if (fn1_out_.size() != 3) { ops1_.clear(); fcache_.clear(); return; }
+    fn1_ok_ = true;
+  }
+  // every launch of the single-view plan becomes the batch plan's own kernel instance for that layer (the planner ranks candidates by a cost model that sees
+  // the batch size; the arithmetic of an instance does not)
+  bool match_fn1() {
+    for (Op &o : ops1_) {
+      const Op *b = nullptr;
+      for (size_t i = 0; i < fork_hi_ && i < ops_.size(); ++i) if (ops_[i].name == o.name) b = &ops_[i];
+      if (!b || b->kind != o.kind) return false;
+      if (o.kind == Op::FRONT || o.kind == Op::HEAD3) continue;
+      if (o.kind != Op::CONV) return false;
+      if (same_instance(o.conv, b->conv)) continue;
+      if (!o.replan) return false;
+      bool found = false;
+      for (int r = 0; r < o.ncand && !found; ++r) {
+        const ConvLaunch c = o.replan(r);
+        if (same_instance(c, b->conv)) { o.conv = c; found = true; }
+      }
+      if (!found) return false;
+    }
+    return true;
+  }
+  static void image_key(const uint8_t *p, size_t n, int H, int W, uint64_t key[2]) {
+    uint64_t a = 0xcbf29ce484222325ull ^ (uint64_t)H, b = 0x9e3779b97f4a7c15ull ^ (uint64_t)W;
+    auto mix = [&](uint64_t w) { a = (a ^ w) * 0x100000001b3ull; b = (b + w) * 0xff51afd7ed558ccdull; b ^= b >> 29; };
+    auto word = [&](size_t off) { uint64_t w; memcpy(&w, p + off, 8); return w; };
+    for (size_t o = 0; o < 64; o += 8) { mix(word(o)); mix(word(n - 64 + o)); }
+    const size_t step = (n / 512) & ~(size_t)7;
+    for (size_t k = 1; k < 512 && step; ++k) mix(word(k * step));
+    key[0] = a; key[1] = b;
+  }
+  // decides, for the window being staged, which views the cache answers.  fc_slot_[v]: the entry that holds (or will hold) view v's features.
+  void plan_cache_use(int H, int W, int V, const uint8_t *const *bgrs, const std::vector<int> &order) {
+    fc_fast_ = false; fc_fill_ = false; fc_miss_ = -1;
+    if (!fn1_ok_ || (int)fcache_.size() < V + 1) return;
+    for (int s = 1; s <= 3; ++s) if (!cv5_applies(s)) return;  // (only k_costvol5 reads the views by pointer)
+    const size_t img_bytes = (size_t)H * W * 3;
+    uint64_t keys[8][2];
+    int nmiss = 0;
+    ++fc_clock_;
+    for (int v = 0; v < V; ++v) {
+      image_key(bgrs[order[v]], img_bytes, H, W, keys[v]);
+      fc_slot_[v] = -1;
+      for (size_t e = 0; e < fcache_.size(); ++e)
+        if (fcache_[e].valid && fcache_[e].key[0] == keys[v][0] && fcache_[e].key[1] == keys[v][1]) { fc_slot_[v] = (int)e; break; }
+      for (int u = 0; u < v; ++u) if (fc_slot_[v] >= 0 && fc_slot_[u] == fc_slot_[v]) fc_slot_[v] = -1;  // (two views with one key: only one may own the entry)
+      if (fc_slot_[v] < 0) { ++nmiss; fc_miss_ = v; } else fcache_[fc_slot_[v]].used = fc_clock_;
+    }
+    auto evict = [&]() {  // the least recently used entry that this window does not use
+      int best = -1;
+      for (size_t e = 0; e < fcache_.size(); ++e) {
+        bool in_window = false;
+        for (int v = 0; v < V; ++v) in_window |= fc_slot_[v] == (int)e;
+        if (!in_window && (best < 0 || !fcache_[e].valid || (fcache_[best].valid && fcache_[e].used < fcache_[best].used))) best = (int)e;
+        if (best >= 0 && !fcache_[best].valid) break;
+      }
+      return best;
+    };
+    if (nmiss <= 1) {
+      fc_fast_ = true;
+      if (nmiss == 1) {
+        const int e = evict();
+        fcache_[e].valid = false;  // (valid again once a forward has enqueued its fill)
+        fcache_[e].key[0] = keys[fc_miss_][0]; fcache_[e].key[1] = keys[fc_miss_][1]; fcache_[e].used = fc_clock_;
+        fc_slot_[fc_miss_] = e;
+      }
+      fc_hits_ += V - nmiss; fc_misses_ += nmiss;
+    } else {  // the batch path computes every view; its outputs fill the cache
+      fc_fill_ = true; fc_miss_ = -1;
+      for (int v = 0; v < V; ++v) {
+        if (fc_slot_[v] >= 0) continue;
+        const int e = evict();
+        fcache_[e].valid = false;
+        fcache_[e].key[0] = keys[v][0]; fcache_[e].key[1] = keys[v][1]; fcache_[e].used = fc_clock_;
+        fc_slot_[v] = e;
+      }
+      fc_misses_ += V; ++fc_batch_windows_;
+    }
+    // where the plane sweep finds each view
+    for (int s = 0; s < 3; ++s)
+      for (int v = 0; v < V; ++v)
+        if (fc_fast_) cv_[s].vfeat[v] = fcache_[fc_slot_[v]].feat[s];
+  }
+  void launch_fn_op(const Op &o, hipStream_t st) {
+    if (o.kind == Op::CONV) launch_conv(o.conv, st);
+    else if (o.kind == Op::FRONT) launch_fn_front(o.front, st);
+    else if (o.kind == Op::HEAD3) launch_fn_head3(o.head3, st);
+    else fail(DR_ERR_UNSUPPORTED, "feature cache: op kind %d in the single-view plan", (int)o.kind);
+  }
+  // fast path of a forward: verify the hits, FeatureNet on the one uncached view, its outputs (and image) into the entry
+  void forward_cached_features() {
+    const size_t img_bytes = (size_t)H_ * W_ * 3;
+    CacheIoArgs io{};  // one launch: the hits compared with their entries' images, the new image filed in its entry
+    for (int v = 0; v < V_; ++v) {
+      io.img[v] = reinterpret_cast<const uint4 *>(d_bgr_ + v * img_bytes);
+      io.entry[v] = reinterpret_cast<uint4 *>(fcache_[fc_slot_[v]].bgr);
+    }
+    io.miss = fc_miss_; io.flag = fc_flag_dev(); io.n16 = img_bytes / 16;
+    hipLaunchKernelGGL(k_cache_io, dim3(32, V_), dim3(256), 0, stream_, io);
+    if (fc_miss_ >= 0) {
+      FcEntry &e = fcache_[fc_slot_[fc_miss_]];
+      for (const FnOut &p : fn1_out_) {
+        Op &o = ops1_[p.op];
+        (o.kind == Op::CONV ? o.conv.args.out : o.head3.out) = e.feat[p.stage] + p.offset;
+      }
+      for (Op &o : ops1_) {
+        if (o.kind == Op::FRONT) o.front.bgr = d_bgr_ + fc_miss_ * img_bytes;
+        launch_fn_op(o, stream_);
+      }
+      e.valid = true;
+    }
+  }
+  // batch path with the cache on: every view's features (and image) into its entry, behind the forward that produced them
+  void fill_cache_from_batch() {
+    const size_t img_bytes = (size_t)H_ * W_ * 3;
+    for (int v = 0; v < V_; ++v) {
+      FcEntry &e = fcache_[fc_slot_[v]];
+      if (e.valid) continue;
+      for (int s = 0; s < 3; ++s) {
+        const DevTensor &t = T("feat" + std::to_string(s + 1));
+        const size_t n1 = t.n() / t.D;
+        DR_HIP(hipMemcpyAsync(e.feat[s], t.d + v * n1, n1 * 4, hipMemcpyDeviceToDevice, stream_));
+      }
+      DR_HIP(hipMemcpyAsync(e.bgr, d_bgr_ + v * img_bytes, img_bytes, hipMemcpyDeviceToDevice, stream_));
+      e.valid = true;
+    }
+  }
+  int *fc_flag_dev() { int *d = nullptr; DR_HIP(hipHostGetDevicePointer((void **)&d, fc_flag_, 0)); return d; }
+  // after a stream synchronise: a hit that was not one (key collision).  The cache is dropped and the staged window runs again on the batch path.
+  bool cache_mismatch_recovered() {
+    if (!fc_flag_ || !*fc_flag_) return false;
+    *fc_flag_ = 0;
+    ++fc_collisions_;
+    for (FcEntry &e : fcache_) e.valid = false;
+    fc_fast_ = false; fc_fill_ = false;
+    for (int s = 0; s < 3; ++s) set_batch_vfeat(s);
+    forward(nullptr);
+    DR_HIP(hipStreamSynchronize(stream_));
+    return true;
+  }
+  void set_batch_vfeat(int s) {
+    const DevTensor &t = T("feat" + std::to_string(s + 1));
+    for (int v = 0; v < V_ && v <= kMaxSrc; ++v) cv_[s].vfeat[v] = t.d + (size_t)v * (t.n() / t.D);
+  }
+
+  void build_plan(int H, int W, int V) {
+    plan_arena_.reset(new DeviceArena());
+    plan_arena_->err_flag = march_err_;
+    for (float *&h : h_out_) if (h) { (void)hipHostFree(h); h = nullptr; }
+    if (h_in_) { (void)hipHostFree(h_in_); h_in_ = nullptr; }
+    for (int b = 0; b < 2; ++b) {
+      DR_HIP(hipHostMalloc((void **)&h_out_[b], (size_t)H * W * 16, hipHostMallocDefault));
+      DR_HIP(hipHostGetDevicePointer((void **)&h_out_dev_[b], h_out_[b], 0));
+    }
+    has_output_ = false;
+    DR_HIP(hipHostMalloc((void **)&h_in_, (size_t)V * H * W * 3, hipHostMallocDefault));
+    d_bgr_ = dalloc<uint8_t>((size_t)V * H * W * 3 + 16); misc_.push_back(d_bgr_);  // (+16: k_fn_front fetches a pixel as the two aligned words around it)
+    d_state_ = dalloc<unsigned>(16); misc_.push_back(d_state_);   // four 4-word slots (the fused-scan form keeps one per level)
+    d_hist_ = dalloc<unsigned>(3 * 2048); misc_.push_back(d_hist_);  // one histogram per level (the k_scan form uses the first only)
+    DR_HIP(hipMemset(d_hist_, 0, 3 * 2048 * 4));
+    DR_HIP(hipMemset(d_state_, 0, 16 * 4));
+
+    build_featurenet(V, H, W);
+    if (fcache_cap_ > 0) build_fn1(H, W);
 
     for (int s = 1; s <= 3; ++s) {
       const int sc = 1 << (3 - s), h = H / sc, w = W / sc, D = blob_.depth_num[s - 1], C = 32 >> (s - 1);
@@ -957,6 +1195,7 @@ class MvsEngine {
       DevTensor &k6 = cbr3(pre + "conv6", cr + "conv6", k5, 1, 1, CONV_NORMAL);
       DevTensor &x7 = dbr3(pre + "conv7", cr + "conv7", k6, four ? 1 : 2, k4);
       DevTensor &x9 = dbr3(pre + "conv9", cr + "conv9", x7, 2, k2);
+#ifdef DR_PARITY_HOOKS
       const HostTensor &w11 = blob_.at(cr + "conv11.conv.weight");
       const HostTensor &wpr = blob_.at(cr + "prob.weight");
       const bool tail = sw_.tail_fused && !sw_.prob_on_conv && !conv_bf3_policy() && w11.dims.size() == 5 && w11.dims[0] == 16 && w11.dims[1] == 8 && w11.dims[2] == 3 &&
@@ -983,7 +1222,9 @@ class MvsEngine {
         o.flops = 2.0 * 3.375 * 16 * 8 * N + 2.0 * 216 * N;  // the algorithmic MACs of both layers (halo recomputation not counted)
         o.bytes = 4.0 * (x9.n() + c0.n() + lg.n());
         ops_.push_back(o);
-      } else {
+      } else
+#endif
+      {
       DevTensor &x11 = dbr3(pre + "conv11", cr + "conv11", x9, 2, c0);
       if (sw_.prob_on_conv && w % 8 == 0) {
         // A/B hook: the Cout = 1 head as 8 x-shifts per column on the MFMA kernel (CONV_X8, 50 % of the rows carry work);
@@ -1137,6 +1378,8 @@ class MvsEngine {
       r.conf = T("conf" + std::to_string(s)).d;
       r.planes = p; r.h = h; r.w = w;
     }
+    for (int s = 0; s < 3; ++s) set_batch_vfeat(s);
+    if (fcache_cap_ > 0) plan_cache_use(H, W, V, bgrs, order);
     // quantile rank, computed in float32 like module.py:1348-1349
     const float hw = (float)(H * W);
     float cut = hw * (100.f - disc);
@@ -1155,7 +1398,9 @@ class MvsEngine {
   // regularisation, whose coarse UNet levels leave most CUs idle; stage 2 / 3's cost volume waits for feat2 / feat3.
   // The next forward's main-stream work is ordered after those waits, so the side stream never runs ahead of a reader.
   void forward(std::vector<hipEvent_t> *ev, size_t first = 0, size_t last = ~(size_t)0) {
-    const bool fork = side_enabled_ && !ev && first == 0 && last >= ops_.size() && fork_lo_ < fork_hi_;
+    const bool cached = fc_fast_ && first == 0 && last >= ops_.size();  // FeatureNet answered by the feature cache: its ops are skipped
+    const bool fork = side_enabled_ && !ev && first == 0 && last >= ops_.size() && fork_lo_ < fork_hi_ && !cached;
+    if (cached) forward_cached_features();
     // view shard, reduce-to-root form: between a stage's cost volume and its regression only rank 0 works
     const bool rooted = comm_ && shard_nsrc_ && !phase_mode_ && !sw_.shard_allreduce;
     bool idle_stage = false;
@@ -1165,6 +1410,7 @@ class MvsEngine {
       if (ev) DR_HIP(hipEventRecord((*ev)[i], stream_));
       ++i;
       if (i - 1 < first || i - 1 >= last) continue;
+      if (cached && i - 1 < fork_hi_) continue;
       if (idle_stage && o.kind != Op::REGRESS) continue;  // (CostRegNet and prob of this stage run on rank 0 only)
       const bool on_side = fork && i - 1 >= fork_lo_ && i - 1 < fork_hi_;
       if (fork && i - 1 == fork_lo_) { DR_HIP(hipEventRecord(ev_fork_, stream_)); DR_HIP(hipStreamWaitEvent(side_, ev_fork_, 0)); }
@@ -1240,7 +1486,9 @@ class MvsEngine {
           break;
         }
         case Op::TAIL:
+#ifdef DR_PARITY_HOOKS
           launch_tail(o.tail, stream_);
+#endif
           break;
         case Op::FRONT:
           launch_fn_front(o.front, stream_);
@@ -1385,6 +1633,7 @@ class MvsEngine {
       if (on_side && i - 1 == feat2_op_) DR_HIP(hipEventRecord(ev_feat2_, side_));
       if (on_side && i - 1 == fork_hi_ - 1) DR_HIP(hipEventRecord(ev_feat3_, side_));
     }
+    if (fc_fill_ && first == 0 && last >= ops_.size()) fill_cache_from_batch();
     if (ev) DR_HIP(hipEventRecord((*ev)[i], stream_));
     DR_HIP(hipGetLastError());
   }
@@ -1406,6 +1655,17 @@ class MvsEngine {
   hipEvent_t ev_fork_ = nullptr, ev_feat2_ = nullptr, ev_feat3_ = nullptr;
   bool side_enabled_ = true;
   size_t fork_lo_ = 0, fork_hi_ = 0, feat2_op_ = 0;  // ops [fork_lo_, fork_hi_) = fn.skip2 .. fn.out3
+  // key-frame feature cache (build_fn1 .. set_batch_vfeat)
+  int fcache_cap_ = 0;             // entries (0: off, the default)
+  std::vector<FcEntry> fcache_;
+  std::vector<Op> ops1_;           // FeatureNet for ONE view
+  std::vector<FnOut> fn1_out_;
+  std::string tprefix_;            // tensor-name prefix while ops1_ is built
+  bool fn1_ok_ = false;            // the single-view plan exists and matches the batch plan's instances
+  bool fc_fast_ = false, fc_fill_ = false;  // the staged window: answered by the cache (at most one view computed) / computed as a batch whose outputs fill the cache
+  int fc_miss_ = -1, fc_slot_[kMaxSrc + 1] = {};
+  int *fc_flag_ = nullptr;         // page-locked: raised by k_verify_image
+  uint64_t fc_clock_ = 0, fc_hits_ = 0, fc_misses_ = 0, fc_batch_windows_ = 0, fc_collisions_ = 0;
 
   const MvsSwitches sw_;  // read once, here
 #ifdef DR_PARITY_HOOKS
@@ -1485,6 +1745,10 @@ int drm_create(const char *weights_path, int device, drm_t **out) {
   });
 }
 void drm_destroy(drm_t *h) { delete h; }
+int drm_set_feature_cache(drm_t *h, int capacity) { return guarded([&] { eng(h)->set_feature_cache(capacity); }); }
+int drm_feature_cache_stats(drm_t *h, uint64_t out[6]) {
+  return guarded([&] { if (!out) dr::fail(DR_ERR_ARG, "drm_feature_cache_stats: null argument"); eng(h)->feature_cache_stats(out); });
+}
 int drm_call_async(drm_t *h, int height, int width, int view_num, int ref_index, const uint8_t *const *bgrs, const float *K9,
                    const float *const *c2ws, float depth_min, float depth_max, float discard_percentage) {
   return guarded([&] { eng(h)->call_async(height, width, view_num, ref_index, bgrs, K9, c2ws, depth_min, depth_max, discard_percentage); });
@@ -1618,6 +1882,9 @@ int drm_debug_tail(int device, const float *x, const float *skip, const float *w
                    int w, int qy, int zchunk, int form, float *out) {
   return guarded([&] {
     using namespace dr;
+#ifndef DR_PARITY_HOOKS
+    fail(DR_ERR_UNSUPPORTED, "drm_debug_tail: k_tail / k_tail_m are built into the parity library (libdr_mi355x_hooks.so, -DDR_PARITY_HOOKS) only");
+#else
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= device) fail(DR_ERR_DEVICE, "no HIP device %d", device);
     if (D <= 0 || h <= 0 || w <= 0 || (D | h | w) & 1) fail(DR_ERR_ARG, "drm_debug_tail: output dims must be positive and even");
@@ -1642,6 +1909,7 @@ int drm_debug_tail(int device, const float *x, const float *skip, const float *w
     DR_HIP(hipDeviceSynchronize());
     DR_HIP(hipGetLastError());
     DR_HIP(hipMemcpy(out, d_out, (size_t)D * h * w * 4, hipMemcpyDeviceToHost));
+#endif
   });
 }
 

@@ -31,6 +31,34 @@ __global__ void k_preprocess(const uint8_t *__restrict__ bgr, float4 *__restrict
   img[i] = make_float4(lut[p[2]], lut[p[1]], lut[p[0]], 0.f);
 }
 
+// Key-frame feature cache (dr_mvsnet.hip): a cache HIT is decided on the host from a sampled hash of the image; this kernel makes it exact -- the image just
+// uploaded is compared, 16 bytes per lane, with the copy the cache entry keeps; any difference raises *flag (page-locked host memory, read after the
+// window's stream synchronise: the engine then drops the cache and runs the window again without it).  The same launch files the window's NEW image
+// (blockIdx.y = its view) in the entry its features go to.
+struct CacheIoArgs {
+  const uint4 *img[kMaxSrc + 1];  // the window's images on the device, model order
+  uint4 *entry[kMaxSrc + 1];      // the cache entry's copy of each
+  int miss;                       // view that is copied instead of compared (-1: none)
+  int *flag;
+  size_t n16;
+};
+__global__ __launch_bounds__(256) void k_cache_io(const CacheIoArgs a) {
+  const int v = blockIdx.y;
+  const uint4 *__restrict__ x = a.img[v];
+  uint4 *__restrict__ y = a.entry[v];
+  const size_t nt = (size_t)gridDim.x * blockDim.x;
+  if (v == a.miss) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n16; i += nt) y[i] = x[i];
+    return;
+  }
+  bool diff = false;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n16; i += nt) {
+    const uint4 p = x[i], q = y[i];
+    diff |= (p.x != q.x) | (p.y != q.y) | (p.z != q.z) | (p.w != q.w);
+  }
+  if (__ballot(diff) != 0 && (threadIdx.x & 63) == 0) *a.flag = 1;
+}
+
 #ifdef DR_PARITY_HOOKS  // only the literal (unfolded) order of FeatureNet's stage-3 head uses this kernel
 // ------------------------------------------------------------------ FeatureNet skip connection
 // inter = nearest_up2(coarser) + conv1x1(x) + bias   (module.py:518-531: `F.interpolate(..., scale_factor=2) + skip(...)`).
@@ -126,6 +154,8 @@ __device__ inline float plane_depth(const PixelPlanes &pp, const PlaneArgs &p, i
 // ------------------------------------------------------------------ cost volume
 struct CostVolArgs {
   const float *feat;  // (V,h,w,C) channels-last, view 0 = reference
+  const float *vfeat[kMaxSrc + 1];  // k_costvol5: the (bordered) feature map of every view of the window by pointer -- feat + v * plane, or, with the key-frame
+                                    // feature cache (dr_mvsnet.hip), the cache entry that holds the image's features
   float *vol;         // (D,h,w,C)
   PlaneArgs planes;
   int V, h, w, dchunk;
@@ -568,11 +598,10 @@ __global__ __launch_bounds__(256) void k_costvol5(const CostVolArgs a) {
   const bool live = x < a.w && y < a.h;
   const int xc = min(x, a.w - 1), yc = min(y, a.h - 1);    // dead lanes keep running for the cross-lane gate sum
   const int h = a.h, w = a.w, nsrc = a.V - 1, wp = w + 2;
-  const size_t vplane = (size_t)(h + 2) * wp * C;  // floats per padded view
   const float fw = (float)w, fh = (float)h, xf = (float)xc, yf = (float)yc;
   if (nsrc <= 0) return;
 
-  const float4 ref = ld4(a.feat + ((size_t)(yc + 1) * wp + xc + 1) * C + q * 4);
+  const float4 ref = ld4(a.vfeat[0] + ((size_t)(yc + 1) * wp + xc + 1) * C + q * 4);
   const float4 gw = make_float4(a.gw[q * 4], a.gw[q * 4 + 1], a.gw[q * 4 + 2], a.gw[q * 4 + 3]);
   const PixelPlanes pp = make_planes(a.planes, yc, xc);
   const float rcp_n = 1.f / a.nsrc_f;
@@ -581,8 +610,7 @@ __global__ __launch_bounds__(256) void k_costvol5(const CostVolArgs a) {
   for (int b = 0; b < NB; ++b) dep[b] = plane_depth(pp, a.planes, d0 + b * LPB + qb);
   // byte offset of a sample's upper-left tap from pixel (-1, -1) of the padded view (never negative: ix, iy >= -1), this lane's channels included
   const unsigned obias = (unsigned)((wp + 1) * C + q * 4) * 4u;
-  const char *const f0 = reinterpret_cast<const char *>(a.feat);
-  const size_t vbytes = vplane * 4, rowbytes = (size_t)wp * C * 4;
+  const size_t rowbytes = (size_t)wp * C * 4;
 
   unsigned ob_prev = 0;
   // plane j of the batch: lane j's set-up, view v (uniform).  REUSE: where the sample's footprint is the one of the lane's previous plane (`prev`, same
@@ -590,7 +618,7 @@ __global__ __launch_bounds__(256) void k_costvol5(const CostVolArgs a) {
   auto gather = [&](const CvProj &P, int j, int v, CvTaps &T, const CvTaps &prev, bool first) {
     const unsigned ob = (unsigned)cv_bcast_i(P.o, LPB, j) * 4u + obias;
     T.w00 = cv_bcast_f(P.w00, LPB, j); T.w01 = cv_bcast_f(P.w01, LPB, j); T.w10 = cv_bcast_f(P.w10, LPB, j); T.w11 = cv_bcast_f(P.w11, LPB, j);
-    const char *r0 = f0 + (size_t)(v + 1) * vbytes, *r1 = r0 + rowbytes;  // wave-uniform bases: rows y0 and y0 + 1
+    const char *r0 = reinterpret_cast<const char *>(a.vfeat[v + 1]), *r1 = r0 + rowbytes;  // wave-uniform bases (a scalar load from the kernel arguments): rows y0 and y0 + 1
     if (REUSE && !first && ob == ob_prev) {
       T.t00 = prev.t00; T.t01 = prev.t01; T.t10 = prev.t10; T.t11 = prev.t11;
 #ifdef DR_PARITY_HOOKS

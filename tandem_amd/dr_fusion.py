@@ -47,14 +47,17 @@ class DrFusion:
         arr = (f32p * max(len(poses), 1))(*[fptr(p) for p in poses])
         check(self._L.drf_render_async(self._h, arr, len(poses)))
 
-    def GetRenderResult(self):
-        """dr_fusion.h:54: returns (bgr list, depth list); arrays are copies of the library-owned pinned buffers."""
+    def GetRenderResult(self, copy=True):
+        """dr_fusion.h:54: returns (bgr list, depth list).  copy=True: copies of the library-owned pinned buffers; copy=False: what the C++ member hands
+        out -- views of those buffers, valid until the NEXT GetRenderResult (tsdf_volume.cu:846-872, the "blocked" / "free" sets)."""
         n = self.options.num_render_streams
         pb, pd = (u8p * max(n, 1))(), (f32p * max(n, 1))()
         check(self._L.drf_get_render_result(self._h, pb, pd, n))
         H, W = self._hw
-        bgrs = [np.ctypeslib.as_array(pb[i], shape=(H, W, 3)).copy() for i in range(n)]
-        depths = [np.ctypeslib.as_array(pd[i], shape=(H, W)).copy() for i in range(n)]
+        bgrs = [np.ctypeslib.as_array(pb[i], shape=(H, W, 3)) for i in range(n)]
+        depths = [np.ctypeslib.as_array(pd[i], shape=(H, W)) for i in range(n)]
+        if copy:
+            bgrs, depths = [b.copy() for b in bgrs], [d.copy() for d in depths]
         return bgrs, depths
 
     def ExtractMeshAsync(self, lower_corner, upper_corner):

@@ -129,6 +129,17 @@ class DrMvsnet:
             np.frombuffer(_view(q, n, self._engine), np.float32).reshape(self._hw) for q in p]
         return out
 
+    def set_feature_cache(self, capacity):
+        """Extension (drm_set_feature_cache): keep FeatureNet's outputs of the last `capacity` key-frame images; a window of which at most one image is
+        new runs FeatureNet on that one view.  0 = off (the default).  Bit-identical results either way."""
+        check(self._L.drm_set_feature_cache(self._h, int(capacity)))
+
+    def feature_cache_stats(self):
+        out = (C.c_uint64 * 6)()
+        check(self._L.drm_feature_cache_stats(self._h, out))
+        return dict(views_from_cache=int(out[0]), views_computed=int(out[1]), batch_windows=int(out[2]), key_collisions=int(out[3]),
+                    single_view_plan=bool(out[4]), entries=int(out[5]))
+
     def alloc_images(self, view_num, height, width):
         """`view_num` (H, W, 3) u8 arrays in page-locked memory (drm_host_alloc): CallAsync uploads such images in place, without the
         gather into the engine's staging block.  The block is freed when the last of the arrays is gone."""

@@ -99,6 +99,8 @@ public:
   }
   // Page-locked memory for key-frame images: CallAsync uploads windows whose images ALL live in such memory in place, skipping the
   // gather into the engine's staging block (6.45 MB at 640 x 480 x 7).
+  // The key-frame feature cache (drm_set_feature_cache): FeatureNet runs on the window's NEW image only; call once after construction.  0 = off.
+  void SetFeatureCache(int key_frames) { check(drm_set_feature_cache(impl, key_frames)); }
   static unsigned char *AllocImage(size_t bytes) { return static_cast<unsigned char *>(drm_host_alloc(bytes)); }
   static void FreeImage(unsigned char *p) { drm_host_free(p); }
 

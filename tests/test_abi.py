@@ -82,6 +82,26 @@ def test_product_path_never_imports_the_oracle():
                 assert not re.search(r'#include\s*[<"][^>"]*oracle', txt), f
 
 
+def test_product_library_reads_only_the_documented_switches():
+    """every DR_* name the PRODUCT library can pass to getenv is one of the sixteen INTEGRATION.md lists; the superseded
+    generations and settled A/Bs are read through hook_env() (csrc/dr_common.h), i.e. by the parity build only, and their kernels
+    (k_tail, k_tail_m, k_conv_b, k_costvol / k_costvol4, ...) are not in the product's code object at all."""
+    import subprocess
+    lib = os.path.join(ROOT, "tandem_amd", "libdr_mi355x.so")
+    if not os.path.isfile(lib):
+        pytest.skip("library not built")
+    names = set(re.findall(r"^DR_[A-Z0-9_]+$", subprocess.run(["strings", lib], capture_output=True, text=True).stdout, re.M))
+    allowed = {"DR_RCCL_LIB", "DR_FUSION_PRIORITY", "DR_MVS_NO_SIDE_STREAM", "DR_CONV_PRINT", "DR_AUTOTUNE_ONLY", "DR_CONV_NO_TUNED", "DR_CONV_RANK", "DR_CONV_ASYNC",
+               "DR_CONV_MARCH", "DR_CONV_ROWMARCH", "DR_CONV_WINO", "DR_CV_DCHUNK1", "DR_CV_DCHUNK2", "DR_CV_DCHUNK3", "DR_PROB_ZCHUNK", "DR_HIST_BLOCKS"}
+    assert names == allowed, (sorted(names - allowed), sorted(allowed - names))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for n in allowed:
+        assert n in doc or (n.startswith("DR_CV_DCHUNK") and "DR_CV_DCHUNK1..3" in doc), n
+    syms = subprocess.run(["strings", lib], capture_output=True, text=True).stdout
+    for k in ("k_tail", "k_conv_b", "k_costvol4", "k_costvolILi"):
+        assert not re.search(r"_ZN2dr\d+%s" % k, syms), k
+
+
 def test_weight_blob_roundtrip(tmp_path):
     from tandem_amd import weights as Wt
     sd = Wt.random_state((48, 32, 8), seed=3)

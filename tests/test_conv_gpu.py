@@ -247,7 +247,7 @@ DECONV = [c for c in CASES if c[6]] + [
 
 @pytest.mark.parametrize("form", [0, 1, 2])
 @pytest.mark.parametrize("case", DECONV, ids=[c[0] for c in DECONV])
-def test_transposed_parity_forms(case, form, monkeypatch):
+def test_transposed_parity_forms(case, form, monkeypatch, parity_hooks):
     monkeypatch.setenv("DR_DECONV_FORM", str(form))
     for rank in range(0, 60, 3):
         monkeypatch.setenv("DR_CONV_RANK", str(rank))
@@ -265,7 +265,7 @@ UP2 = [
 
 
 @pytest.mark.parametrize("case", UP2, ids=[c[0] for c in UP2])
-def test_conv_over_upsampled_input(case, monkeypatch):
+def test_conv_over_upsampled_input(case, monkeypatch, parity_hooks):
     from tandem_amd.dr_mvsnet import debug_conv
     name, dims, cin, cout = case
     rng = np.random.RandomState(abs(hash(name)) % (2 ** 31))
@@ -287,7 +287,7 @@ def test_conv_over_upsampled_input(case, monkeypatch):
 # (profiles/r04_first_ab.txt): all cases green, so they are part of the suite.  The mode is never the headline (operands carry 16
 # mantissa bits, not 24): bench.py reports it as its own object.
 @pytest.mark.parametrize("case", [c for c in CASES if c[2] % 8 == 0], ids=[c[0] for c in CASES if c[2] % 8 == 0])
-def test_bf16x3_conv_matches_torch(case, monkeypatch, capfd):
+def test_bf16x3_conv_matches_torch(case, monkeypatch, capfd, parity_hooks):
     """Same layers, same torch fp32 reference; the bound is the three-term split's (tools/study_split_bf16.py: ~2^-16 per product,
     1e-5 of the value range measured on the emulation), and the error must be ABOVE fp32 reassociation -- or the fp32 kernel ran."""
     monkeypatch.setenv("DR_CONV_BF16X3", "1")
@@ -299,7 +299,7 @@ def test_bf16x3_conv_matches_torch(case, monkeypatch, capfd):
 
 
 @pytest.mark.parametrize("case", SWEEP, ids=[c[0] for c in SWEEP])
-def test_bf16x3_every_plan_candidate(case, monkeypatch):
+def test_bf16x3_every_plan_candidate(case, monkeypatch, parity_hooks):
     monkeypatch.setenv("DR_CONV_BF16X3", "1")
     _REF_CACHE.pop(case[0], None)
     for rank in range(0, 120, 1):

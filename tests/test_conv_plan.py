@@ -19,7 +19,8 @@ def conv_emul(tmp_path_factory):
         pytest.skip("needs hipcc to compile the host emulation")
     exe = tmp_path_factory.mktemp("conv_emul") / "conv_emul"
     subprocess.check_call([HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-Wno-unused-function",
-                           "-Wno-pass-failed", "-Wno-unused-result", os.path.join(ROOT, "tests", "cpp", "conv_emul.hip"), "-o", str(exe)])
+                           "-Wno-pass-failed", "-Wno-unused-result", "-DDR_PARITY_HOOKS",  # (the transposed layers' other forms and the bf16 x 3 plans exist in the parity build only)
+                           os.path.join(ROOT, "tests", "cpp", "conv_emul.hip"), "-o", str(exe)])
     return str(exe)
 
 

@@ -312,7 +312,7 @@ def test_fused_skip_equals_the_two_kernel_path(trained_blob, monkeypatch, parity
         assert np.array_equal(a.depth, b.depth) and np.array_equal(a.confidence, b.confidence)
 
 
-def test_fused_front_equals_the_three_kernel_path(trained_blob, monkeypatch):
+def test_fused_front_equals_the_three_kernel_path(trained_blob, monkeypatch, parity_hooks):
     """FeatureNet's first block (module.py:461-470; u8 -> float as dr_mvsnet.cpp:184-217) in one launch (k_fn_front, csrc/fn_front.h: the
     float image and conv0.0's output never leave the CU) against k_preprocess + the two convolution launches in their direct form: the same
     products in the same order, so `fn.conv0.1` agrees bit for bit wherever the direct plan keeps one accumulator per position tile (every
@@ -349,7 +349,7 @@ def test_fused_front_equals_the_three_kernel_path(trained_blob, monkeypatch):
             assert np.abs(fa - fb).max() <= 2e-6 * np.abs(fb).max(), (pb["fn.conv0.0"], pb["fn.conv0.1"], np.abs(fa - fb).max())
 
 
-def test_fused_head3_equals_the_four_launch_form(trained_blob, monkeypatch):
+def test_fused_head3_equals_the_four_launch_form(trained_blob, monkeypatch, parity_hooks):
     """FeatureNet's folded stage-3 head (module.py:480-485,524-529) in one launch (k_fn_head3, csrc/fn_head3.h: conv3x3(conv0; Wout . Wskip),
     the two row-parity phase layers over inter2 and the border term meet in one accumulator) against the four launches fn.out3a..d: the
     same three terms, their partial sums added in another order (and fn.out3a in the Winograd form there) -- fp32 reassociation, held to
@@ -381,7 +381,7 @@ def test_fused_head3_equals_the_four_launch_form(trained_blob, monkeypatch):
         assert np.abs(da - db).mean() < 1e-4
 
 
-def test_fewer_launches_at_the_tail_are_bit_identical(trained_blob, tmp_path, monkeypatch):
+def test_fewer_launches_at_the_tail_are_bit_identical(trained_blob, tmp_path, monkeypatch, parity_hooks):
     """Round 5's two launch reductions behind the last convolution, each against the form it replaces, bit for bit on every output:
     (1) the edge filter's radix select with every level's scan as the prologue of the kernel that follows it (k_hist_s / k_apply_s, 8 -> 5
     launches; module.py:1320-1361) -- integers only; (2) softmax / expectation / confidence in the launch that computes the logits where a
@@ -453,7 +453,7 @@ def test_fused_skip_on_the_marching_kernel(trained_blob, monkeypatch, parity_hoo
         assert np.abs(fa - fb).max() <= 2e-5 * np.abs(fb).max()
 
 
-def test_register_regression_equals_the_three_pass_kernel(trained_blob, tmp_path, monkeypatch):
+def test_register_regression_equals_the_three_pass_kernel(trained_blob, tmp_path, monkeypatch, parity_hooks):
     """Round 3's k_regress_r<D> (the pixel's logits in registers, one round of loads) against the three-pass k_regress: same
     expressions in the same order -- at plane counts with a register instance (48/32/8, 48/4/4) and without (16/8/8: the generic
     kernel either way): all four output maps equal bit for bit (both kernels take the exponential through expf_value(), which
@@ -523,7 +523,7 @@ def test_folded_out_stage3_equals_the_literal_order(trained_blob, monkeypatch, p
 
 
 @pytest.mark.parametrize("views", [2, 3, 4, 6, 7])
-def test_shared_setup_cost_volume_is_bit_identical(trained_blob, tmp_path, monkeypatch, views):
+def test_shared_setup_cost_volume_is_bit_identical(trained_blob, tmp_path, monkeypatch, views, parity_hooks):
     """k_costvol3 (the lanes of a pixel take different (plane, view) samples of a batch, set them up once and hand the tap offset
     and weights round by DPP) against k_costvol2 (every lane sets up every sample): same products in the same order, so the
     three cost volumes are equal bit for bit -- 1 to 6 source views (batches that straddle planes), view aggregation and plain
@@ -647,7 +647,7 @@ def test_lds_staged_cost_volume_is_bit_identical(trained_blob, monkeypatch, view
 
 # ---- the opt-in bf16 x 3 precision mode (csrc/conv_bf3.h, DR_CONV_BF16X3=1; first run on a GPU in round 4: green) ----
 @pytest.mark.parametrize("path", [p for p in GOLD if "rand" not in p and "novar" not in p], ids=lambda p: os.path.basename(p))
-def test_bf16x3_mode_stays_inside_the_fp32_bounds(path, trained_blob, tmp_path, monkeypatch):
+def test_bf16x3_mode_stays_inside_the_fp32_bounds(path, trained_blob, tmp_path, monkeypatch, parity_hooks):
     """With every convolution (Cin % 8 == 0) on k_conv_b the depth maps must still pass the bounds the fp32 path is held to -- what
     tools/study_split_bf16.py predicts from the oracle (mean 2e-5 m, max 2e-4 m) -- and must differ from the fp32 engine's."""
     from tandem_amd.dr_mvsnet import DrMvsnet
@@ -735,3 +735,75 @@ def test_pinned_upload_and_result_view_equal_the_copying_boundary(trained_blob):
     v3 = m.GetResult()
     assert np.array_equal(v3.depth_dense, ref.depth_dense)
     m.close()
+
+
+# ---- the key-frame feature cache (round 6; drm_set_feature_cache) ----
+def _sliding_windows(h, w, n_windows, seed):
+    """A synthetic sliding key-frame sequence: 7 + n_windows - 1 images of one scene with their poses; window k = images k .. k + 6 (six of them were
+    in window k - 1), reference = the second newest, as TANDEM builds it (FullSystem.cpp:1127)."""
+    from synth import scene
+    big = scene.make_window(h, w, 7 + n_windows - 1, seed=seed)
+    for k in range(n_windows):
+        yield dict(bgrs=[np.ascontiguousarray(b) for b in big["bgrs"][k:k + 7]], c2ws=list(big["c2ws"][k:k + 7]), K=big["K"], ref_index=5)
+
+
+@pytest.mark.parametrize("h,w", [(96, 160), (224, 352)])
+def test_feature_cache_is_bit_identical(trained_blob, h, w):
+    """Cache on against cache off over a sliding sequence: every window's four maps are equal bit for bit (the single-view FeatureNet plan is built
+    from the batch plan's own kernel instances); the first window takes the batch path and fills the cache, every later window computes ONE view;
+    a change of resolution evicts everything and the cache works again at the new shape."""
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    a, b = DrMvsnet(trained_blob), DrMvsnet(trained_blob)
+    b.set_feature_cache(12)
+    n = 5
+    for shape in ((h, w), (64, 96), (h, w)):
+        before = b.feature_cache_stats()
+        for k, win in enumerate(_sliding_windows(shape[0], shape[1], n, seed=31)):
+            outs = []
+            for m in (a, b):
+                m.CallAsync(shape[0], shape[1], 7, win["ref_index"], win["bgrs"], win["K"], win["c2ws"], 0.5, 5.0, 10.0)
+                outs.append(m.GetResult())
+            for name in ("depth", "confidence", "depth_dense", "confidence_dense"):
+                x, y = getattr(outs[0], name), getattr(outs[1], name)
+                assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (shape, k, name, np.abs(x - y).max())
+        st = b.feature_cache_stats()
+        assert st["single_view_plan"] and st["key_collisions"] == 0
+        assert st["batch_windows"] - before["batch_windows"] == 1, st                      # the first window of a shape
+        assert st["views_from_cache"] - before["views_from_cache"] == 6 * (n - 1), st      # six hits in each of the others
+        assert st["views_computed"] - before["views_computed"] == 7 + (n - 1), st
+    assert a.feature_cache_stats()["views_from_cache"] == 0
+    a.close(); b.close()
+
+
+def test_feature_cache_catches_a_key_collision(trained_blob):
+    """The cache's key samples the image (first / last 64 bytes + 512 evenly spaced words); a hit is made exact by the device compare.  An image that
+    differs from a cached one ONLY in bytes the key does not sample finds that entry -- the compare must notice, and the window's result must be the
+    one of an engine without a cache."""
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    h, w = 96, 160
+    wins = list(_sliding_windows(h, w, 2, seed=33))
+    a, b = DrMvsnet(trained_blob), DrMvsnet(trained_blob)
+    b.set_feature_cache(10)
+    args = lambda win: (h, w, 7, win["ref_index"], win["bgrs"], win["K"], win["c2ws"], 0.5, 5.0, 10.0)  # noqa: E731
+    b.CallAsync(*args(wins[0])); b.GetResult()
+    win = dict(wins[1])
+    forged = [x.copy() for x in win["bgrs"]]
+    n = h * w * 3
+    step = (n // 512) & ~7
+    flat = forged[2].reshape(-1)
+    assert step >= 40
+    flat[200 * step + 16: 200 * step + 32] ^= 0x5A  # between two sampled words (200 * step and 201 * step), away from the first and last 64 bytes
+    win["bgrs"] = forged
+    outs = []
+    for m in (a, b):
+        m.CallAsync(*args(win))
+        outs.append(m.GetResult())
+    st = b.feature_cache_stats()
+    assert st["key_collisions"] == 1, st
+    for name in ("depth", "confidence", "depth_dense", "confidence_dense"):
+        assert np.array_equal(getattr(outs[0], name).view(np.uint32), getattr(outs[1], name).view(np.uint32)), name
+    # ... and the engine goes on: the next window is computed as a batch and fills the cache again
+    b.CallAsync(*args(wins[1])); r = b.GetResult()
+    a.CallAsync(*args(wins[1])); r0 = a.GetResult()
+    assert np.array_equal(r.depth_dense.view(np.uint32), r0.depth_dense.view(np.uint32))
+    a.close(); b.close()

@@ -26,7 +26,7 @@ def reference(x, skip, wd, scale, bias, wp):
     (2, 2, 2, 8, 0),                               # the smallest volume: one input position
 ])
 @pytest.mark.parametrize("form", [1, 0])
-def test_tail_matches_torch(D, h, w, qy, zchunk, form):
+def test_tail_matches_torch(D, h, w, qy, zchunk, form, parity_hooks):
     if form == 1 and qy == 32:
         pytest.skip("k_tail_m works on groups of 16 cells along x: no 32 x 8 tile")
     from tandem_amd.dr_mvsnet import debug_tail
@@ -43,7 +43,7 @@ def test_tail_matches_torch(D, h, w, qy, zchunk, form):
     assert err <= 2e-5 * np.abs(ref).max(), f"max err {err} of range {np.abs(ref).max()} (form {form}, qy {qy}, zchunk {zchunk})"
 
 
-def test_tail_fused_and_two_kernel_paths_agree(trained_blob, monkeypatch):
+def test_tail_fused_and_two_kernel_paths_agree(trained_blob, monkeypatch, parity_hooks):
     """The engine with k_tail (DR_TAIL_FUSED=1, opt-in) against the default two-kernel path (transposed convolution on the MFMA kernel, then k_prob2):
     every stage's depth map within fp32 reassociation of each other, on a fixture-sized window."""
     from synth import scene

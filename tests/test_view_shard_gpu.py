@@ -214,8 +214,12 @@ def test_engine_collective_with_several_ranks_on_one_gpu(world, allreduce, tmp_p
     script = str(tmp_path / "rank.py")
     open(script, "w").write(_RANK_SCRIPT)
     env = dict(os.environ, DR_RCCL_LIB=stub)
-    if allreduce:
+    if allreduce:  # round 2's form lives in the parity build: the rank processes load that library
+        from tandem_amd import _lib
+        if not os.path.isfile(_lib.HOOKS_LIB_PATH):
+            pytest.skip("tandem_amd/libdr_mi355x_hooks.so not built")
         env["DR_SHARD_ALLREDUCE"] = "1"
+        env["DR_MI355X_LIB"] = _lib.HOOKS_LIB_PATH
     procs = [subprocess.Popen([sys.executable, script, str(r), str(world), str(tmp_path), trained_blob, str(H), str(W), str(V), root], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
     for p in procs:

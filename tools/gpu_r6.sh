@@ -35,6 +35,14 @@ for step in "$@"; do
       export DR_MI355X_LIB=$PWD/tandem_amd/libdr_mi355x_hooks.so DR_OPS_RANGE=0.01,10 
       for abl in 0 1 2 4 3 5 7; do echo "DR_CV5_ABL=$abl (1 no gathers, 2 no stores, 4 no tap arithmetic): $(DR_CV5_ABL=$abl timeout 300 python tools/profile_ops.py "costvol" 2>&1 | tail -1)"; done | tee $OUT/${TAG}_costvol_abl.txt
       unset DR_MI355X_LIB DR_OPS_RANGE ;;
+    tsdf16m)  # SURVEY 8(d)'s fusion configuration once: a pool of 16 M voxel blocks (64 GB), everything else as the bench runs it
+      timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-boundary --no-loop --no-tsdf-native --no-tsdf-boundary --tsdf-blocks 16000000 > $OUT/${TAG}_bench_tsdf16m.json 2> $OUT/${TAG}_bench_tsdf16m.err
+      python -c "import json; d=json.load(open('$OUT/${TAG}_bench_tsdf16m.json'))['tsdf']; print({k: d[k] for k in ('value','ms_per_frame','blocks','kernel_ms_per_frame')}); print(d['config']['workload'][:400])" ;;
+    tests_fc) timeout 1200 python -m pytest tests/test_mvsnet_gpu.py -m gpu -x -q -k "feature_cache or golden" > $OUT/${TAG}_gpu_tests_fc.log 2>&1; tail -15 $OUT/${TAG}_gpu_tests_fc.log ;;
+    fc_time) timeout 600 python tools/time_feature_cache.py 2>&1 | tee $OUT/${TAG}_feature_cache_time.txt ;;
+    loop_sliding)  # the TandemBackend loop on a sliding window, feature cache off / on
+      timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-tsdf --no-boundary > $OUT/${TAG}_bench_loop.json 2> $OUT/${TAG}_bench_loop.err
+      python -c "import json; d=json.load(open('$OUT/${TAG}_bench_loop.json'))['tandem_loop']; print({k: (v.get('keyframes_per_s'), v.get('mean_ms')) for k, v in d.items() if isinstance(v, dict) and 'keyframes_per_s' in v}); print(json.dumps(d.get('sliding_window'), indent=1))" ;;
     tests_cv) timeout 1200 python -m pytest tests/test_mvsnet_gpu.py -m gpu -x -q -k "cost_volume or golden" > $OUT/${TAG}_gpu_tests_cv.log 2>&1; tail -5 $OUT/${TAG}_gpu_tests_cv.log ;;
     tests) timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/${TAG}_gpu_tests.log 2>&1; tail -5 $OUT/${TAG}_gpu_tests.log ;;
     tests_fast) timeout 1200 python -m pytest tests -m gpu -x -q -k "${DR_TESTS_K:-mvsnet or conv}" > $OUT/${TAG}_gpu_tests_fast.log 2>&1; tail -5 $OUT/${TAG}_gpu_tests_fast.log ;;
@@ -107,7 +115,7 @@ PY
     ops) timeout 600 python tools/profile_ops.py > $OUT/${TAG}_ops.txt 2>&1; tail -4 $OUT/${TAG}_ops.txt ;;
     pmc)  # counters in their own passes (--kernel-trace only), strictly sequential kernels (one engine, side stream off) -> profiles/r06_pmc_traffic.json, stamped with this tree's source hash
       export DR_MVS_NO_SIDE_STREAM=1
-      S="--no-cpu --engines 1 --no-boundary --no-loop --no-tsdf-native"; A="--steps 3 --warmup 1 --tsdf-frames 60 $S"
+      S="--no-cpu --engines 1 --no-boundary --no-loop --no-tsdf-native --no-tsdf-boundary"; A="--steps 3 --warmup 1 --tsdf-frames 60 $S"
       rm -rf $OUT/pm1 $OUT/pm2 $OUT/pm3 $OUT/pm4
       timeout 600 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pm1 -o pmc -- python bench.py $A > $OUT/pm1.log 2>&1
       timeout 600 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pm2 -o pmc -- python bench.py $A > $OUT/pm2.log 2>&1
@@ -120,7 +128,7 @@ PY
     shipped) timeout 600 python bench.py --config shipped --steps 240 --no-tsdf --no-loop --no-cpu > $OUT/${TAG}_bench_shipped.json 2> $OUT/${TAG}_bench_shipped.err; head -c 300 $OUT/${TAG}_bench_shipped.json; echo ;;
     prof_seq)  # per-kernel durations without overlap: one engine, side stream off
       rm -rf $OUT/prof
-      DR_MVS_NO_SIDE_STREAM=1 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python bench.py --steps 20 --warmup 3 --tsdf-frames 200 --no-cpu --engines 1 --no-boundary --no-loop --no-tsdf-native > $OUT/${TAG}_bench_prof.json 2> $OUT/prof.err
+      DR_MVS_NO_SIDE_STREAM=1 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python bench.py --steps 20 --warmup 3 --tsdf-frames 200 --no-cpu --engines 1 --no-boundary --no-loop --no-tsdf-native --no-tsdf-boundary > $OUT/${TAG}_bench_prof.json 2> $OUT/prof.err
       python tools/rocprof_summary.py $(find $OUT/prof -name "*_results.db" | head -1) > $OUT/${TAG}_bench_kernel_stats.txt 2>&1; head -14 $OUT/${TAG}_bench_kernel_stats.txt; rm -rf $OUT/prof ;;
     prof_driver)  # the same under the driver's own command (three engines in flight)
       rm -rf $OUT/prof

@@ -9,7 +9,12 @@
 // reads the tracking depth map under its mutex the way CoarseTracker::makeCoarseDepthL0 does (CoarseTracker.cpp:655-668).
 // Everything between those calls and the GPU -- GetResult(k-1), CallAsync(k), IntegrateScanAsync / RenderAsync / GetRenderResult
 // of k-1, the A/B depth-map swap, the mesh every mesh_freq-th call, the output-wrapper pushes -- is the reference's code.
-//   usage: tandem_backend_run <weights.tdmw> <window.tdms> <keyframes> [voxel_size=0.01] [mesh_freq=0] [dense_tracking=1]
+//   usage: tandem_backend_run <weights.tdmw> <window.tdms> <keyframes> [voxel_size=0.01] [mesh_freq=0] [dense_tracking=1] [sliding=0] [feature_cache=0]
+// sliding = 1: the window SLIDES as TANDEM's does -- key frame k's window is the previous one without its oldest image plus one NEW image
+// (FullSystem.cpp:1159-1173 pushes the active key frames; one is marginalised, one is added): the stored window's seven views are used
+// cyclically with their own poses (any subset of them is a consistent multi-view set), and the image that enters the window is made a new
+// image -- its first 16 bytes carry the key-frame number -- so six of the seven images of a window were in the one before and one never was.
+// feature_cache = n > 0: DrMvsnet::SetFeatureCache(n) (extension of this library: FeatureNet runs on the new image only).
 // Prints ONE JSON line.
 #include <chrono>
 #include <cmath>
@@ -44,6 +49,8 @@ int main(int argc, char **argv) {
   const float voxel = argc > 4 ? (float) atof(argv[4]) : 0.01f;   // FullSystem.cpp:260
   const int mesh_freq = argc > 5 ? atoi(argv[5]) : 0;
   const bool dense_tracking = argc > 6 ? atoi(argv[6]) != 0 : true;
+  const bool sliding = argc > 7 ? atoi(argv[7]) != 0 : false;
+  const int feature_cache = argc > 8 ? atoi(argv[8]) : 0;
   FILE *f = fopen(argv[2], "rb");
   if (!f) { fprintf(stderr, "cannot open %s\n", argv[2]); return 2; }
   char magic[8]; int hdr[4]; float sc[3], K[9];
@@ -57,6 +64,7 @@ int main(int argc, char **argv) {
 
   // FullSystem::initDr (FullSystem.cpp:255-290): the two operators, then the back-end that owns the call order
   DrMvsnet *mvsnet = new DrMvsnet(argv[1]);
+  if (feature_cache > 0) mvsnet->SetFeatureCache(feature_cache);
   DrFusionOptions o;
   o.voxel_size = voxel; o.num_buckets = 1000000; o.bucket_size = 10; o.num_blocks = 1000000; o.block_size = 8; o.max_sdf_weight = 64;
   o.truncation_distance = 4 * voxel; o.max_sensor_depth = 10.f; o.min_sensor_depth = 0.1f; o.num_render_streams = dense_tracking ? 1 : 0;
@@ -81,7 +89,12 @@ int main(int argc, char **argv) {
     // deliverDrFrame builds them (FullSystem.cpp:1159-1173): images are views of the frames' buffers, poses are owned 4x4 floats
     const float ang = 0.01f * k, cs = std::cos(ang), sn = std::sin(ang), tx = 0.04f * k;
     std::vector<cv::Mat> bgrs_in, c2ws_in;
-    for (int v = 0; v < V; v++) {
+    if (sliding) {  // the image entering the window (its last position) has never been seen: stamp the key-frame number into it
+      unsigned char *fresh = img.data() + (size_t) ((k + V - 1) % V) * npx * 3;
+      for (int b = 0; b < 16; b++) fresh[b] = (unsigned char) ((k >> (8 * (b & 3))) ^ (37 * b));
+    }
+    for (int p = 0; p < V; p++) {
+      const int v = sliding ? (k + p) % V : p;  // stored view at window position p
       bgrs_in.emplace_back(H, W, CV_8U, img.data() + (size_t) v * npx * 3);
       c2ws_in.emplace_back(4, 4, CV_32F);
       const float *a = c2w0.data() + 16 * v;
@@ -114,12 +127,12 @@ int main(int argc, char **argv) {
   backend->Wait();
   fusion->Synchronize();
   const double total = ms_since(t_begin);
-  printf("{\"driver\": \"reference tandem_backend.cpp, unchanged\", \"keyframes\": %d, \"keyframes_per_s\": %.3f, \"ms_per_keyframe\": %.4f, "
+  printf("{\"driver\": \"reference tandem_backend.cpp, unchanged\", \"sliding_window\": %d, \"feature_cache\": %d, \"keyframes\": %d, \"keyframes_per_s\": %.3f, \"ms_per_keyframe\": %.4f, "
          "\"height\": %d, \"width\": %d, \"views\": %d, \"voxel_size\": %g, \"dense_tracking\": %d, \"mesh_every\": %d, "
          "\"mean_ms\": {\"backend_wait\": %.4f, \"backend_CallAsync\": %.4f, \"tracking_map_read\": %.4f, \"IntegrateScanAsync\": %.4f, \"fusion_mesh\": %.4f}, "
          "\"pushed\": {\"images\": %d, \"depth_maps\": %d, \"meshes\": %d, \"last_mesh_vertices\": %zu}, \"tracking_maps_valid\": %d, "
          "\"tracked_sample\": %zu, \"last_depth_sample_sum\": %.3f}\n",
-         n_kf, 1e3 * n_kf / total, total / n_kf, H, W, V, voxel, (int) dense_tracking, mesh_freq, t_wait / n_kf, t_call / n_kf, t_track / n_kf,
+         (int) sliding, feature_cache, n_kf, 1e3 * n_kf / total, total / n_kf, H, W, V, voxel, (int) dense_tracking, mesh_freq, t_wait / n_kf, t_call / n_kf, t_track / n_kf,
          dr_timer.mean_timing("IntegrateScanAsync"), dr_timer.mean_timing("fusion-mesh"), wrapper.images, wrapper.depths, wrapper.meshes,
          wrapper.last_mesh_vertices, valid_maps, tracked, wrapper.depth_sum);
   fflush(stdout);
