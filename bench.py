@@ -821,7 +821,7 @@ def main():
     ap.add_argument("--no-boundary", action="store_true", help="skip the operator-boundary (CallAsync/GetResult) leg")
     ap.add_argument("--no-loop", action="store_true", help="skip the TandemBackend-shaped loop leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
-    ap.add_argument("--engines", type=int, default=3, help="DrMvsnet engines (independent windows in flight) per GPU; 1 = latency configuration")
+    ap.add_argument("--engines", type=int, default=4, help="DrMvsnet engines (independent windows in flight) per GPU; 1 = latency configuration")
     ap.add_argument("--no-tsdf", action="store_true")
     ap.add_argument("--no-tsdf-native", action="store_true", help="skip the extra TSDF run at the reference's native 1 cm / 4 cm setting (profiling runs: keeps "
                                                                    "per-kernel averages to the 5 mm loop the roofline is quoted on)")

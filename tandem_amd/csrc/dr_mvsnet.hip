@@ -813,12 +813,22 @@ class MvsEngine {
   }
   // FeatureNet's first block: u8 BGR -> RGB0 / 255, conv0.0 (3 -> 8), conv0.1 (8 -> 8), both 3x3 + BN + ReLU (module.py:461-470).  One launch
   // (k_fn_front, fn_front.h) when the weights have that shape; DR_FN_FRONT=0, the bf16x3 mode and any other shape keep the three launches.
+  // the fused FeatureNet kernels need 55 KB / 133.5 KB of dynamic LDS per workgroup: plan them only where the device grants that much to one
+  // workgroup (on a part with less the launch would be rejected in every forward while the multi-launch forms still exist)
+  bool lds_fits(size_t bytes) const {
+    int optin = 0;
+    if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, device_) != hipSuccess || optin <= 0) {
+      (void)hipGetLastError();
+      if (hipDeviceGetAttribute(&optin, hipDeviceAttributeMaxSharedMemoryPerBlock, device_) != hipSuccess) { (void)hipGetLastError(); return false; }
+    }
+    return (size_t)optin >= bytes;
+  }
   DevTensor &front_block(const std::string &fn, int V, int H, int W) {
     const HostTensor &wa = blob_.at(fn + "conv0.0.conv.weight"), &wb = blob_.at(fn + "conv0.1.conv.weight");
     const bool shape_ok = wa.dims.size() == 4 && wa.dims[0] == 8 && wa.dims[1] == 3 && wa.dims[2] == 3 && wa.dims[3] == 3 &&
                           wb.dims.size() == 4 && wb.dims[0] == 8 && wb.dims[1] == 8 && wb.dims[2] == 3 && wb.dims[3] == 3;
     const bool fits32 = (double)V * H * W * 32.0 < 2147483648.0 && ((uintptr_t)d_bgr_ & 3) == 0;  // (the kernel addresses both tensors with 32-bit byte offsets from an aligned base)
-    if (!sw_.fn_front || conv_bf3_policy() || !shape_ok || !fits32) {
+    if (!sw_.fn_front || conv_bf3_policy() || !shape_ok || !fits32 || !lds_fits(kFrontLdsBytes)) {
       DevTensor &img = alloc("image", V, H, W, 4);
       { Op o; o.kind = Op::PREPROCESS; o.name = "preprocess"; o.bytes = (double)V * H * W * (3 + 16); ops_.push_back(o); }
       DevTensor &c3a = cbr2("fn.conv0.0", fn + "conv0.0", img, 3, 1, CONV_XPAIR);
@@ -916,7 +926,7 @@ class MvsEngine {
         }
       for (int co = 0; co < 8; ++co) { double b = 0; for (int t = 0; t < 9; ++t) b += (double)T[t * 8 + co]; bint[co] = (float)b; }
       DevTensor &f3 = alloc("feat3", c3.D, c3.H, c3.W, 8, fpad);
-      if (sw_.fn_head3 && !conv_bf3_policy() && (double)f3.n() * 4.0 < 2147483648.0 && (double)i2.n() * 4.0 < 2147483648.0) {  // one launch: the three terms meet in one accumulator (fn_head3.h)
+      if (sw_.fn_head3 && !conv_bf3_policy() && (double)f3.n() * 4.0 < 2147483648.0 && (double)i2.n() * 4.0 < 2147483648.0 && lds_fits(kH3LdsBytes)) {  // one launch: the three terms meet in one accumulator (fn_head3.h)
         Op o; o.kind = Op::HEAD3; o.name = "fn.head3";
         Head3Args &a = o.head3;
         a.c0 = c3.d; a.i2 = i2.d;

@@ -50,6 +50,9 @@ class _Owned:
         self._release, self.what = release, what
 
     def __del__(self):
+        self.release_now()
+
+    def release_now(self):
         rel, self._release = self._release, None
         if rel is not None:
             rel(self.what)
@@ -72,11 +75,17 @@ class DrMvsnet:
         self._engine = _Owned(lambda h: L.drm_destroy(h), C.c_void_p(self._h.value))  # result views hold a reference to it
         self._hw = None
 
-    def close(self):
+    def close(self, force=False):
         """Drops the engine.  It is destroyed now unless result views (GetResultView) are still alive -- then when the last of them
-        goes; page-locked image blocks (alloc_images) likewise live as long as their arrays."""
+        goes (the garbage collector decides when: device memory and streams of a closed engine can outlive this call); page-locked image
+        blocks (alloc_images) likewise live as long as their arrays.  force=True destroys the engine NOW: views handed out earlier then point
+        into freed page-locked memory and must not be touched again."""
+        eng = getattr(self, "_engine", None)
+        if force and eng is not None:
+            eng.release_now()
         self._h = C.c_void_p()
         self._engine = None
+        self._next_out = None
 
     __del__ = close
 
@@ -90,6 +99,7 @@ class DrMvsnet:
         self._hw = (height, width)
         # the object GetResult() will return: allocated and its pages touched NOW, while the device works on the window (as the C++ shim does:
         # the first-touch page faults of 4.9 MB of fresh result memory otherwise sit inside GetResult, on the caller's critical path)
+        # (one object per call: GetResult() hands the previous one over to the caller, who keeps it -- TandemBackend never deletes its outputs)
         nxt = getattr(self, "_next_out", None)
         if nxt is None or (nxt.height, nxt.width) != (height, width):
             nxt = DrMvsnetOutput(height, width)

@@ -102,7 +102,7 @@ PY
         python -c "import json; d=json.load(open('$OUT/${TAG}_bench_fnq.json')); print('value %.1f /s  ms_per_step %.3f  single_window %.3f ms' % (d['value'], d['ms_per_step'], d['single_window_ms']))"
       done | tee -a $OUT/${TAG}_fn_quick.txt ;;
     engines)  # windows in flight: 2 / 3 / 4 engines (the quick bench line each)
-      for n in 3 4 2 3 4; do
+      for n in ${DR_ENGINES_LIST:-3 4 2 3 4}; do
         timeout 600 python bench.py --gpus 1 --steps 60 --warmup 5 --engines $n --no-cpu --no-loop --no-boundary --no-tsdf > $OUT/${TAG}_bench_eng.json 2> $OUT/${TAG}_bench_eng.err
         python -c "import json; d=json.load(open('$OUT/${TAG}_bench_eng.json')); print('engines $n: value %.1f /s  ms_per_step %.3f' % (d['value'], d['ms_per_step']))"
       done | tee $OUT/${TAG}_engines.txt ;;
