@@ -649,8 +649,13 @@ def test_lds_staged_cost_volume_is_bit_identical(trained_blob, monkeypatch, view
 @pytest.mark.parametrize("path", [p for p in GOLD if "rand" not in p and "novar" not in p], ids=lambda p: os.path.basename(p))
 def test_bf16x3_mode_stays_inside_the_fp32_bounds(path, trained_blob, tmp_path, monkeypatch, parity_hooks):
     """With every convolution (Cin % 8 == 0) on k_conv_b the depth maps must still pass the bounds the fp32 path is held to -- what
-    tools/study_split_bf16.py predicts from the oracle (mean 2e-5 m, max 2e-4 m) -- and must differ from the fp32 engine's."""
+    tools/study_split_bf16.py predicts from the oracle (mean 2e-5 m, max 2e-4 m) -- and must differ from the fp32 engine's.
+    Run with strictly sequential kernels (DR_MVS_NO_SIDE_STREAM): round 6 found that this parity-build-only mode is NOT bit-stable from run to run
+    when its unfused FeatureNet head launches overlap the stage-1 plane sweep (tools/study/determinism.py: the stage-1 volume differs in ~50 voxels per
+    run, enough to move one pixel by 5-10 mm and trip the pairwise bound below); sequentially it is, and the fp32 product path is bit-stable either way
+    (16 of 16 runs, same script).  The mode left the product library in round 6; the interaction was not pursued."""
     from tandem_amd.dr_mvsnet import DrMvsnet
+    monkeypatch.setenv("DR_MVS_NO_SIDE_STREAM", "1")
     g = np.load(path)
     blob = blob_for(g, trained_blob, tmp_path)
     bgrs = [np.ascontiguousarray(b) for b in g["bgrs"]]
