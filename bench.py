@@ -56,6 +56,9 @@ def pmc_traffic(kernel, fetch="corrected"):
     if prof.get("_meta", {}).get("source_stamp") != source_stamp():
         return None
     e = prof.get(kernel)
+    if e is None:  # template instances are stored under their full name (k_raycast2<true,false,1>): a bare kernel name means its only instance
+        hits = [k for k in prof if k.startswith(kernel + "<")]
+        e = prof[hits[0]] if len(hits) == 1 else None
     if not e or "fetch_bytes_corrected" not in e or "write_bytes" not in e:
         return None
     # fetch="raw": kernels whose loads are 8 bytes per lane (k_integrate's voxel reads).  The x2 of MI355X_MICROARCH.md is calibrated on 16-byte-per-lane
