@@ -1052,7 +1052,7 @@ class MvsEngine {
   // decides, for the window being staged, which views the cache answers.  fc_slot_[v]: the entry that holds (or will hold) view v's features.
   void plan_cache_use(int H, int W, int V, const uint8_t *const *bgrs, const std::vector<int> &order) {
     fc_fast_ = false; fc_fill_ = false; fc_miss_ = -1;
-    if (!fn1_ok_ || (int)fcache_.size() < V + 1) return;
+    if (!fn1_ok_ || (int)fcache_.size() < V + 1 || shard_nsrc_ || comm_ || phase_mode_) return;  // (a view-shard rank computes its own views every time)
     for (int s = 1; s <= 3; ++s) if (!cv5_applies(s)) return;  // (only k_costvol5 reads the views by pointer)
     const size_t img_bytes = (size_t)H * W * 3;
     uint64_t keys[8][2];
@@ -1408,7 +1408,11 @@ class MvsEngine {
   // regularisation, whose coarse UNet levels leave most CUs idle; stage 2 / 3's cost volume waits for feat2 / feat3.
   // The next forward's main-stream work is ordered after those waits, so the side stream never runs ahead of a reader.
   void forward(std::vector<hipEvent_t> *ev, size_t first = 0, size_t last = ~(size_t)0) {
-    const bool cached = fc_fast_ && first == 0 && last >= ops_.size();  // FeatureNet answered by the feature cache: its ops are skipped
+    if ((fc_fast_ || fc_fill_) && !(first == 0 && last >= ops_.size())) {  // a partial forward (phases, one op) cannot skip FeatureNet: the window goes back to the batch path
+      fc_fast_ = fc_fill_ = false;
+      for (int s = 0; s < 3; ++s) set_batch_vfeat(s);
+    }
+    const bool cached = fc_fast_;  // FeatureNet answered by the feature cache: its ops are skipped
     const bool fork = side_enabled_ && !ev && first == 0 && last >= ops_.size() && fork_lo_ < fork_hi_ && !cached;
     if (cached) forward_cached_features();
     // view shard, reduce-to-root form: between a stage's cost volume and its regression only rank 0 works
