@@ -43,6 +43,14 @@ for step in "$@"; do
     loop_sliding)  # the TandemBackend loop on a sliding window, feature cache off / on
       timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-tsdf --no-boundary > $OUT/${TAG}_bench_loop.json 2> $OUT/${TAG}_bench_loop.err
       python -c "import json; d=json.load(open('$OUT/${TAG}_bench_loop.json'))['tandem_loop']; print({k: (v.get('keyframes_per_s'), v.get('mean_ms')) for k, v in d.items() if isinstance(v, dict) and 'keyframes_per_s' in v}); print(json.dumps(d.get('sliding_window'), indent=1))" ;;
+    ab_classloop)  # k_conv's class loop (one workgroup per tile walks all parity classes of a single-pass transposed layer) against class-per-workgroup launches
+      export DR_MI355X_LIB=$PWD/tandem_amd/libdr_mi355x_hooks.so DR_OPS_RANGE=0.01,10
+      for r in 1 2; do
+        echo "class loop: $(timeout 300 python tools/profile_ops.py "conv11|conv9|conv7" 2>&1 | tail -1)"
+        echo "class per workgroup: $(DR_CONV_NO_CLASS_LOOP=1 timeout 300 python tools/profile_ops.py "conv11|conv9|conv7" 2>&1 | tail -1)"
+      done | tee $OUT/${TAG}_classloop_ab.txt
+      unset DR_MI355X_LIB DR_OPS_RANGE ;;
+    tests_conv) timeout 1500 python -m pytest tests/test_conv_gpu.py tests/test_mvsnet_gpu.py -m gpu -x -q -k "transposed or deconv or golden or conv_matches or plan_candidate" > $OUT/${TAG}_gpu_tests_conv.log 2>&1; tail -4 $OUT/${TAG}_gpu_tests_conv.log ;;
     tests_cv) timeout 1200 python -m pytest tests/test_mvsnet_gpu.py -m gpu -x -q -k "cost_volume or golden" > $OUT/${TAG}_gpu_tests_cv.log 2>&1; tail -5 $OUT/${TAG}_gpu_tests_cv.log ;;
     tests) timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/${TAG}_gpu_tests.log 2>&1; tail -5 $OUT/${TAG}_gpu_tests.log ;;
     tests_fast) timeout 1200 python -m pytest tests -m gpu -x -q -k "${DR_TESTS_K:-mvsnet or conv}" > $OUT/${TAG}_gpu_tests_fast.log 2>&1; tail -5 $OUT/${TAG}_gpu_tests_fast.log ;;
