@@ -523,7 +523,7 @@ def tsdf_leg(args, rank, dev, world):
                                traffic_if_fetch_doubled=pmc_traffic("k_integrate"))
         # the ray-cast (74 % of the frame) against SURVEY 8(d)'s own lower bound: 7 B written + steps x 8 corners x 8 B read per output pixel, with the
         # measured step count; and against what the counters say actually left the caches
-        rs = None if args.no_tsdf_boundary else raycast_steps(min(n, 200))
+        rs = None if (args.no_tsdf_boundary or world > 1) else raycast_steps(min(n, 200))  # (a subprocess on this rank's GPU: single-GPU runs only)
         rc_ms = ms["raycast"] / n
         rc = dict(bound="hbm", kernel="k_raycast2", avg_launch_ms=rc_ms, steps=rs, peak=PEAK_HBM_GBPS, unit="GB/s",
                   traffic=pmc_traffic("k_raycast2", fetch="raw"), traffic_if_fetch_doubled=pmc_traffic("k_raycast2"))
