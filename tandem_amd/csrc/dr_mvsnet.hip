@@ -330,6 +330,7 @@ class MvsEngine {
     if (ev_h2d_) (void)hipEventDestroy(ev_h2d_);
     if (march_err_) (void)hipHostFree(march_err_);
     if (fc_flag_) (void)hipHostFree(fc_flag_);
+    if (up_stream_) { (void)hipStreamSynchronize(up_stream_); (void)hipEventDestroy(ev_hits_); (void)hipStreamDestroy(up_stream_); }
     (void)hipStreamSynchronize(side_);
     for (auto e : {ev_fork_, ev_feat2_, ev_feat3_}) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(side_);
@@ -342,7 +343,7 @@ class MvsEngine {
     check_args(H, W, V, ref, bgrs, K9, c2ws);
     std::unique_lock<std::mutex> lk(mu_);  // held by the worker for the whole forward (dr_mvsnet.cpp:84-92)
     done_cv_.wait(lk, [&] { return !unprocessed_; });
-    stage_inputs(H, W, V, ref, bgrs, K9, c2ws, dmin, dmax, disc);
+    stage_inputs(H, W, V, ref, bgrs, K9, c2ws, dmin, dmax, disc, true);
     unprocessed_ = true;
     input_cv_.notify_all();
   }
@@ -665,7 +666,8 @@ class MvsEngine {
       if (unprocessed_) {
         try {
           DR_HIP(hipSetDevice(device_));
-          forward(nullptr);
+          if (prelaunched_) prelaunched_ = false;  // (CallAsync enqueued this window's forward itself: stage_inputs)
+          else forward(nullptr);
           const size_t n = (size_t)H_ * W_ * 4;
           const int blk = out_cur_ ^ 1;  // the block the previous result does NOT live in (drm_get_result_view: that one may still be read)
           float *ho = h_out_[blk];
@@ -1007,6 +1009,7 @@ class MvsEngine {
       e.bgr = dalloc<uint8_t>(img_bytes + 16); misc_.push_back(e.bgr);
     }
     if (!fc_flag_) { DR_HIP(hipHostMalloc((void **)&fc_flag_, sizeof(int), hipHostMallocDefault)); *fc_flag_ = 0; }
+    if (!up_stream_) { DR_HIP(hipStreamCreateWithFlags(&up_stream_, hipStreamNonBlocking)); DR_HIP(hipEventCreateWithFlags(&ev_hits_, hipEventDisableTiming)); }
     // the single-view plan writes its three outputs straight into the entry of the image it runs on: which launches store into feat1..3, and where
     fn1_out_.clear();
     for (size_t i = 0; i < ops1_.size(); ++i) {
@@ -1107,22 +1110,29 @@ class MvsEngine {
     else if (o.kind == Op::HEAD3) launch_fn_head3(o.head3, st);
     else fail(DR_ERR_UNSUPPORTED, "feature cache: op kind %d in the single-view plan", (int)o.kind);
   }
-  // fast path of a forward: verify the hits, FeatureNet on the one uncached view, its outputs (and image) into the entry
-  void forward_cached_features() {
+  // one launch: the hits compared with their entries' images, the new image filed in its entry
+  void launch_cache_io() {
     const size_t img_bytes = (size_t)H_ * W_ * 3;
-    CacheIoArgs io{};  // one launch: the hits compared with their entries' images, the new image filed in its entry
+    CacheIoArgs io{};
     for (int v = 0; v < V_; ++v) {
       io.img[v] = reinterpret_cast<const uint4 *>(d_bgr_ + v * img_bytes);
       io.entry[v] = reinterpret_cast<uint4 *>(fcache_[fc_slot_[v]].bgr);
     }
     io.miss = fc_miss_; io.flag = fc_flag_dev(); io.n16 = img_bytes / 16;
     hipLaunchKernelGGL(k_cache_io, dim3(32, V_), dim3(256), 0, stream_, io);
+  }
+  // fast path of a forward: verify the hits, FeatureNet on the one uncached view, its outputs (and image) into the entry
+  void forward_cached_features() {
+    const size_t img_bytes = (size_t)H_ * W_ * 3;
+    if (!defer_cache_io_) launch_cache_io();
     if (fc_miss_ >= 0) {
       FcEntry &e = fcache_[fc_slot_[fc_miss_]];
       for (const FnOut &p : fn1_out_) {
         Op &o = ops1_[p.op];
         (o.kind == Op::CONV ? o.conv.args.out : o.head3.out) = e.feat[p.stage] + p.offset;
       }
+      // (the heads on the side stream, as the batch path runs them, were measured: device time 1.821 -> 1.825 ms, the sliding loop x 1.10 instead of x 1.12-1.15 --
+      // two cross-stream waits cost what the overlap of three small launches wins; not kept)
       for (Op &o : ops1_) {
         if (o.kind == Op::FRONT) o.front.bgr = d_bgr_ + fc_miss_ * img_bytes;
         launch_fn_op(o, stream_);
@@ -1272,7 +1282,7 @@ class MvsEngine {
   // Copies the window into pinned memory in model order [ref, others] (dr_mvsnet.cpp:190-197), enqueues
   // the H2D copy and derives every per-call kernel parameter.  Caller holds mu_.
   void stage_inputs(int H, int W, int V, int ref, const uint8_t *const *bgrs, const float *K9, const float *const *c2ws,
-                    float dmin, float dmax, float disc) {
+                    float dmin, float dmax, float disc, bool may_prelaunch = false) {
     DR_HIP(hipSetDevice(device_));
     configure(H, W, V);
     const size_t img_bytes = (size_t)H * W * 3;
@@ -1300,28 +1310,6 @@ class MvsEngine {
         pinned = p >= lo && p + img_bytes <= lo + span;
       }
     }
-    auto upload_views = [&, pinned](int v0) {  // views v0, v0 + 2, ...: gather into the staging block (unless page-locked already), then the copy engine
-      DR_HIP(hipSetDevice(device_));
-      for (int v = v0; v < V; v += 2) {
-        const uint8_t *src = bgrs[order[v]];
-        if (!pinned) { memcpy(h_in_ + v * img_bytes, src, img_bytes); src = h_in_ + v * img_bytes; }
-        DR_HIP(hipMemcpyAsync(d_bgr_ + v * img_bytes, src, img_bytes, hipMemcpyHostToDevice, stream_));
-      }
-    };
-    if (!pinned) {
-      copier_.run([&] { upload_views(1); });  // the helper thread takes every other view
-      try { upload_views(0); } catch (...) { copier_.wait_quiet(); throw; }  // (the job refers to this frame's locals)
-      copier_.wait();
-    } else {
-      upload_views(1);
-      upload_views(0);
-    }
-    if (pinned) {
-      if (!ev_h2d_) DR_HIP(hipEventCreateWithFlags(&ev_h2d_, hipEventDisableTiming));
-      DR_HIP(hipEventRecord(ev_h2d_, stream_));
-      DR_HIP(hipEventSynchronize(ev_h2d_));
-    }
-
     // stage intrinsics: rows 0-1 x 0.25 / 0.5 / 1 (the C++ rule, dr_mvsnet.cpp:226-247)
     double w2c[8][16];
     for (int v = 0; v < V; ++v) {
@@ -1398,6 +1386,67 @@ class MvsEngine {
     if (ci < 0) ci = 0;
     if (ci > (long long)H * W - 1) ci = (long long)H * W - 1;
     filter_rank_ = (unsigned)ci;
+    prelaunched_ = false;
+    // PRELAUNCH (CallAsync with the feature cache answering the window): the device needs ONE image -- the new one -- to start; the other six are only compared
+    // with their cache entries, which can happen last.  So the new image goes up first, the helper thread stages and uploads the rest on a second stream, and
+    // THIS thread enqueues the whole forward meanwhile; the comparison (k_cache_io) is enqueued behind it once the uploads are in flight.  The device starts
+    // ~0.3 ms earlier in TandemBackend's loop (it idles while a window is staged); the call still returns only when every image has been copied.
+    if (may_prelaunch && fc_fast_ && up_stream_) {
+      auto up_one = [&, pinned](int v, hipStream_t st) {
+        const uint8_t *src = bgrs[order[v]];
+        if (!pinned) { memcpy(h_in_ + v * img_bytes, src, img_bytes); src = h_in_ + v * img_bytes; }
+        DR_HIP(hipMemcpyAsync(d_bgr_ + v * img_bytes, src, img_bytes, hipMemcpyHostToDevice, st));
+      };
+      const int miss = fc_miss_;
+      if (miss >= 0) {
+        up_one(miss, stream_);
+        if (pinned) {  // (read in place from the caller's page-locked image: waited for before the call returns)
+          if (!ev_h2d_) DR_HIP(hipEventCreateWithFlags(&ev_h2d_, hipEventDisableTiming));
+          DR_HIP(hipEventRecord(ev_h2d_, stream_));
+        }
+      }
+      copier_.run([&, miss] {
+        DR_HIP(hipSetDevice(device_));
+        for (int v = 0; v < V; ++v) if (v != miss) up_one(v, up_stream_);
+        DR_HIP(hipEventRecord(ev_hits_, up_stream_));
+      });
+      try {
+        defer_cache_io_ = true;
+        forward(nullptr);
+        defer_cache_io_ = false;
+      } catch (...) { defer_cache_io_ = false; copier_.wait_quiet(); throw; }
+      copier_.wait();
+      DR_HIP(hipStreamWaitEvent(stream_, ev_hits_, 0));
+      launch_cache_io();
+      if (pinned) {  // uploaded in place from the caller's page-locked images: they must have been read before the call returns
+        DR_HIP(hipEventSynchronize(ev_hits_));
+        if (miss >= 0) DR_HIP(hipEventSynchronize(ev_h2d_));
+      }
+      prelaunched_ = true;
+    } else {
+    auto upload_views = [&, pinned](int v0) {  // views v0, v0 + 2, ...: gather into the staging block (unless page-locked already), then the copy engine
+        DR_HIP(hipSetDevice(device_));
+        for (int v = v0; v < V; v += 2) {
+          const uint8_t *src = bgrs[order[v]];
+          if (!pinned) { memcpy(h_in_ + v * img_bytes, src, img_bytes); src = h_in_ + v * img_bytes; }
+          DR_HIP(hipMemcpyAsync(d_bgr_ + v * img_bytes, src, img_bytes, hipMemcpyHostToDevice, stream_));
+        }
+      };
+      if (!pinned) {
+        copier_.run([&] { upload_views(1); });  // the helper thread takes every other view
+        try { upload_views(0); } catch (...) { copier_.wait_quiet(); throw; }  // (the job refers to this frame's locals)
+        copier_.wait();
+      } else {
+        upload_views(1);
+        upload_views(0);
+      }
+      if (pinned) {
+        if (!ev_h2d_) DR_HIP(hipEventCreateWithFlags(&ev_h2d_, hipEventDisableTiming));
+        DR_HIP(hipEventRecord(ev_h2d_, stream_));
+        DR_HIP(hipEventSynchronize(ev_h2d_));
+      }
+
+    }
   }
 
   // Enqueue one complete forward on stream_ (or the ops [first, last) of it).  ev (optional): ops_.size()+1 events
@@ -1678,7 +1727,11 @@ class MvsEngine {
   bool fn1_ok_ = false;            // the single-view plan exists and matches the batch plan's instances
   bool fc_fast_ = false, fc_fill_ = false;  // the staged window: answered by the cache (at most one view computed) / computed as a batch whose outputs fill the cache
   int fc_miss_ = -1, fc_slot_[kMaxSrc + 1] = {};
-  int *fc_flag_ = nullptr;         // page-locked: raised by k_verify_image
+  int *fc_flag_ = nullptr;         // page-locked: raised by k_cache_io
+  hipStream_t up_stream_ = nullptr;  // uploads of the images the cache answers (prelaunch, stage_inputs)
+  hipEvent_t ev_hits_ = nullptr;
+  bool prelaunched_ = false;       // the staged window's forward is already on the stream (the worker only publishes)
+  bool defer_cache_io_ = false;    // ... and its image comparison follows once the uploads are in flight
   uint64_t fc_clock_ = 0, fc_hits_ = 0, fc_misses_ = 0, fc_batch_windows_ = 0, fc_collisions_ = 0;
 
   const MvsSwitches sw_;  // read once, here

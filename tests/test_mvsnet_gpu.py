@@ -841,3 +841,32 @@ def test_engines_in_flight_are_bit_stable(trained_blob):
                 assert np.array_equal(m.tensor(n).view(np.uint32), want[n].view(np.uint32)), n
     for m in engines + [ref]:
         m.close()
+
+
+def test_feature_cache_with_page_locked_images(trained_blob):
+    """The cache's CallAsync path (the new image uploaded first, the forward enqueued by the calling thread while the helper thread uploads the cached images on a second
+    stream, their comparison last) with images in page-locked memory, which are uploaded IN PLACE: same maps as an engine without the cache, and the images may
+    be overwritten as soon as CallAsync has returned."""
+    from synth import scene
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    h, w, n = 96, 160, 5
+    big = scene.make_window(h, w, 7 + n - 1, seed=35)
+    a, b = DrMvsnet(trained_blob), DrMvsnet(trained_blob)
+    b.set_feature_cache(12)
+    pinned = b.alloc_images(7, h, w)  # ONE set of page-locked buffers, refilled for every window (what a caller that reuses its buffers does)
+    for k in range(n):
+        imgs = [np.ascontiguousarray(x) for x in big["bgrs"][k:k + 7]]
+        for dst, src in zip(pinned, imgs):
+            dst[...] = src
+        c2ws = list(big["c2ws"][k:k + 7])
+        b.CallAsync(h, w, 7, 5, pinned, big["K"], c2ws, 0.5, 5.0, 10.0)
+        for dst in pinned:
+            dst[...] = 0  # the call has returned: the engine must not need the caller's images any more
+        rb = b.GetResult()
+        a.CallAsync(h, w, 7, 5, imgs, big["K"], c2ws, 0.5, 5.0, 10.0)
+        ra = a.GetResult()
+        for name in ("depth", "confidence", "depth_dense", "confidence_dense"):
+            assert np.array_equal(getattr(ra, name).view(np.uint32), getattr(rb, name).view(np.uint32)), (k, name)
+    st = b.feature_cache_stats()
+    assert st["views_from_cache"] == 6 * (n - 1) and st["key_collisions"] == 0, st
+    a.close(); b.close()
