@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6's GPU script (round 5's, carried on): ONE parameterised entry point for every gpurun call.
 #   tools/gpu_r6.sh <tag> <step> [<step> ...]       results under gpurun_out/<tag>_*
-# steps: fused_sweep fused_prio corun batch_proxy ops ab_front ab_head3 fn_quick engines ab_ops ab_tail ops_tail ops_prob cv_sweep loop_raycast bench_host tune tests tests_fast smoke bench bench_quick shipped pmc prof_seq prof_driver
+# steps: ab_costvol abl_costvol tests_cv tests_fc tests_conv fc_time loop_sliding ab_classloop tsdf16m corun engines (DR_ENGINES_LIST) fused_sweep fused_prio batch_proxy ops ab_front ab_head3 fn_quick ab_ops ab_tail ops_tail ops_prob cv_sweep loop_raycast bench_host tune tests tests_fast smoke bench bench_quick shipped pmc prof_seq prof_driver
 #   the round's closing evidence, in the order bench.py needs it:  tools/gpu_r6.sh final pmc tests smoke bench shipped prof_seq prof_driver
 set -u
 cd "$(dirname "$0")/.."
@@ -73,8 +73,11 @@ PY
         DR_CONV_PRINT=1 timeout 600 python tools/try_autotune.py 400 > $OUT/${TAG}_tune_head_$r.txt 2>&1; tail -3 $OUT/${TAG}_tune_head_$r.txt | cut -c1-150
         DR_CONV_PRINT=1 timeout 600 python tools/try_autotune.py 400 320 512 48,4,4 > $OUT/${TAG}_tune_ship_$r.txt 2>&1; tail -3 $OUT/${TAG}_tune_ship_$r.txt | cut -c1-150
       done ;;
-    ab_tail)  # DR_TAIL_FUSED=1 per-op profile with every A/B library under build/ab
-      for so in build/ab/libdr_*.so; do nme=$(basename $so .so); echo "--- $nme: $(DR_TAIL_FUSED=1 DR_MI355X_LIB=$PWD/$so timeout 300 python tools/profile_ops.py "tail" 2>&1 | tail -1)"; done ;;
+    ab_tail)  # (switches of the parity build: these A/Bs run on libdr_mi355x_hooks.so)
+      export DR_MI355X_LIB=$PWD/tandem_amd/libdr_mi355x_hooks.so
+       # DR_TAIL_FUSED=1 per-op profile with every A/B library under build/ab
+      for so in build/ab/libdr_*.so; do nme=$(basename $so .so); echo "--- $nme: $(DR_TAIL_FUSED=1 DR_MI355X_LIB=$PWD/$so timeout 300 python tools/profile_ops.py "tail" 2>&1 | tail -1)"; done 
+      unset DR_MI355X_LIB ;;
     cv_sweep)  # cost-volume depth chunks and register caps (A/B libraries under build/ab)
       for cfg in "" "DR_CV_DCHUNK1=8" "DR_CV_DCHUNK1=12" "DR_CV_DCHUNK1=16" "DR_CV_DCHUNK2=4" "DR_CV_DCHUNK2=16" "DR_CV_DCHUNK3=4"; do echo "[$cfg] $(env $cfg timeout 300 python tools/profile_ops.py "costvol" 2>&1 | tail -1)"; done
       for so in build/ab/libdr_*.so; do nme=$(basename $so .so); echo "--- $nme: $(DR_MI355X_LIB=$PWD/$so timeout 300 python tools/profile_ops.py "costvol" 2>&1 | tail -1)"; done ;;
@@ -87,22 +90,34 @@ print("value %.1f  single %.3f  boundary %.3f  pinned %.3f" % (d["value"], d["si
 print({k:(v.get("keyframes_per_s"),v.get("mean_ms")) for k,v in d["tandem_loop"].items() if isinstance(v,dict)})
 PY
       ;;
-    ops_prob)  # k_prob2<NR>: rows per lane 1 / 2 / 4
-      for f in 1 2 4; do echo "DR_PROB_ROWS=$f: $(DR_PROB_ROWS=$f timeout 300 python tools/profile_ops.py "prob" 2>&1 | tail -1)"; done ;;
-    ops_tail)  # per-op profile with the fused tail forms beside the default
-      for f in 0 1 2; do DR_TAIL_FUSED=$f timeout 300 python tools/profile_ops.py "tail|conv11|prob" > $OUT/${TAG}_ops_tail$f.txt 2>&1; echo "DR_TAIL_FUSED=$f: $(tail -1 $OUT/${TAG}_ops_tail$f.txt)"; done ;;
-    ab_front)  # k_fn_front against the three launches it replaces: per-op times, then the quick bench line, both ways
+    ops_prob)  # (switches of the parity build: these A/Bs run on libdr_mi355x_hooks.so)
+      export DR_MI355X_LIB=$PWD/tandem_amd/libdr_mi355x_hooks.so
+       # k_prob2<NR>: rows per lane 1 / 2 / 4
+      for f in 1 2 4; do echo "DR_PROB_ROWS=$f: $(DR_PROB_ROWS=$f timeout 300 python tools/profile_ops.py "prob" 2>&1 | tail -1)"; done 
+      unset DR_MI355X_LIB ;;
+    ops_tail)  # (switches of the parity build: these A/Bs run on libdr_mi355x_hooks.so)
+      export DR_MI355X_LIB=$PWD/tandem_amd/libdr_mi355x_hooks.so
+       # per-op profile with the fused tail forms beside the default
+      for f in 0 1 2; do DR_TAIL_FUSED=$f timeout 300 python tools/profile_ops.py "tail|conv11|prob" > $OUT/${TAG}_ops_tail$f.txt 2>&1; echo "DR_TAIL_FUSED=$f: $(tail -1 $OUT/${TAG}_ops_tail$f.txt)"; done 
+      unset DR_MI355X_LIB ;;
+    ab_front)  # (switches of the parity build: these A/Bs run on libdr_mi355x_hooks.so)
+      export DR_MI355X_LIB=$PWD/tandem_amd/libdr_mi355x_hooks.so
+       # k_fn_front against the three launches it replaces: per-op times, then the quick bench line, both ways
       for f in 1 0; do echo "DR_FN_FRONT=$f: $(DR_FN_FRONT=$f timeout 300 python tools/profile_ops.py "preprocess|fn.front|fn.conv0|fn.conv1.0" 2>&1 | tail -1)"; done | tee $OUT/${TAG}_front_ops.txt
       for f in 1 0 1 0; do
         DR_FN_FRONT=$f timeout 600 python bench.py --gpus 1 --steps 60 --warmup 5 --no-cpu --no-loop --no-boundary --no-tsdf > $OUT/${TAG}_bench_front$f.json 2> $OUT/${TAG}_bench_front$f.err
         python -c "import json; d=json.load(open('$OUT/${TAG}_bench_front$f.json')); print('DR_FN_FRONT=$f: value %.1f /s  ms_per_step %.3f  single_window %.3f ms' % (d['value'], d['ms_per_step'], d['single_window_ms']))"
-      done | tee -a $OUT/${TAG}_front_ops.txt ;;
-    ab_head3)  # k_fn_head3 against the four launches it replaces
+      done | tee -a $OUT/${TAG}_front_ops.txt 
+      unset DR_MI355X_LIB ;;
+    ab_head3)  # (switches of the parity build: these A/Bs run on libdr_mi355x_hooks.so)
+      export DR_MI355X_LIB=$PWD/tandem_amd/libdr_mi355x_hooks.so
+       # k_fn_head3 against the four launches it replaces
       for f in 1 0; do echo "DR_FN_HEAD3=$f: $(DR_FN_HEAD3=$f timeout 300 python tools/profile_ops.py "fn.head3|fn.out3|fn.out2|fn.skip2" 2>&1 | tail -1)"; done | tee $OUT/${TAG}_head3_ops.txt
       for f in 1 0 1 0; do
         DR_FN_HEAD3=$f timeout 600 python bench.py --gpus 1 --steps 60 --warmup 5 --no-cpu --no-loop --no-boundary --no-tsdf > $OUT/${TAG}_bench_head3$f.json 2> $OUT/${TAG}_bench_head3$f.err
         python -c "import json; d=json.load(open('$OUT/${TAG}_bench_head3$f.json')); print('DR_FN_HEAD3=$f: value %.1f /s  ms_per_step %.3f  single_window %.3f ms' % (d['value'], d['ms_per_step'], d['single_window_ms']))"
-      done | tee -a $OUT/${TAG}_head3_ops.txt ;;
+      done | tee -a $OUT/${TAG}_head3_ops.txt 
+      unset DR_MI355X_LIB ;;
     fn_quick)  # the two fused FeatureNet kernels as they stand: per-op times and the quick bench line, twice
       echo "$(timeout 300 python tools/profile_ops.py "fn.front|fn.head3" 2>&1 | tail -1)" | tee $OUT/${TAG}_fn_quick.txt
       for r in 1 2; do
@@ -114,12 +129,15 @@ PY
         timeout 600 python bench.py --gpus 1 --steps 60 --warmup 5 --engines $n --no-cpu --no-loop --no-boundary --no-tsdf > $OUT/${TAG}_bench_eng.json 2> $OUT/${TAG}_bench_eng.err
         python -c "import json; d=json.load(open('$OUT/${TAG}_bench_eng.json')); print('engines $n: value %.1f /s  ms_per_step %.3f' % (d['value'], d['ms_per_step']))"
       done | tee $OUT/${TAG}_engines.txt ;;
-    ab_launches)  # the edge filter's folded scans and prob + regression in one launch, against the forms they replace
+    ab_launches)  # (switches of the parity build: these A/Bs run on libdr_mi355x_hooks.so)
+      export DR_MI355X_LIB=$PWD/tandem_amd/libdr_mi355x_hooks.so
+       # the edge filter's folded scans and prob + regression in one launch, against the forms they replace
       for f in 1 0; do echo "DR_FILTER_FUSED=$f DR_PROB_REGRESS=$f: $(DR_FILTER_FUSED=$f DR_PROB_REGRESS=$f timeout 300 python tools/profile_ops.py "filter|s3.prob|s3.regress" 2>&1 | tail -1)"; done | tee $OUT/${TAG}_launches_ops.txt
       for f in 1 0 1 0; do
         DR_FILTER_FUSED=$f DR_PROB_REGRESS=$f timeout 600 python bench.py --gpus 1 --steps 60 --warmup 5 --no-cpu --no-loop --no-boundary --no-tsdf > $OUT/${TAG}_bench_l$f.json 2> $OUT/${TAG}_bench_l$f.err
         python -c "import json; d=json.load(open('$OUT/${TAG}_bench_l$f.json')); print('fused=$f: value %.1f /s  ms_per_step %.3f  single_window %.3f ms' % (d['value'], d['ms_per_step'], d['single_window_ms']))"
-      done | tee -a $OUT/${TAG}_launches_ops.txt ;;
+      done | tee -a $OUT/${TAG}_launches_ops.txt 
+      unset DR_MI355X_LIB ;;
     ops) timeout 600 python tools/profile_ops.py > $OUT/${TAG}_ops.txt 2>&1; tail -4 $OUT/${TAG}_ops.txt ;;
     pmc)  # counters in their own passes (--kernel-trace only), strictly sequential kernels (one engine, side stream off) -> profiles/r06_pmc_traffic.json, stamped with this tree's source hash
       export DR_MVS_NO_SIDE_STREAM=1
