@@ -231,9 +231,9 @@ struct MvsSwitches {
   bool out3_folded = hnum("DR_OUT3_FOLDED", 1) != 0;     // 0: FeatureNet's stage-3 head in its literal order (fused-skip kernel)
   bool d2h_copy = hook_env("DR_MVS_D2H") && !strcmp(hook_env("DR_MVS_D2H"), "copy");  // four copy-engine transfers instead of k_publish4
   // k_costvol5's two choices (round 6, profiles/r06_costvol_ab.txt): a sample whose footprint is the previous plane's issues no gathers (0.109 / 0.172 / 0.120 ->
-  // 0.084 / 0.150 / 0.117 ms at depth chunks of 4 / 8 / 8 planes); the workgroup tile is four rows of a quarter segment at stage 3 only (C = 8: 0.106 -> 0.095 ms
-  // there, 0.083 -> 0.089 at stage 1, nothing at stage 2)
-  int cv5_rows = hnum("DR_CV5_ROWS", 0);                 // 0: the product's rule (4 rows where C = 8); 1 / 4: that tile at every stage
+  // 0.084 / 0.150 / 0.117 ms at depth chunks of 4 / 8 / 8 planes; 0.078 / 0.126 / 0.099 in the single-set form); the workgroup tile is four rows of a quarter segment
+  // (0.108 -> 0.099 ms at stage 3, 0.126 -> 0.122 at stage 2, nothing at stage 1)
+  int cv5_rows = hnum("DR_CV5_ROWS", 0);                 // 0: the product's rule (4 rows); 1 / 4: that tile at every stage
   bool cv5_reuse = hnum("DR_CV5_REUSE", 1) != 0;         // 0: every sample gathers its four taps
   int cv5_abl = hnum("DR_CV5_ABL", 0);                   // measuring hook: k_costvol5 without its gathers (1), stores (2), tap arithmetic (4)
   // k_costvol4 (round 4: source taps staged through LDS -- north_star's "LDS staging of per-pixel feature slices"): bit-identical to
@@ -1608,14 +1608,13 @@ class MvsEngine {
               CostVolArgs b4 = b;  // the four-row tile: x segments of a quarter of the pixels, four rows per workgroup
               b4.gx = cdiv(a.w, 256 / C); b4.nwg = b4.gx * b4.gz * cdiv(a.h, 4);
               const dim3 grid4(8 * cdiv(b4.nwg, 8));
-              const bool rows4 = sw_.cv5_rows ? sw_.cv5_rows == 4 : C == 8;
+              [[maybe_unused]] const bool rows4 = sw_.cv5_rows ? sw_.cv5_rows == 4 : true;  // (four-row tiles at every stage since the single-set form: 0.126 -> 0.122 ms at stage 2, stage 1 unchanged)
 #ifdef DR_PARITY_HOOKS
 #define DR_CV5(CC, DD) do { if (!sw_.cv5_reuse) hipLaunchKernelGGL((k_costvol5<CC, DD, 0, 1>), grid, dim3(256), 0, stream_, b); \
                             else if (rows4) hipLaunchKernelGGL((k_costvol5<CC, DD, 1, 4>), grid4, dim3(256), 0, stream_, b4); \
                             else hipLaunchKernelGGL((k_costvol5<CC, DD, 1, 1>), grid, dim3(256), 0, stream_, b); } while (0)
 #else
-#define DR_CV5(CC, DD) do { if (rows4) hipLaunchKernelGGL((k_costvol5<CC, DD, 1, (CC == 8 ? 4 : 1)>), grid4, dim3(256), 0, stream_, b4); \
-                            else hipLaunchKernelGGL((k_costvol5<CC, DD, 1, (CC == 8 ? 4 : 1)>), grid, dim3(256), 0, stream_, b); } while (0)
+#define DR_CV5(CC, DD) hipLaunchKernelGGL((k_costvol5<CC, DD, 1, 4>), grid4, dim3(256), 0, stream_, b4)
 #endif
               if (C == 32 && d8) DR_CV5(32, 8);
               else if (C == 32) DR_CV5(32, 4);

@@ -651,6 +651,35 @@ __global__ __launch_bounds__(256) void k_costvol5(const CostVolArgs a) {
   };
   CvRay R = cv_ray(a.M[0], xf, yf);
   CvProj P = cv_project_ray(a.M[0], R, dep[0], fw, fh, wp, C);
+  // REUSE: ONE tap set and no software pipelining.  A lane whose footprint repeats keeps its taps where they are (no gather, no copy); a lane whose footprint moved
+  // gathers into the same registers and waits.  Against the two-set pipeline (gathers of plane j + 1 in flight under the arithmetic of plane j, reused taps COPIED from
+  // one set to the other: eight moves per sample) the waves, not the lane's own pipeline, hide the latency: 0.096 / 0.140 / 0.105 -> 0.078 / 0.125 / 0.097 ms
+  // (profiles/r06_costvol_ab.txt; six or seven waves per SIMD make no difference, and a register cap that spills two dwords into the view loop costs 30 %).
+  // Without reuse every sample gathers, and the pipelined form below is the better one (the parity build's DR_CV5_REUSE=0).
+  if constexpr (REUSE != 0) {
+    CvTaps T;
+    T.t00 = T.t01 = T.t10 = T.t11 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int v = 0; v < nsrc; ++v) {
+      const float *m = a.M[v];
+      const CvRay Rv = cv_ray(m, xf, yf);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const CvProj Pb = cv_project_ray(m, Rv, dep[b], fw, fh, wp, C);
+#pragma unroll
+        for (int jj = 0; jj < LPB; ++jj) {
+          const unsigned ob = (unsigned)cv_bcast_i(Pb.o, LPB, jj) * 4u + obias;
+          T.w00 = cv_bcast_f(Pb.w00, LPB, jj); T.w01 = cv_bcast_f(Pb.w01, LPB, jj); T.w10 = cv_bcast_f(Pb.w10, LPB, jj); T.w11 = cv_bcast_f(Pb.w11, LPB, jj);
+          if ((b == 0 && jj == 0) || ob != ob_prev) {
+            const char *r0 = reinterpret_cast<const char *>(a.vfeat[v + 1]), *r1 = r0 + rowbytes;
+            T.t00 = ld4(reinterpret_cast<const float *>(r0 + ob)); T.t01 = ld4(reinterpret_cast<const float *>(r0 + ob) + C);
+            T.t10 = ld4(reinterpret_cast<const float *>(r1 + ob)); T.t11 = ld4(reinterpret_cast<const float *>(r1 + ob) + C);
+          }
+          ob_prev = ob;
+          consume(acc[b * LPB + jj], T);
+        }
+      }
+    }
+  } else {
   CvTaps TA, TB;
   gather(P, 0, 0, TA, TA, true);
   for (int v = 0; v < nsrc; ++v) {
@@ -670,6 +699,7 @@ __global__ __launch_bounds__(256) void k_costvol5(const CostVolArgs a) {
       P = Pn;
     }
     R = Rn;
+  }
   }
 #ifdef DR_PARITY_HOOKS
   if ((a.abl & 2) && acc[0].x != 123.456f) return;

@@ -22,7 +22,7 @@ for step in "$@"; do
     ab_costvol)  # k_costvol5 (product) against k_costvol3 (DR_COSTVOL_V3, parity build) and against its own A/B forms, headline shape and depth range 0.01 .. 10
       export DR_MI355X_LIB=$PWD/tandem_amd/libdr_mi355x_hooks.so DR_OPS_RANGE=0.01,10
       for r in 1 2; do
-        echo "k_costvol5 (chunks of 4 planes, footprint reuse, 4-row tiles at stage 3): $(timeout 300 python tools/profile_ops.py "costvol" 2>&1 | tail -1)"
+        echo "k_costvol5 (chunks of 4 planes, footprint reuse in one tap set, 4-row tiles): $(timeout 300 python tools/profile_ops.py "costvol" 2>&1 | tail -1)"
         echo "k_costvol5 one-row tiles everywhere: $(DR_CV5_ROWS=1 timeout 300 python tools/profile_ops.py "costvol" 2>&1 | tail -1)"
         echo "k_costvol5 four-row tiles everywhere: $(DR_CV5_ROWS=4 timeout 300 python tools/profile_ops.py "costvol" 2>&1 | tail -1)"
         echo "k_costvol5 chunks of 8 planes: $(DR_CV_DCHUNK1=8 DR_CV_DCHUNK2=8 DR_CV_DCHUNK3=8 timeout 300 python tools/profile_ops.py "costvol" 2>&1 | tail -1)"
