@@ -617,7 +617,16 @@ def tandem_loop_leg(args, dev):
                         break
                     d = json.loads(r.stdout.strip().splitlines()[-1])
                     sl.setdefault("cache_%d" % cache, []).append(dict(keyframes_per_s=d["keyframes_per_s"], ms_per_keyframe=d["ms_per_keyframe"], mean_ms=d["mean_ms"]))
+                if "error" not in sl:  # ... and with GetResult() handing out views of the page-locked result block on top (DrMvsnet::SetResultViews: no 4.9 MB copy per key frame)
+                    for _ in range(3):
+                        r = subprocess.run([exe, blob, sample, str(3 * args.loop_keyframes), vs, "0", "1", "1", "16", "1"], capture_output=True, text=True, timeout=900, env=env)
+                        if r.returncode != 0:
+                            sl["error"] = (r.stdout + r.stderr)[-500:]
+                            break
+                        d = json.loads(r.stdout.strip().splitlines()[-1])
+                        sl.setdefault("cache_16_result_views", []).append(dict(keyframes_per_s=d["keyframes_per_s"], ms_per_keyframe=d["ms_per_keyframe"], mean_ms=d["mean_ms"]))
                 if "error" not in sl:
+                    sl["keyframes_per_s_cache_on_result_views"] = sorted(x["keyframes_per_s"] for x in sl["cache_16_result_views"])[1]
                     off, on = (sorted(x["keyframes_per_s"] for x in sl["cache_%d" % c])[1] for c in (0, 16))  # the median of three
                     sl.update(keyframes_per_s_cache_off=off, keyframes_per_s_cache_on=on, speedup=on / off,
                               note="1 cm voxels (TANDEM's setting), sliding synthetic sequence: each key frame drops the oldest image of the window and adds a new one; "

@@ -73,14 +73,16 @@ public:
     // never deletes its DrMvsnetOutputs, so every result lands in 4.9 MB of fresh memory, and the first-touch page faults of that memory
     // (1200 of them at 640 x 480) were paid inside GetResult, on the caller's critical path -- more time than the copy itself.
     if (spare_ && (spare_->height != height || spare_->width != width)) { delete spare_; spare_ = nullptr; }
-    if (!spare_) {
+    if (!spare_ && !result_views_) {
       spare_ = new DrMvsnetOutput(height, width);
       const size_t bytes = sizeof(float) * (size_t) width * height;
       memset(spare_->depth, 0, bytes); memset(spare_->confidence, 0, bytes); memset(spare_->depth_dense, 0, bytes); memset(spare_->confidence_dense, 0, bytes);
     }
   }
   // Blocking.  Ownership of the result passes to the caller (delete it), as in the reference.
+  // With SetResultViews(true) (extension, below) the object's four maps are VIEWS of the engine's page-locked result block instead of copies.
   DrMvsnetOutput *GetResult() {
+    if (result_views_) return GetResultView();
     DrMvsnetOutput *out = spare_ ? spare_ : new DrMvsnetOutput(height_, width_);
     spare_ = nullptr;
     if (drm_get_result(impl, out->depth, out->confidence, out->depth_dense, out->confidence_dense) != DR_OK) {
@@ -99,6 +101,10 @@ public:
   }
   // Page-locked memory for key-frame images: CallAsync uploads windows whose images ALL live in such memory in place, skipping the
   // gather into the engine's staging block (6.45 MB at 640 x 480 x 7).
+  // GetResult() without its 4.9 MB host copy (640 x 480): the maps handed out are views (GetResultView) -- valid while the NEXT CallAsync is processed, overwritten by
+  // the one after it.  That is exactly how TandemBackend uses a result (tandem_backend.cpp:147-177: read during the call that follows, never touched again), so its
+  // unchanged code may run on views; a caller that keeps results longer must not switch this on.
+  void SetResultViews(bool on) { result_views_ = on; }
   // The key-frame feature cache (drm_set_feature_cache): FeatureNet runs on the window's NEW image only; call once after construction.  0 = off.
   void SetFeatureCache(int key_frames) { check(drm_set_feature_cache(impl, key_frames)); }
   static unsigned char *AllocImage(size_t bytes) { return static_cast<unsigned char *>(drm_host_alloc(bytes)); }
@@ -116,6 +122,7 @@ private:
   drm_t *impl;
   int height_, width_;
   DrMvsnetOutput *spare_ = nullptr;  // the next GetResult()'s object, pages already touched (CallAsync)
+  bool result_views_ = false;
 };
 
 // test_dr_mvsnet (dr_mvsnet.cpp:376-556): feeds a stored window through CallAsync/Ready/GetResult

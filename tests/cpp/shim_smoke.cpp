@@ -41,6 +41,23 @@ int main(int argc, char **argv) {
     for (int v = 0; v < V; v++) DrMvsnet::FreeImage(pb[v]);
     if (!same) return 4;
   }
+  // round 6's extensions on the same object: GetResult() handing out views (SetResultViews) and the key-frame feature cache (SetFeatureCache) -- same maps again,
+  // and the previous result's views stay readable while the next window is processed (TandemBackend reads result k - 1 after CallAsync(k), tandem_backend.cpp:147-166)
+  {
+    mvsnet.SetResultViews(true);
+    mvsnet.SetFeatureCache(V + 2);
+    mvsnet.CallAsync(H, W, V, ref, bgrs.data(), K, c2ws.data(), sc[0], sc[1], sc[2]);
+    DrMvsnetOutput *a = mvsnet.GetResult();
+    mvsnet.CallAsync(H, W, V, ref, bgrs.data(), K, c2ws.data(), sc[0], sc[1], sc[2]);  // answered by the cache; its result goes to the OTHER pinned block
+    const bool kept = !memcmp(a->depth, out->depth, sizeof(float) * H * W) && !memcmp(a->depth_dense, out->depth_dense, sizeof(float) * H * W);
+    DrMvsnetOutput *b = mvsnet.GetResult();
+    const bool same = kept && !memcmp(b->depth, out->depth, sizeof(float) * H * W) && !memcmp(b->confidence, out->confidence, sizeof(float) * H * W);
+    printf("mvsnet: result views + feature cache %s the copying path\n", same ? "equal" : "DIFFER FROM");
+    delete a; delete b;
+    mvsnet.SetResultViews(false);
+    mvsnet.SetFeatureCache(0);
+    if (!same) return 5;
+  }
 
   DrFusionOptions o;
   o.voxel_size = 0.01f; o.num_buckets = 50000; o.bucket_size = 10; o.num_blocks = 100000; o.block_size = 8; o.max_sdf_weight = 64;

@@ -9,12 +9,13 @@
 // reads the tracking depth map under its mutex the way CoarseTracker::makeCoarseDepthL0 does (CoarseTracker.cpp:655-668).
 // Everything between those calls and the GPU -- GetResult(k-1), CallAsync(k), IntegrateScanAsync / RenderAsync / GetRenderResult
 // of k-1, the A/B depth-map swap, the mesh every mesh_freq-th call, the output-wrapper pushes -- is the reference's code.
-//   usage: tandem_backend_run <weights.tdmw> <window.tdms> <keyframes> [voxel_size=0.01] [mesh_freq=0] [dense_tracking=1] [sliding=0] [feature_cache=0]
+//   usage: tandem_backend_run <weights.tdmw> <window.tdms> <keyframes> [voxel_size=0.01] [mesh_freq=0] [dense_tracking=1] [sliding=0] [feature_cache=0] [result_views=0]
 // sliding = 1: the window SLIDES as TANDEM's does -- key frame k's window is the previous one without its oldest image plus one NEW image
 // (FullSystem.cpp:1159-1173 pushes the active key frames; one is marginalised, one is added): the stored window's seven views are used
 // cyclically with their own poses (any subset of them is a consistent multi-view set), and the image that enters the window is made a new
 // image -- its first 16 bytes carry the key-frame number -- so six of the seven images of a window were in the one before and one never was.
 // feature_cache = n > 0: DrMvsnet::SetFeatureCache(n) (extension of this library: FeatureNet runs on the new image only).
+// result_views = 1: DrMvsnet::SetResultViews(true) (extension: GetResult() hands out views of the engine's page-locked result block, no 4.9 MB copy).
 // Prints ONE JSON line.
 #include <chrono>
 #include <cmath>
@@ -51,6 +52,7 @@ int main(int argc, char **argv) {
   const bool dense_tracking = argc > 6 ? atoi(argv[6]) != 0 : true;
   const bool sliding = argc > 7 ? atoi(argv[7]) != 0 : false;
   const int feature_cache = argc > 8 ? atoi(argv[8]) : 0;
+  const bool result_views = argc > 9 ? atoi(argv[9]) != 0 : false;
   FILE *f = fopen(argv[2], "rb");
   if (!f) { fprintf(stderr, "cannot open %s\n", argv[2]); return 2; }
   char magic[8]; int hdr[4]; float sc[3], K[9];
@@ -65,6 +67,7 @@ int main(int argc, char **argv) {
   // FullSystem::initDr (FullSystem.cpp:255-290): the two operators, then the back-end that owns the call order
   DrMvsnet *mvsnet = new DrMvsnet(argv[1]);
   if (feature_cache > 0) mvsnet->SetFeatureCache(feature_cache);
+  if (result_views) mvsnet->SetResultViews(true);
   DrFusionOptions o;
   o.voxel_size = voxel; o.num_buckets = 1000000; o.bucket_size = 10; o.num_blocks = 1000000; o.block_size = 8; o.max_sdf_weight = 64;
   o.truncation_distance = 4 * voxel; o.max_sensor_depth = 10.f; o.min_sensor_depth = 0.1f; o.num_render_streams = dense_tracking ? 1 : 0;
@@ -127,12 +130,12 @@ int main(int argc, char **argv) {
   backend->Wait();
   fusion->Synchronize();
   const double total = ms_since(t_begin);
-  printf("{\"driver\": \"reference tandem_backend.cpp, unchanged\", \"sliding_window\": %d, \"feature_cache\": %d, \"keyframes\": %d, \"keyframes_per_s\": %.3f, \"ms_per_keyframe\": %.4f, "
+  printf("{\"driver\": \"reference tandem_backend.cpp, unchanged\", \"sliding_window\": %d, \"feature_cache\": %d, \"result_views\": %d, \"keyframes\": %d, \"keyframes_per_s\": %.3f, \"ms_per_keyframe\": %.4f, "
          "\"height\": %d, \"width\": %d, \"views\": %d, \"voxel_size\": %g, \"dense_tracking\": %d, \"mesh_every\": %d, "
          "\"mean_ms\": {\"backend_wait\": %.4f, \"backend_CallAsync\": %.4f, \"tracking_map_read\": %.4f, \"IntegrateScanAsync\": %.4f, \"fusion_mesh\": %.4f}, "
          "\"pushed\": {\"images\": %d, \"depth_maps\": %d, \"meshes\": %d, \"last_mesh_vertices\": %zu}, \"tracking_maps_valid\": %d, "
          "\"tracked_sample\": %zu, \"last_depth_sample_sum\": %.3f}\n",
-         (int) sliding, feature_cache, n_kf, 1e3 * n_kf / total, total / n_kf, H, W, V, voxel, (int) dense_tracking, mesh_freq, t_wait / n_kf, t_call / n_kf, t_track / n_kf,
+         (int) sliding, feature_cache, (int) result_views, n_kf, 1e3 * n_kf / total, total / n_kf, H, W, V, voxel, (int) dense_tracking, mesh_freq, t_wait / n_kf, t_call / n_kf, t_track / n_kf,
          dr_timer.mean_timing("IntegrateScanAsync"), dr_timer.mean_timing("fusion-mesh"), wrapper.images, wrapper.depths, wrapper.meshes,
          wrapper.last_mesh_vertices, valid_maps, tracked, wrapper.depth_sum);
   fflush(stdout);
