@@ -870,3 +870,41 @@ def test_feature_cache_with_page_locked_images(trained_blob):
     st = b.feature_cache_stats()
     assert st["views_from_cache"] == 6 * (n - 1) and st["key_collisions"] == 0, st
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("views,capacity,stride", [(7, 8, 1), (7, 9, 2), (4, 5, 1), (3, 12, 3)])
+def test_feature_cache_eviction_and_batch_windows(trained_blob, views, capacity, stride):
+    """The cache at its edges: the smallest legal capacity (view count + 1: every new image evicts the least recently used entry that the window does not use), windows that
+    bring TWO or more new images (computed as a batch, which refills the cache), other view counts, and windows that share nothing with the last one -- always the maps of an
+    engine without a cache, bit for bit; the counters say which path every window took."""
+    from synth import scene
+    from tandem_amd.dr_mvsnet import DrMvsnet
+    h, w, n = 96, 160, 6
+    big = scene.make_window(h, w, views + stride * (n - 1), seed=37)
+    a, b = DrMvsnet(trained_blob), DrMvsnet(trained_blob)
+    b.set_feature_cache(capacity)
+    for k in range(n):
+        lo = k * stride
+        imgs = [np.ascontiguousarray(x) for x in big["bgrs"][lo:lo + views]]
+        c2ws = list(big["c2ws"][lo:lo + views])
+        outs = []
+        for m in (a, b):
+            m.CallAsync(h, w, views, views - 2, imgs, big["K"], c2ws, 0.5, 5.0, 10.0)
+            outs.append(m.GetResult())
+        for name in ("depth", "confidence", "depth_dense", "confidence_dense"):
+            assert np.array_equal(getattr(outs[0], name).view(np.uint32), getattr(outs[1], name).view(np.uint32)), (k, name)
+    st = b.feature_cache_stats()
+    new_per_window = min(stride, views)
+    assert st["key_collisions"] == 0 and st["single_view_plan"], st
+    if new_per_window == 1:
+        assert st["batch_windows"] == 1 and st["views_from_cache"] == (views - 1) * (n - 1), st
+    else:  # two or more new images: every window is a batch window; what it could have reused it recomputed
+        assert st["batch_windows"] == n and st["views_from_cache"] == 0, st
+    # going BACK to the first window after the slide: with the smallest capacity its images have been evicted (stride 1: n - 1 = 5 evictions >= views - ... ) or not -- either way the maps are right
+    imgs = [np.ascontiguousarray(x) for x in big["bgrs"][:views]]
+    outs = []
+    for m in (a, b):
+        m.CallAsync(h, w, views, views - 2, imgs, big["K"], list(big["c2ws"][:views]), 0.5, 5.0, 10.0)
+        outs.append(m.GetResult())
+    assert np.array_equal(outs[0].depth_dense.view(np.uint32), outs[1].depth_dense.view(np.uint32))
+    a.close(); b.close()
