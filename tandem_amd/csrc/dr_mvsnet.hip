@@ -303,6 +303,9 @@ class MvsEngine {
     if (hipGetDeviceCount(&n) != hipSuccess || n <= device) fail(DR_ERR_DEVICE, "DrMvsnet: no HIP device %d (found %d) -- the MI355X path has no CPU fallback", device, n);
     DR_HIP(hipSetDevice(device_));
     DR_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    // Both streams are created HERE, whether the side stream will be used or not: the runtime (ROCm 7.2, four hardware queues by default) gives a new stream the
+    // least-shared queue, and with two streams per engine the main streams of four engines land on four different queues (tools/ubench/stream_queues.hip shows
+    // the mapping; one stream per engine puts the fourth engine on the third one's queue: 535 instead of 580 depth maps/s, profiles/r06_queues_side_stream.txt).
     DR_HIP(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
     for (auto *e : {&ev_fork_, &ev_feat2_, &ev_feat3_}) DR_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     side_enabled_ = sw_.side_stream;
@@ -414,6 +417,7 @@ class MvsEngine {
     std::unique_lock<std::mutex> lk(mu_);
     require_config();
     DR_HIP(hipSetDevice(device_));
+    InFlight windows(device_, false);  // (several engines driven through this hook at once count as windows in flight, like CallAsync's)
     hipEvent_t e0, e1;
     DR_HIP(hipEventCreate(&e0)); DR_HIP(hipEventCreate(&e1));
     DR_HIP(hipEventRecord(e0, stream_));
@@ -660,12 +664,23 @@ class MvsEngine {
   void rethrow_worker_error() {
     if (!worker_error_.empty()) { std::string e = worker_error_; worker_error_.clear(); fail(DR_ERR_DEVICE, "%s", e.c_str()); }
   }
+  // windows whose kernels are enqueued or running, per device, over all engines of the process (forward() forks onto its side stream only when it is alone)
+  static std::atomic<int> &windows_in_flight(int device) {
+    static std::atomic<int> n[16];
+    return n[device & 15];
+  }
+  struct InFlight {
+    int dev;
+    InFlight(int d, bool counted_already) : dev(d) { if (!counted_already) windows_in_flight(dev).fetch_add(1, std::memory_order_relaxed); }
+    ~InFlight() { windows_in_flight(dev).fetch_sub(1, std::memory_order_relaxed); }
+  };
   void loop() {  // dr_mvsnet.cpp:83-93
     std::unique_lock<std::mutex> lk(mu_);
     while (running_) {
       if (unprocessed_) {
         try {
           DR_HIP(hipSetDevice(device_));
+          InFlight window(device_, prelaunched_);  // (counted from here, or from CallAsync's own launch, to the end of this block)
           if (prelaunched_) prelaunched_ = false;  // (CallAsync enqueued this window's forward itself: stage_inputs)
           else forward(nullptr);
           const size_t n = (size_t)H_ * W_ * 4;
@@ -1410,6 +1425,11 @@ class MvsEngine {
         for (int v = 0; v < V; ++v) if (v != miss) up_one(v, up_stream_);
         DR_HIP(hipEventRecord(ev_hits_, up_stream_));
       });
+      struct Count {  // this window counts as in flight from here; the worker's InFlight takes the count over once prelaunched_ is set
+        std::atomic<int> &n; bool handed_over = false;
+        explicit Count(std::atomic<int> &a) : n(a) { n.fetch_add(1, std::memory_order_relaxed); }
+        ~Count() { if (!handed_over) n.fetch_sub(1, std::memory_order_relaxed); }
+      } count(windows_in_flight(device_));
       try {
         defer_cache_io_ = true;
         forward(nullptr);
@@ -1423,6 +1443,7 @@ class MvsEngine {
         if (miss >= 0) DR_HIP(hipEventSynchronize(ev_h2d_));
       }
       prelaunched_ = true;
+      count.handed_over = true;
     } else {
     auto upload_views = [&, pinned](int v0) {  // views v0, v0 + 2, ...: gather into the staging block (unless page-locked already), then the copy engine
         DR_HIP(hipSetDevice(device_));
@@ -1462,7 +1483,11 @@ class MvsEngine {
       for (int s = 0; s < 3; ++s) set_batch_vfeat(s);
     }
     const bool cached = fc_fast_;  // FeatureNet answered by the feature cache: its ops are skipped
-    const bool fork = side_enabled_ && !ev && first == 0 && last >= ops_.size() && fork_lo_ < fork_hi_ && !cached;
+    // ... unless other engines of this process have windows in flight on the device: their kernels already fill the idle CUs, and a second stream per
+    // engine only adds queue contention (4 engines: 580 depth maps/s without the fork against 570 with it, profiles/r06_queues_side_stream.txt; alone: 2.150 ms
+    // with it against 2.165).  Same kernels in the same per-stream order either way: the result does not depend on it.
+    const bool alone = windows_in_flight(device_).load(std::memory_order_relaxed) <= 1;
+    const bool fork = side_enabled_ && alone && !ev && first == 0 && last >= ops_.size() && fork_lo_ < fork_hi_ && !cached;
     if (cached) forward_cached_features();
     // view shard, reduce-to-root form: between a stage's cost volume and its regression only rank 0 works
     const bool rooted = comm_ && shard_nsrc_ && !phase_mode_ && !sw_.shard_allreduce;

@@ -16,8 +16,8 @@ static void layer(const char *name, int D, int H, int W, int Cin, int Cout, int 
   ConvPlanOut P = plan_conv(L, mode, &in, D, H, W, Cin, &out, nullptr, 0, arena, 0);
   const ConvLaunch &c = P.launches.at(0);
   const char *kind = c.async == 2 ? (c.march.rm ? "rowmarch" : (c.march.wino ? "winomarch" : "march")) : (c.async == 4 ? "k_conv_w" : (c.async ? "k_conv_a" : "k_conv"));
-  printf("%-10s %2dx%3dx%3d %2d->%2d s%d%s  %-9s ci=%2d ct=%d pt=%d tile %dx%dx%-3d npass=%d grid=%ux%ux%u = %5u WG  lds=%3zu KB  %.2f GFLOP\n", name, D, H, W, Cin, Cout, sd, tr ? "T" : " ", kind, c.ci, c.ct,
-         c.pt, c.args.TZ, c.args.TY, c.args.TXT * 16, c.args.npass, c.grid.x, c.grid.y, c.grid.z, c.grid.x * c.grid.y * c.grid.z, c.lds_bytes >> 10, c.flops / 1e9);
+  printf("%-10s %2dx%3dx%3d %2d->%2d s%d%s  %-9s ci=%2d ct=%d pt=%d tile %dx%dx%-3d npass=%d grid=%ux%ux%u = %5u WG  lds=%3zu KB (%zu B, nuMax %d, halo %dx%dx%d)  %.2f GFLOP\n", name, D, H, W, Cin, Cout, sd, tr ? "T" : " ", kind, c.ci, c.ct,
+         c.pt, c.args.TZ, c.args.TY, c.args.TXT * 16, c.args.npass, c.grid.x, c.grid.y, c.grid.z, c.grid.x * c.grid.y * c.grid.z, c.lds_bytes >> 10, c.lds_bytes, c.args.nuMax, c.args.TZI, c.args.TYI, c.args.TXI, c.flops / 1e9);
 }
 int main() {
   const int Ds[3] = {48, 32, 8}, hs[3] = {120, 240, 480}, ws[3] = {160, 320, 640}, Cs[3] = {32, 16, 8};
