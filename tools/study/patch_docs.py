@@ -27,12 +27,12 @@ sub(r"640x480_5mm: \*\*\d+ keyframes/s\*\*; 640x480_10mm: \*\*\d+\*\*; `sliding_
     f"640x480_5mm: **{lp['640x480_5mm']['keyframes_per_s']:.0f} keyframes/s**; 640x480_10mm: **{lp['640x480_10mm']['keyframes_per_s']:.0f}**; `sliding_window` (new: each key frame drops the oldest image and adds a new one; 1 cm): {lp['sliding_window']['keyframes_per_s_cache_off']:.0f} without, **{lp['sliding_window']['keyframes_per_s_cache_on']:.0f} with the feature cache** (× {lp['sliding_window']['speedup']:.2f};")
 sub(r"\| `tracker` \| \d+ Gauss-Newton iterations/s \|", f"| `tracker` | {d['tracker']['gauss_newton_iterations_per_s']:.0f} Gauss-Newton iterations/s |")
 sub(r"\| \*\*\d+ depth maps/s\*\* \(4 engines\), single window [\d.]+ ms \(`profiles/r06_bench_shipped.json`\)", f"| **{sh['value']:.0f} depth maps/s** (4 engines), single window {sh['single_window_ms']:.3f} ms (`profiles/r06_bench_shipped.json`)")
-sub(r"≥ 600 depth maps/s: \*\*\d+ on the final run's box, 560–570 on the others\*\*", f"≥ 600 depth maps/s: **{d['value']:.0f} on the final run's box, 560–570 on the others**")
+sub(r"≥ 600 depth maps/s: \*\*\d+ on the final run's box, 578–580 on the others\*\*", f"≥ 600 depth maps/s: **{d['value']:.0f} on the final run's box, 578–580 on the others**")
 sub(r"Single window ≤ 2.0 ms: \*\*[\d.]+ ms in the final run \(2.14–2.16 on faster boxes\)\*\*", f"Single window ≤ 2.0 ms: **{d['single_window_ms']:.2f} ms in the final run (2.14–2.16 on faster boxes)**")
 open(p, 'w').write(s)
 p = root + '/README.md'; s = open(p).read()
-sub(r"\*\*\d+ depth maps/s\*\* at 640×480×7 views, planes 48/32/8, fp32 \(4 windows in flight; 560–570 on the round's other boxes, `profiles/r06_engines_in_flight.txt`; [\d.]+ ms for a",
-    f"**{d['value']:.0f} depth maps/s** at 640×480×7 views, planes 48/32/8, fp32 (4 windows in flight; 560–570 on the round's other boxes, `profiles/r06_engines_in_flight.txt`; {d['single_window_ms']:.2f} ms for a")
+sub(r"\*\*\d+ depth maps/s\*\* at 640×480×7 views, planes 48/32/8, fp32 \(4 windows in flight; 578–580 in the quick line on the round's other boxes, `profiles/r06_queues_side_stream.txt`; [\d.]+ ms for a",
+    f"**{d['value']:.0f} depth maps/s** at 640×480×7 views, planes 48/32/8, fp32 (4 windows in flight; 578–580 in the quick line on the round's other boxes, `profiles/r06_queues_side_stream.txt`; {d['single_window_ms']:.2f} ms for a")
 sub(r"views; [\d.]+ ms through `CallAsync`/`GetResult` with host buffers,\n[\d.]+ ms with page-locked images and result views\); \d+ /s \([\d.]+ ms\) for the shipped",
     f"views; {d['boundary_single_engine_ms']:.2f} ms through `CallAsync`/`GetResult` with host buffers,\n{d['boundary_pinned_single_engine_ms']:.2f} ms with page-locked images and result views); {sh['value']:.0f} /s ({sh['single_window_ms']:.2f} ms) for the shipped")
 sub(r"\n[\d.]+ ms per 640×480 frame into a 5 mm grid \([\d.]+ G voxels/s device-resident, [\d.]+ ms / [\d.]+ G voxels/s through",
