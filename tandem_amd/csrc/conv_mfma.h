@@ -71,6 +71,7 @@ struct ConvArgs {
   const float *zero16;  // 16 zero bytes: the source of every staged element outside the tensor
   int a_slots;          // 16-byte LDS slots per tile buffer (multiple of 512)
   int a_wbufs;          // weight buffers: npass when all passes fit (each fetched once per workgroup), else 2 (one per pass in flight)
+  int class_loop;       // k_conv, single-pass transposed layers: > 0 = the number of parity classes ONE workgroup walks on its staged tile (grid.y = 1), see k_conv
 };
 
 constexpr int kConvThreads = 256;
@@ -391,6 +392,74 @@ __global__ __launch_bounds__(kConvThreads, DR_KCONV_MIN_WAVES(CT, FZ)) void k_co
       float4 scv[CT], biv[CT];
       conv_load_affine<CT>(a, g, ct0, scv, biv);
       conv_epilogue<CT, PT>(a, cls, acc, scv, biv, wave, j, g, ct0, pz0, py0, px0);
+      return;
+    }
+  }
+  // CLASS LOOP (a.class_loop = number of parity classes; single-pass transposed layers: conv11).  With one class per workgroup a layer like stage 2's conv11 is
+  // 4800 workgroups whose life is three dependent round trips (weights + tile, barrier, residual operand) around 1.7 us of MFMA work: 0.072 ms, 0.050 of it with the
+  // MFMA loop compiled out (profiles/r06_strided_layers_ablation.txt).  Here a workgroup stages its tile ONCE and walks the classes on it, the NEXT class's weights
+  // streaming into the other weight buffer (LDS-DMA) under the current class's MFMA loop and epilogue: one exposed round trip per workgroup instead of one per class.
+  // Every class's tap table sits in LDS from the start.  Same tile values, same weights, same chunk order per output: bit-identical to the class-per-workgroup launch.
+  if constexpr (FZ == 0) {
+    if (a.class_loop > 0) {
+      const int ncls = a.class_loop, tstride = a.nuMax * TPC;
+      float4 *wb1 = wl + (size_t)a.nuMax * CT * 64;
+      int *tap_all = reinterpret_cast<int *>(wb1 + (size_t)a.nuMax * CT * 64);  // [ncls][nuMax * TPC], behind both weight buffers
+      for (int i = tid; i < ncls * tstride; i += kConvThreads) {
+        const int c = i / tstride, k = i - c * tstride;
+        tap_all[i] = k < a.cls[c].NU * TPC ? a.tapoff[a.cls[c].tap_base + k] * CIS : 0;
+      }
+      auto issue_w = [&](int c) {  // class c's packed weights -> buffer c & 1
+        float4 *wb = (c & 1) ? wb1 : wl;
+        const float4 *wsrc = a.wpk + a.cls[c].w_base + (size_t)ct0 * 64;
+        const int n = a.cls[c].NU * CT;
+        for (int e = wave; e < n; e += kConvThreads / 64) {
+          const int u = e / CT, ct = e - u * CT;
+          conv_a_dma16(wsrc + ((size_t)u * a.ctTot + ct) * 64 + lane, __builtin_amdgcn_readfirstlane(conv_a_lds_addr(wb + (size_t)e * 64)));
+        }
+      };
+      __builtin_amdgcn_s_setprio(2);
+      issue_w(0);
+      constexpr int kStageBatchC = 12;
+      for (unsigned e0 = 0; e0 < total; e0 += kConvThreads * kStageBatchC) {
+        float4 v[kStageBatchC];
+        int dst[kStageBatchC];
+#pragma unroll
+        for (int k = 0; k < kStageBatchC; ++k) {
+          const unsigned e = e0 + k * kConvThreads + tid;
+          const unsigned pos = e / C4, c4 = e - pos * C4;
+          const unsigned t = a.magicX ? __umulhi(pos, a.magicX) : pos, x = pos - t * a.TXI;
+          const unsigned z = a.magicY ? __umulhi(t, a.magicY) : t, y = t - z * a.TYI;
+          const int gz = iz0 + (int)z, gy = iy0 + (int)y, gx = ix0 + (int)x;
+          v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+          dst[k] = e < total ? (int)(pos * CIS + c4 * 4) : -1;
+          if (e < total && gz >= 0 && gz < a.inD && gy >= 0 && gy < a.inH && gx >= 0 && gx < a.inW)
+            v[k] = *reinterpret_cast<const float4 *>(a.in + (((size_t)gz * a.inH + gy) * a.inW + gx) * a.inC + c4 * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < kStageBatchC; ++k)
+          if (dst[k] >= 0) *reinterpret_cast<float4 *>(lds + dst[k]) = v[k];
+      }
+      float4 scv[CT], biv[CT];
+      conv_load_affine<CT>(a, g, ct0, scv, biv);
+      for (int c = 0; c < ncls; ++c) {
+        conv_a_wait_dma();  // class c's weights have landed (and, first time round, nothing else of this wave is in flight) ...
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();    // ... everybody's have, the tile and the tap tables are written, and every wave has left the buffer class c + 1 goes into
+        if (c + 1 < ncls) issue_w(c + 1);
+        const ConvClass cc = a.cls[c];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+          for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
+        const float4 *wc = (c & 1) ? wb1 : wl;
+        const int *tpc = tap_all + c * tstride + sub;
+        if constexpr (CT * PT <= 2) {
+          const float4 *wp = wc + lane;
+          conv_kloop_narrow<CT, PT>(tpc, TPC, cc.NU, acc, [&](int toff, int u, float4 (&av)[CT], float4 (&bv)[PT]) { conv_chunk_load<CT, PT>(lds, wp, toff, u, base, av, bv); });
+        } else conv_kloop<CT, PT>(lds, wc, tpc, TPC, cc.NU, lane, base, acc);
+        conv_epilogue<CT, PT>(a, cc, acc, scv, biv, wave, j, g, ct0, pz0, py0, px0);
+      }
       return;
     }
   }
@@ -1469,7 +1538,16 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   a.nuMax = nu_max;
   cl.lds_bytes = (size_t)TZI * TYI * TXI * CIS * 4 + (size_t)nu_max * CT * (bf3 ? 2048 : 1024) + (size_t)nu_max * TPC * 4 + 64;
   cl.bf3 = bf3 ? 1 : 0;
-  a.zero16 = nullptr; a.a_slots = 0; a.a_wbufs = 1;
+  a.zero16 = nullptr; a.a_slots = 0; a.a_wbufs = 1; a.class_loop = 0;
+  // k_conv's class loop (see the kernel): single-pass layers with several parity classes, both weight buffers and every class's tap table next to the tile
+  if (ASYNC == 0 && !bf3 && !fz && ncls > 1 && npass == 1 && !hook_env("DR_CONV_NO_CLASS_LOOP")) {
+    const size_t with_loop = cl.lds_bytes + (size_t)nu_max * CT * 1024 + (size_t)(ncls - 1) * nu_max * TPC * 4;
+    if (with_loop <= kConvMaxLds) {
+      a.class_loop = ncls;
+      cl.lds_bytes = with_loop;
+      cl.grid.y = 1;
+    }
+  }
   // k_conv with pipelined passes (see the kernel): small multi-pass layers on the one-position-tile instances whose tile is at most 6 loads per lane
   if (ASYNC == 0 && !bf3 && !fz && PT == 1 && CT <= 2 && npass >= 2 && (size_t)TZI * TYI * TXI * (CI / 4) <= 6 * kConvThreads && !hook_env("DR_CONV_NO_PIPE") &&
       cl.lds_bytes + (size_t)nu_max * CT * 1024 <= kConvMaxLds) {

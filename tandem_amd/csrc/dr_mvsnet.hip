@@ -1958,8 +1958,8 @@ int drm_debug_conv(int device, const float *in, int D, int H, int W, int Cin, co
     if (march_err) fail(DR_ERR_DEVICE, "k_conv_m: a ring wait gave up (code %d)", march_err);
     if (getenv("DR_CONV_PRINT")) {
       const ConvLaunch &c = P.launches.at(0);
-      fprintf(stderr, "debug_conv: %s<%d,%d,%d> nup %d tile %dx%dx%d lds %zu grid %ux%u (%d candidates)\n", (c.async == 2 ? (c.march.rm ? "rowmarch" : (c.march.wino ? "winomarch" : "march")) : (c.async == 4 ? "wino" : (c.async ? "async" : (c.bf3 ? "bf16x3" : "sync")))), c.ci, c.ct, c.pt,
-              c.nup, c.args.TZ, c.args.TY, c.args.TXT * 16, c.lds_bytes, c.grid.x, c.grid.z, P.ncand);
+      fprintf(stderr, "debug_conv: %s<%d,%d,%d> nup %d tile %dx%dx%d lds %zu grid %ux%u (%d candidates)%s\n", (c.async == 2 ? (c.march.rm ? "rowmarch" : (c.march.wino ? "winomarch" : "march")) : (c.async == 4 ? "wino" : (c.async ? "async" : (c.bf3 ? "bf16x3" : "sync")))), c.ci, c.ct, c.pt,
+              c.nup, c.args.TZ, c.args.TY, c.args.TXT * 16, c.lds_bytes, c.grid.x, c.grid.z, P.ncand, c.args.class_loop ? ", class loop" : "");
     }
     DR_HIP(hipMemcpy(out, d_out, on * 4, hipMemcpyDeviceToHost));
     if (out_dims) { out_dims[0] = oD; out_dims[1] = oH; out_dims[2] = oW; }

@@ -254,6 +254,42 @@ def test_transposed_parity_forms(case, form, monkeypatch, parity_hooks):
         run_case(case)
 
 
+# ---- k_conv's class loop (single-pass transposed layers: one workgroup walks the parity classes on one staged tile, the next class's weights in flight)
+# against the class-per-workgroup launch of the same plan: same bits, every plan candidate.
+CLASS_LOOP = [
+    ("class loop 16->8 +skip (conv11's shape)", (6, 20, 48), 16, 8, (3, 3, 3), (2, 2, 2), True, True, "same"),
+    ("class loop 16->8 ragged", (3, 7, 21), 16, 8, (3, 3, 3), (2, 2, 2), True, True, "same"),
+    ("class loop 8->8 no skip", (4, 9, 33), 8, 8, (3, 3, 3), (2, 2, 2), True, False, "none"),
+    ("class loop 16->16 one plane", (1, 12, 40), 16, 16, (3, 3, 3), (2, 2, 2), True, True, "same"),
+]
+
+
+@pytest.mark.parametrize("case", CLASS_LOOP, ids=[c[0] for c in CLASS_LOOP])
+def test_class_loop_is_bit_identical(case, monkeypatch, parity_hooks, capfd):
+    from tandem_amd.dr_mvsnet import debug_conv
+    name, dims, cin, cout, k, stride, transposed, relu, add_mode = case
+    rng = np.random.RandomState(abs(hash(name)) % (2 ** 31))
+    x = rng.randn(*dims, cin).astype(np.float32)
+    w = (rng.randn(cin, cout, *k) / np.sqrt(cin * np.prod(k))).astype(np.float32)
+    scale = (1.0 + 0.3 * rng.randn(cout)).astype(np.float32)
+    bias = (0.2 * rng.randn(cout)).astype(np.float32)
+    add = rng.randn(*(d * 2 for d in dims), cout).astype(np.float32) if add_mode == "same" else None
+    ref = torch_ref(x, w, stride, transposed, scale, bias, relu, add, add_mode)
+    looped = 0
+    for rank in range(0, 40, 2):
+        monkeypatch.setenv("DR_CONV_RANK", str(rank))
+        monkeypatch.setenv("DR_CONV_PRINT", "1")
+        monkeypatch.delenv("DR_CONV_NO_CLASS_LOOP", raising=False)
+        a = debug_conv(x, w, stride, transposed, scale, bias, relu, add, False)
+        looped += "class loop" in capfd.readouterr().err
+        monkeypatch.setenv("DR_CONV_NO_CLASS_LOOP", "1")
+        b = debug_conv(x, w, stride, transposed, scale, bias, relu, add, False)
+        assert "class loop" not in capfd.readouterr().err
+        assert np.array_equal(a, b), f"{name}, candidate {rank}: class loop differs from class per workgroup (max {np.abs(a - b).max():.3e})"
+        assert np.abs(a - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    assert looped > 0, "no candidate took the class loop"
+
+
 # ---- ConvLayer::up2: a 3x3 layer over the nearest x2 upsampling of its (half-resolution) input, as 2 x 2-tap phase convolutions
 # with summed kernel entries (conv_mfma.h axis_classes_up2) -- the second half of the folded out.stage3 (FeatureNet).
 UP2 = [
