@@ -410,12 +410,12 @@ __global__ __launch_bounds__(kConvThreads, DR_KCONV_MIN_WAVES(CT, FZ)) void k_co
         tap_all[i] = k < a.cls[c].NU * TPC ? a.tapoff[a.cls[c].tap_base + k] * CIS : 0;
       }
       auto issue_w = [&](int c) {  // class c's packed weights -> buffer c & 1
-        float4 *wb = (c & 1) ? wb1 : wl;
+        const unsigned wb = conv_a_lds_addr(wl) + (unsigned)(c & 1) * (unsigned)a.nuMax * CT * 1024u;  // (LDS byte address; an address-space cast of a SELECTED pointer trips hipcc -O2)
         const float4 *wsrc = a.wpk + a.cls[c].w_base + (size_t)ct0 * 64;
         const int n = a.cls[c].NU * CT;
         for (int e = wave; e < n; e += kConvThreads / 64) {
           const int u = e / CT, ct = e - u * CT;
-          conv_a_dma16(wsrc + ((size_t)u * a.ctTot + ct) * 64 + lane, __builtin_amdgcn_readfirstlane(conv_a_lds_addr(wb + (size_t)e * 64)));
+          conv_a_dma16(wsrc + ((size_t)u * a.ctTot + ct) * 64 + lane, __builtin_amdgcn_readfirstlane(wb + (unsigned)e * 1024u));
         }
       };
       __builtin_amdgcn_s_setprio(2);

@@ -32,7 +32,8 @@ static bool emulate(const ConvLaunch &c, const float *in, float *out, const floa
   const int RB = (CI + 4) * 4, LO = 2 * CI;
   std::vector<unsigned char> tileb(c.bf3 ? (size_t)NP * RB : 0, 0xff);
   const unsigned short *wpb = reinterpret_cast<const unsigned short *>(a.wpk);
-  for (unsigned ic = 0; ic < c.grid.y; ++ic) {
+  const unsigned ncls = a.class_loop > 0 ? (unsigned)a.class_loop : c.grid.y;  // (class loop: one workgroup walks the classes, grid.y = 1)
+  for (unsigned ic = 0; ic < ncls; ++ic) {
     const ConvClass &cls = a.cls[ic];
     for (unsigned bz = 0; bz < c.grid.z; ++bz) {
       const int ct0 = (int)bz * CT;
@@ -418,7 +419,7 @@ static int run_case(const Case &cs, int max_plans) {
     for (size_t i = 0; i < on; ++i) worst = std::max(worst, (double)std::fabs(out[i] - ref[i]) / (1.0 + std::fabs(ref[i])));
     const bool pass = ok && worst < (c.bf3 ? 1e-4 : 2e-5) && (c.bf3 != 0) == (conv_bf3_policy() && cs.Cin % 8 == 0);  // (bf16 x 3: the dropped w_l x_l term and the lo terms' rounding, ~2^-16 per product)
     printf("%-26s plan rank %3d %s ci=%d ct=%d pt=%d tile %dx%dx%d classes %u rows %d: %s (max rel err %.2e)\n", cs.name, rank, c.async == 4 ? "k_conv_w" : (c.async ? "k_conv_a" : (c.bf3 ? "k_conv_b" : "k_conv")), c.ci, c.ct, c.pt, c.args.TZ, c.args.TY,
-           c.args.TXT * 16, c.grid.y, c.args.rows_valid, pass ? "ok" : "FAIL", worst);
+           c.args.TXT * 16, c.args.class_loop > 0 ? (unsigned)c.args.class_loop : c.grid.y, c.args.rows_valid, pass ? "ok" : "FAIL", worst);
     ++done;
     if (!pass) ++fails;
   }
