@@ -292,8 +292,10 @@ __device__ inline unsigned conv_a_lds_addr(const void *p) {
 #else
 #define DR_KCONV_MIN_WAVES(CT, FZ) ((CT) == 1 && (FZ) == 0 ? 4 : 1)
 #endif
-template <int CI, int CT, int PT, int FZ = 0>
-__global__ __launch_bounds__(kConvThreads, DR_KCONV_MIN_WAVES(CT, FZ)) void k_conv(const ConvArgs a) {
+// (the body of k_conv and of k_conv_c, its class-loop form: two kernels so that the class loop's code does not sit in the instances that never take it --
+// inside one kernel it cost conv9's instance <16,2,4> 25 %, 0.031 -> 0.039 ms, without ever running there)
+template <int CI, int CT, int PT, int FZ, bool CL>
+__device__ __forceinline__ void conv_tile_body(const ConvArgs &a) {
   extern __shared__ float4 lds4[];
   float *lds = reinterpret_cast<float *>(lds4);
   constexpr int CIS = CI + 4;  // LDS floats per staged position (+4: spreads b128 reads over bank slots)
@@ -400,8 +402,8 @@ __global__ __launch_bounds__(kConvThreads, DR_KCONV_MIN_WAVES(CT, FZ)) void k_co
   // MFMA loop compiled out (profiles/r06_strided_layers_ablation.txt).  Here a workgroup stages its tile ONCE and walks the classes on it, the NEXT class's weights
   // streaming into the other weight buffer (LDS-DMA) under the current class's MFMA loop and epilogue: one exposed round trip per workgroup instead of one per class.
   // Every class's tap table sits in LDS from the start.  Same tile values, same weights, same chunk order per output: bit-identical to the class-per-workgroup launch.
-  if constexpr (FZ == 0) {
-    if (a.class_loop > 0) {
+  if constexpr (CL) {
+    {
       const int ncls = a.class_loop, tstride = a.nuMax * TPC;
       float4 *wb1 = wl + (size_t)a.nuMax * CT * 64;
       int *tap_all = reinterpret_cast<int *>(wb1 + (size_t)a.nuMax * CT * 64);  // [ncls][nuMax * TPC], behind both weight buffers
@@ -607,6 +609,16 @@ __global__ __launch_bounds__(kConvThreads, DR_KCONV_MIN_WAVES(CT, FZ)) void k_co
   conv_load_affine<CT>(a, g, ct0, scv, biv);
   conv_epilogue<CT, PT>(a, cls, acc, scv, biv, wave, j, g, ct0, pz0, py0, px0);
 }
+template <int CI, int CT, int PT, int FZ = 0>
+__global__ __launch_bounds__(kConvThreads, DR_KCONV_MIN_WAVES(CT, FZ)) void k_conv(const ConvArgs a) {
+  conv_tile_body<CI, CT, PT, FZ, false>(a);
+}
+// k_conv_c: k_conv's CLASS LOOP form (a.class_loop parity classes per workgroup, grid.y = 1), under k_conv's register bound
+template <int CI, int CT, int PT>
+__global__ __launch_bounds__(kConvThreads, DR_KCONV_MIN_WAVES(CT, 0)) void k_conv_c(const ConvArgs a) {
+  conv_tile_body<CI, CT, PT, 0, true>(a);
+}
+inline bool conv_c_instance_exists(int ci, int ct, int pt) { return (ci == 8 || ci == 16) && (ct == 1 || ct == 2) && (pt == 1 || pt == 4); }
 
 #ifdef DR_PARITY_HOOKS  // the bf16 x 3 precision mode is not fp32 arithmetic and never the product's: its kernel is built into the parity library only
 #include "conv_bf3.h"  // k_conv_b: k_conv on the bf16 matrix cores with three-term split operands (DR_CONV_BF16X3=1)
@@ -1540,7 +1552,7 @@ inline ConvPlanOut plan_conv(const ConvLayer &L, ConvMode mode, const float *in,
   cl.bf3 = bf3 ? 1 : 0;
   a.zero16 = nullptr; a.a_slots = 0; a.a_wbufs = 1; a.class_loop = 0;
   // k_conv's class loop (see the kernel): single-pass layers with several parity classes, both weight buffers and every class's tap table next to the tile
-  if (ASYNC == 0 && !bf3 && !fz && ncls > 1 && npass == 1 && !hook_env("DR_CONV_NO_CLASS_LOOP")) {
+  if (ASYNC == 0 && !bf3 && !fz && ncls > 1 && npass == 1 && conv_c_instance_exists(CI, CT, PT) && !hook_env("DR_CONV_NO_CLASS_LOOP")) {
     const size_t with_loop = cl.lds_bytes + (size_t)nu_max * CT * 1024 + (size_t)(ncls - 1) * nu_max * TPC * 4;
     if (with_loop <= kConvMaxLds) {
       a.class_loop = ncls;
@@ -1639,6 +1651,12 @@ inline void launch_conv_b_inst(const ConvLaunch &c, hipStream_t st) {
 }
 #endif
 template <int CI, int CT, int PT>
+inline void launch_conv_c_inst(const ConvLaunch &c, hipStream_t st) {
+  static std::atomic<unsigned long long> done{0};
+  conv_allow_big_lds(reinterpret_cast<const void *>(&k_conv_c<CI, CT, PT>), done, c.lds_bytes);
+  hipLaunchKernelGGL((k_conv_c<CI, CT, PT>), c.grid, dim3(kConvThreads), c.lds_bytes, st, c.args);
+}
+template <int CI, int CT, int PT>
 inline void launch_conv_a_inst(const ConvLaunch &c, hipStream_t st) {
   static std::atomic<unsigned long long> done{0};
   conv_allow_big_lds(reinterpret_cast<const void *>(&k_conv_a<CI, CT, PT>), done, c.lds_bytes);
@@ -1733,6 +1751,20 @@ inline void launch_conv(const ConvLaunch &c, hipStream_t st) {
     return;
   }
 #endif
+  if (c.args.class_loop > 0) {
+#define DR_CONV_C_CASE(CI_, CT_)                                                \
+  if (c.ci == CI_ && c.ct == CT_) {                                             \
+    if (c.pt == 4) launch_conv_c_inst<CI_, CT_, 4>(c, st);                      \
+    else launch_conv_c_inst<CI_, CT_, 1>(c, st);                                \
+    return;                                                                     \
+  }
+    DR_CONV_C_CASE(8, 1)
+    DR_CONV_C_CASE(8, 2)
+    DR_CONV_C_CASE(16, 1)
+    DR_CONV_C_CASE(16, 2)
+#undef DR_CONV_C_CASE
+    fail(DR_ERR_ARG, "launch_conv: no class-loop instance CI=%d CT=%d PT=%d", c.ci, c.ct, c.pt);
+  }
 #define DR_CONV_CASE(CI_, CT_)                                                  \
   if (c.ci == CI_ && c.ct == CT_) {                                             \
     if (c.pt == 4) launch_conv_inst<CI_, CT_, 4>(c, st);                        \

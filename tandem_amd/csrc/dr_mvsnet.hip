@@ -609,6 +609,7 @@ class MvsEngine {
       else if (o.kind == Op::CONV && o.conv.async == 4) snprintf(kn, sizeof kn, "k_conv_w<%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt);
       else if (o.kind == Op::CONV && o.conv.async) snprintf(kn, sizeof kn, "k_conv_a<%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt);
       else if (o.kind == Op::CONV && o.conv.bf3) snprintf(kn, sizeof kn, "k_conv_b<%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt);
+      else if (o.kind == Op::CONV && o.conv.args.class_loop > 0) snprintf(kn, sizeof kn, "k_conv_c<%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt);
       else if (o.kind == Op::CONV) snprintf(kn, sizeof kn, "k_conv<%d,%d,%d,%d>", o.conv.ci, o.conv.ct, o.conv.pt, o.conv.fz);
       else if (o.kind == Op::COSTVOL) {
         const CostVolArgs &ca = cv_[o.stage - 1];
